@@ -1,0 +1,435 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs ONLY in the build container, never on the GPU box).
+
+Imports the reference's EDaGe-PP modules *unmodified* from /root/reference/EDaGe-PP and
+records their inputs/outputs under fixed seeds as small .npz/.json fixtures next to this
+script.  Absent third-party modules are replaced by `sys.modules` stubs:
+
+  cv2, imgviz            -> empty modules (imported, never called on the recorded paths)
+  torchvision            -> ToTensor = u8 HWC / PIL -> f32 CHW / 255 ; RandomRotation and
+                            functional.affine = identity ; utils.save_image = no-op ;
+                            Resize / ToPILImage = identity
+
+so every *non-raster* quantity recorded here is a genuine reference result; the rotated /
+resampled rasters (`Path.Space`, the JPEG occupancy image) are NOT recorded because the
+stubs make them meaningless (torchvision / libjpeg rasters are "parity unpinned").
+
+Nothing from the reference is copied: fixtures hold numbers only.
+
+    python tests/golden/make_fixtures.py        # rewrites tests/golden/*.npz
+"""
+import io
+import json
+import os
+import signal
+import sys
+import tempfile
+import types
+import contextlib
+
+import numpy as np
+import torch
+
+REF = "/root/reference/EDaGe-PP"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ----------------------------------------------------------------------------- stubs
+def _install_stubs():
+    from PIL import Image
+
+    def to_tensor(pic):
+        if isinstance(pic, Image.Image):
+            a = np.asarray(pic)
+        else:
+            a = np.asarray(pic)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+        if t.dtype == torch.uint8:
+            t = t.float() / 255.0
+        return t
+
+    class ToTensor:
+        def __call__(self, pic):
+            return to_tensor(pic)
+
+    class Identity:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, x):
+            return x
+
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional")
+    tvu = types.ModuleType("torchvision.utils")
+    tvt.ToTensor = ToTensor
+    tvt.RandomRotation = Identity
+    tvt.Resize = Identity
+    tvt.ToPILImage = Identity
+    tvt.CenterCrop = Identity
+    tvf.affine = lambda img, **k: img
+    tvt.functional = tvf
+    tvu.save_image = lambda *a, **k: None
+    tv.transforms = tvt
+    tv.utils = tvu
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tvt
+    sys.modules["torchvision.transforms.functional"] = tvf
+    sys.modules["torchvision.utils"] = tvu
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    sys.modules["imgviz"] = types.ModuleType("imgviz")
+    import matplotlib
+    matplotlib.use("Agg")
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def _f64(x):
+    return np.asarray(x, dtype=np.float64)
+
+
+class RefHang(Exception):
+    pass
+
+
+@contextlib.contextmanager
+def time_limit(seconds):
+    """The reference has unbounded loops (Path.py:478 `while sum(obs_size) < size_max`,
+    MapGenerate.py:58-62 up to 1e6 retries); a case that does not finish is skipped and listed."""
+    def handler(signum, frame):
+        raise RefHang()
+    old = signal.signal(signal.SIGALRM, handler)
+    signal.alarm(seconds)
+    try:
+        yield
+    finally:
+        signal.alarm(0)
+        signal.signal(signal.SIGALRM, old)
+
+
+# ----------------------------------------------------------------------------- G1
+def fixture_pathseg(PathSegMod):
+    out = {}
+    for seed in (0, 1, 2, 7):
+        for forced in (False, True):
+            np.random.seed(seed)
+            st = np.random.get_state()
+            seg = PathSegMod.PathSeg(polyorder=4, dim=2, is_straight=forced)
+            seg.random()
+            st2 = np.random.get_state()
+            # replay the raw draws that were consumed
+            np.random.set_state(st)
+            n = (0 if forced else 1) + 1000 + 1
+            draws = np.random.random(n)
+            assert np.random.get_state()[2] == st2[2]
+            k = f"s{seed}_f{int(forced)}"
+            out[k + "_draws"] = draws
+            out[k + "_poly"] = _f64(seg.Poly)
+            out[k + "_endpoint"] = _f64(seg.EndPoint).reshape(-1)
+            out[k + "_translation"] = _f64(seg.Translation).reshape(-1)
+            out[k + "_grad"] = _f64([np.ravel(seg.GradSt)[0], np.ravel(seg.GradEnd)[0]])
+            out[k + "_length"] = _f64(seg.Length).reshape(-1)
+            out[k + "_straight"] = np.array([int(seg.is_straight)])
+    np.savez_compressed(os.path.join(OUT, "g1_pathseg.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- G2..G8
+def run_path(PathMod, seed, R, clearance, is_straight, map_size=50, tseed=None):
+    """One full reference Path: generate -> draw_boundary -> path_obstacles (stubbed rasters)."""
+    np.random.seed(seed)
+    torch.manual_seed(seed if tseed is None else tseed)
+    st = np.random.get_state()
+    rec = {}
+    with quiet():
+        p = PathMod.Path(seg_num=10, poly_order=4, dim=2, clearance=clearance, is_straight=is_straight)
+        p.generate(show_now=False)
+        rec["seg_poly"] = _f64([s.Poly for s in p.PathSeg])
+        rec["seg_endpoint"] = _f64([np.ravel(s.EndPoint)[0] for s in p.PathSeg])
+        rec["seg_straight"] = np.array([int(s.is_straight) for s in p.PathSeg])
+        rec["seg_rotation"] = _f64([float(s.Rotation) for s in p.PathSeg])
+        rec["seg_translation"] = _f64([np.ravel(s.Translation) for s in p.PathSeg])
+        rec["seg_length"] = _f64([np.ravel(s.Length)[0] for s in p.PathSeg])
+        rec["segpoint"] = _f64(p.SegPoint)
+        rec["pathpoint_world"] = _f64(p.PathPoint)
+        rec["length"] = _f64(p.Length).reshape(-1)
+        # number of numpy draws consumed by generate()
+        st2 = np.random.get_state()
+        np.random.set_state(st)
+        n_straight = int(rec["seg_straight"].sum())
+        n = 10 * 1001 + (0 if is_straight else 10)
+        rec["draws"] = np.random.random(n)
+        assert np.random.get_state()[2] == st2[2] and (np.random.get_state()[1] == st2[1]).all()
+
+        p.draw_boundary(show_now=False)
+        rec["boundarypoint_world"] = _f64(p.BoundaryPoint)
+        rec["up_dir"] = _f64(p.Boundary.upboundary.direction)
+        rec["up_point"] = _f64(p.Boundary.upboundary.point)
+        rec["down_point"] = _f64(p.Boundary.downboundary.point)
+        rec["init_boundary"] = _f64(p.Boundary.initboundary)
+        rec["end_boundary"] = _f64(p.Boundary.endboundary)
+
+        # --- path_space pieces, called the way Path.path_space does (Path.py:113-142)
+        p.Resolution, p.MapSize, p.MapOffset = R, map_size, R / 2
+        space = torch.zeros([R * 2, R * 2])
+        step_len = 1 / R * map_size
+        dis = 0.8 * clearance / step_len
+        B = p.Boundary
+        for i in range(50):
+            d = -step_len * B.initboundary[i] / np.linalg.norm(B.initboundary[i])
+            space = p.free_space_bydirection(space, B.initboundary[i], d, dis, mapoffset=R)
+        for i in range(50):
+            v = np.reshape(p.EndPoint, [2]) - B.endboundary[i]
+            d = step_len * v / np.linalg.norm(v)
+            space = p.free_space_bydirection(space, B.endboundary[i], d, dis, mapoffset=R)
+        for i in range(10):
+            for j in range(50):
+                space = p.free_space_bydirection(space, B.upboundary.point[i][j], step_len * B.upboundary.direction[i][j], dis, mapoffset=R)
+        for i in range(10):
+            for j in range(50):
+                space = p.free_space_bydirection(space, B.downboundary.point[i][j], step_len * B.downboundary.direction[i][j], dis, mapoffset=R)
+        nz = torch.nonzero(space).numpy().astype(np.int32)
+        rec["canvas_nz"] = nz
+        assert set(np.unique(space.numpy())) <= {0.0, 255.0}
+
+    # fresh object for the real call chain (path_obstacles consumes no numpy draws)
+    np.random.seed(seed)
+    torch.manual_seed(seed if tseed is None else tseed)
+    with quiet():
+        p = PathMod.Path(seg_num=10, poly_order=4, dim=2, clearance=clearance, is_straight=is_straight)
+        p.generate(show_now=False)
+        p.draw_boundary(show_now=False)
+        # hull in scipy's order before normalisation
+        p.Resolution, p.MapSize, p.MapOffset = R, map_size, R / 2
+        hull_pts, hull_c = p.convexhull()
+        rec["hull_raw"] = _f64(hull_pts.numpy())
+        tstate = torch.get_rng_state()
+        ok = p.path_obstacles(resolution=R, map_size=map_size, map_offset=R / 2)
+        # torch draws consumed by set_obstacles: replay a generous prefix
+        tstate2 = torch.get_rng_state()
+        torch.set_rng_state(tstate)
+        rec["torch_draws"] = np.array([torch.rand(1).item() for _ in range(600)], dtype=np.float32)
+        torch.set_rng_state(tstate2)
+    rec["ok"] = np.array([int(bool(ok))])
+    rec["rotation"] = _f64(p.Rotation).reshape(-1)
+    rec["translation"] = _f64([float(p.Translation[0]), float(p.Translation[1])])
+    rec["hull_norm"] = _f64(np.asarray(p.ConvexHull))
+    rec["segpoint_image"] = _f64(p.SegPointImage)
+    rec["pathpoint_image"] = _f64(np.asarray(p.PathPoint))
+    rec["boundarypoint_image"] = _f64(p.BoundaryPoint)
+    obs = [[float(o[0]), float(o[1]), float(o[2])] for o in p.obstacles]
+    rec["obstacles"] = _f64(obs).reshape(-1, 3)
+    # isles: recover slice bounds by re-running search_isle (pure function of PathPoint/ConvexHull)
+    if not is_straight:
+        with quiet():
+            isles = p.search_isle()
+        pp = np.asarray(p.PathPoint)
+        bounds = []
+        for isle in isles:
+            a = np.asarray(isle)
+            n = len(a)
+            found = None
+            for s in range(0, len(pp) - n + 1):
+                if np.array_equal(pp[s:s + n], a):
+                    found = s
+                    break
+            assert found is not None
+            bounds.append([found, found + n])
+        rec["isle_bounds"] = np.array(bounds, dtype=np.int32).reshape(-1, 2)
+    else:
+        rec["isle_bounds"] = np.zeros((0, 2), np.int32)
+    return rec, p
+
+
+def fixture_paths(PathMod):
+    cases = [
+        # (seed, R, clearance, straight)
+        (0, 64, 3, False), (1, 64, 3, False), (2, 64, 1, False),
+        (0, 224, 1, False), (3, 224, 3, False),
+        (0, 256, 3, False), (1, 256, 3, False), (4, 256, 1, False), (5, 256, 3, True),
+        (6, 128, 3, False), (8, 64, 3, False), (9, 256, 3, False),
+    ]
+    out = {}
+    names = []
+    hung = []
+    for (seed, R, c, straight) in cases:
+        name = f"s{seed}_R{R}_c{c}_st{int(straight)}"
+        try:
+            with time_limit(40):
+                rec, _ = run_path(PathMod, seed, R, c, straight)
+        except RefHang:
+            hung.append(name)
+            print("reference did not terminate:", name, flush=True)
+            continue
+        print("path case", name, "ok", flush=True)
+        names.append(name)
+        for k, v in rec.items():
+            out[f"{name}/{k}"] = v
+    out["cases"] = np.array(names)
+    out["reference_nonterminating"] = np.array(hung)
+    np.savez_compressed(os.path.join(OUT, "g2_paths.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- G9
+def fixture_boundary_check(PathMod):
+    for seed in (11, 12, 13, 14):
+        try:
+            with time_limit(40):
+                rec, p = run_path(PathMod, seed, 256, 3, False)
+            break
+        except RefHang:
+            print("boundary_check fixture: reference did not terminate for seed", seed, flush=True)
+    rng = np.random.RandomState(123)
+    angles = rng.random_sample(1000) * 360 - 180
+    trans = np.array(rng.random_sample((1000, 2)) * 256 - 128, dtype=int)
+    oks = []
+    hulls = []
+    for a, t in zip(angles, trans):
+        ok, h = p.boundary_check(-np.array([a]), [t[1], t[0]])
+        oks.append(int(ok))
+        hulls.append(np.asarray(h))
+    np.savez_compressed(os.path.join(OUT, "g9_boundary_check.npz"),
+                        hull_norm=rec["hull_norm"], angles=angles, trans=trans,
+                        ok=np.array(oks, np.int8), hull_out=_f64(hulls[:16]),
+                        R=np.array([256]))
+
+
+# ----------------------------------------------------------------------------- G10 / config 1
+def fixture_mapgenerate(MapGenMod):
+    """Config 1: np.random.seed(0); torch.manual_seed(0); MapGenerate(10, 64, 50, 5, 20, 3).generate(100)."""
+    captured = []
+
+    def fake_plot_obstacles(size, obstacles, resolution=(224, 224)):
+        captured.append([[float(o[0]), float(o[1]), float(o[2])] for o in obstacles])
+        return torch.ones([3, resolution[0], resolution[1]])
+
+    MapGenMod.plot_obstacles = fake_plot_obstacles
+    R = 64
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        np.random.seed(0)
+        torch.manual_seed(0)
+        MapGenMod.cnt = 0
+        with quiet():
+            mg = MapGenMod.MapGenerate(path_num=10, resolution=R, map_size=50, obstacles_size=5,
+                                       obstacles_num=20, clearance=3)
+            # stage-A summaries for each target path
+            stageA = {}
+            for j, tp in enumerate(mg.PathGroup.TargetPaths):
+                stageA[f"p{j}/hull_norm"] = _f64(np.asarray(tp.ConvexHull))
+                stageA[f"p{j}/segpoint_image"] = _f64(tp.SegPointImage)
+                stageA[f"p{j}/pathpoint_image"] = _f64(np.asarray(tp.PathPoint))
+                stageA[f"p{j}/obstacles"] = _f64([[float(o[0]), float(o[1]), float(o[2])] for o in tp.obstacles]).reshape(-1, 3)
+                stageA[f"p{j}/length"] = _f64(tp.Length).reshape(-1)
+                stageA[f"p{j}/straight"] = np.array([int(tp.is_straight)])
+                stageA[f"p{j}/rotation"] = _f64(tp.Rotation).reshape(-1)
+                stageA[f"p{j}/translation"] = _f64([float(tp.Translation[0]), float(tp.Translation[1])])
+            mg.generate(map_num=100, folder_path=os.path.join(tmp, "out"), round_index=0)
+        with open("unsolved_problems.txt") as f:
+            problems = [json.loads(l) for l in f]
+    finally:
+        os.chdir(cwd)
+    assert len(mg.MapLabel) == 100 and len(problems) == 100 and len(captured) == 100
+    out = dict(stageA)
+    out["angle"] = _f64([np.ravel(l[1])[0] for l in mg.MapLabel])
+    out["translation"] = np.array([[int(l[2][0]), int(l[2][1])] for l in mg.MapLabel], dtype=np.int64)
+    out["segpoint"] = _f64([l[3] for l in mg.MapLabel])
+    out["pathpoint"] = _f64([l[4] for l in mg.MapLabel])
+    out["n_obs"] = np.array([len(c) for c in captured], dtype=np.int32)
+    out["obstacles"] = _f64([o for c in captured for o in c]).reshape(-1, 3)
+    out["problem_index"] = np.array([p["Index"] for p in problems])
+    out["problem_length"] = _f64([p["Length"] for p in problems])
+    out["problem_init"] = _f64([p["Init"] for p in problems])
+    out["problem_end"] = _f64([p["End"] for p in problems])
+    # final numpy RNG position: lets the oracle prove it consumed exactly the same stream
+    out["np_next_draws"] = np.random.random(4)
+    np.savez_compressed(os.path.join(OUT, "g10_config1_R64.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- G11 / G12
+def fixture_plan_tail(PM):
+    rng = np.random.RandomState(5)
+    # collision_check_circle_edge on random segments x obstacle sets
+    S, E, OBS, HIT = [], [], [], []
+    nob = []
+    for t in range(400):
+        K = int(rng.randint(1, 30))
+        obs = np.concatenate([rng.random_sample((K, 2)) * 224, rng.random_sample((K, 1)) * 18], axis=1)
+        s = rng.random_sample(2) * 240 - 8
+        e = s + (rng.random_sample(2) - 0.5) * 60
+        s32 = torch.tensor(s, dtype=torch.float32)
+        e32 = torch.tensor(e, dtype=torch.float32)
+        with quiet():
+            hit = PM.collision_check_circle_edge(s32, e32, [list(o) for o in obs], 1 / 50 * 224)
+        S.append(s32.numpy()); E.append(e32.numpy()); OBS.append(obs); HIT.append(int(bool(hit))); nob.append(K)
+    np.savez_compressed(os.path.join(OUT, "g11_collision.npz"), s=np.array(S), e=np.array(E),
+                        obs=np.concatenate(OBS, 0), n_obs=np.array(nob, np.int32), hit=np.array(HIT, np.int8),
+                        clearance=np.array([1 / 50 * 224]))
+
+    # extract_path on synthetic heat maps (a smooth ridge along a curve)
+    from PIL import Image
+    out = {}
+    ncase = 0
+    for t in range(12):
+        R = 224 if t % 2 == 0 else 256
+        yy, xx = np.mgrid[0:R, 0:R].astype(np.float64)
+        # ridge: quadratic bezier from init to end through a random control point
+        init = rng.random_sample(2) * (R * 0.3) + R * 0.1
+        end = rng.random_sample(2) * (R * 0.3) + R * 0.6
+        ctrl = rng.random_sample(2) * R * 0.8 + R * 0.1
+        ts = np.linspace(0, 1, 400)[:, None]
+        curve = (1 - ts) ** 2 * init + 2 * ts * (1 - ts) * ctrl + ts ** 2 * end
+        d2 = np.min((yy[None] - curve[:, 0, None, None]) ** 2 + (xx[None] - curve[:, 1, None, None]) ** 2, axis=0)
+        heat = np.exp(-d2 / (2 * 4.0 ** 2))
+        if t >= 10:
+            heat[:] = 0  # failure case: all-zero candidates
+        img = (heat * 255).astype(np.uint8)
+        with quiet():
+            ok, path = PM.extract_path(Image.fromarray(img, mode="L"), init_state=init, end_state=end, down_sample_rate=2)
+        out[f"c{ncase}_img"] = img
+        out[f"c{ncase}_init"] = init
+        out[f"c{ncase}_end"] = end
+        out[f"c{ncase}_ok"] = np.array([int(bool(ok))])
+        out[f"c{ncase}_path"] = path.numpy().astype(np.float64) if ok else np.zeros((0, 2))
+        ncase += 1
+    out["ncase"] = np.array([ncase])
+    np.savez_compressed(os.path.join(OUT, "g11_extract_path.npz"), **out)
+
+    # add_init_end_single on a zero image
+    img = torch.zeros([3, 64, 64])
+    res = PM.add_init_end_single(img, np.array([3.4, 61.5]), np.array([30.5, 31.5]))
+    np.savez_compressed(os.path.join(OUT, "g12_init_end.npz"), out=res.numpy().astype(np.float32),
+                        init=np.array([3.4, 61.5]), end=np.array([30.5, 31.5]))
+
+
+def main():
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import PathSeg as PathSegMod
+    import Path as PathMod
+    fixture_pathseg(PathSegMod)
+    fixture_paths(PathMod)
+    fixture_boundary_check(PathMod)
+    import MapGenerate as MapGenMod
+    try:
+        with time_limit(1500):
+            fixture_mapgenerate(MapGenMod)
+    except RefHang:
+        print("config-1 fixture: reference did not terminate within 1500 s (seed 0)", flush=True)
+    import process_map as PM
+    fixture_plan_tail(PM)
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
