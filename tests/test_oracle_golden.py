@@ -1,0 +1,250 @@
+"""Pins the CPU oracle (oracle/edage_np.py, oracle/philox_np.py) against golden vectors captured
+from the reference's own EDaGe-PP modules (tests/golden/make_fixtures.py).  CPU only.
+
+Tolerances: the reference and the oracle run the same NumPy here, so most quantities agree
+bit for bit; 1e-11 absolute (pixels / world units) absorbs torch.mean-vs-numpy summation order
+in the hull centre (Path.py:167).  Integer results (canvas pixel set, hull vertices, isle slice
+bounds, accept masks, RNG stream position) must be exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import edage_np as E
+from oracle import philox_np as px
+
+TOL = 1e-11
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _close(a, b, tol=TOL):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size:
+        assert float(np.abs(a - b).max()) <= tol, float(np.abs(a - b).max())
+
+
+# ------------------------------------------------------------------ Philox known answers
+def test_philox_random123_kat():
+    # Random123 kat_vectors, philox4x32 10 rounds
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = px.philox4x32_10(*ctr, *key)
+        assert tuple(int(g) for g in got) == want
+
+
+def test_philox_streams_are_independent_of_batching():
+    a = px.doubles(7, px.STREAM_PATH, 3, 0, 101)
+    b = np.concatenate([px.doubles(7, px.STREAM_PATH, 3, 0, 37), px.doubles(7, px.STREAM_PATH, 3, 37, 64)])
+    assert (a == b).all() and (a >= 0).all() and (a < 1).all()
+    f = px.floats(7, px.STREAM_POCKET, 3, 0, 50)
+    g = np.concatenate([px.floats(7, px.STREAM_POCKET, 3, 0, 13), px.floats(7, px.STREAM_POCKET, 3, 13, 37)])
+    assert (f == g).all() and f.dtype == np.float32 and (f < 1).all()
+    assert not (px.doubles(7, px.STREAM_PATH, 4, 0, 8) == a[:8]).any()
+
+
+# ------------------------------------------------------------------ G1 PathSeg
+@pytest.mark.parametrize("key", ["s0_f0", "s0_f1", "s1_f0", "s1_f1", "s2_f0", "s2_f1", "s7_f0", "s7_f1"])
+def test_pathseg_random(golden_dir, key):
+    g = _load(golden_dir, "g1_pathseg.npz")
+    forced = key.endswith("f1")
+    d = g[key + "_draws"]
+    d = np.concatenate([[1.0], d]) if forced else d
+    r = E.pathseg_random(d, forced)
+    _close(r["poly"], g[key + "_poly"], 1e-13)
+    _close(r["endpoint"], g[key + "_endpoint"][0], 0)
+    _close(r["translation"], g[key + "_translation"], 1e-13)
+    _close([r["grad_st"], r["grad_end"]], g[key + "_grad"], 1e-13)
+    _close(r["length"], g[key + "_length"][0], 1e-12)
+    assert bool(r["straight"]) == bool(g[key + "_straight"][0])
+
+
+# ------------------------------------------------------------------ G2..G8 one path, every stage
+def _cases(golden_dir):
+    g = _load(golden_dir, "g2_paths.npz")
+    return g, [str(c) for c in g["cases"]]
+
+
+def _parse(name):
+    R = int(name.split("_R")[1].split("_")[0])
+    c = int(name.split("_c")[1].split("_")[0])
+    return R, c, name.endswith("st1")
+
+
+def _fixed_layout(compact, straight):
+    """golden draws are in the reference's compact consumption order; the oracle takes the fixed
+    layout [path flag][seg flag, 1000 samples, end] x 10."""
+    full = np.ones(E.DRAWS_PER_PATH)
+    full[0] = 0.0 if straight else 1.0
+    pos = 0
+    for s in range(E.PATHSEGNUM):
+        b = 1 + s * E.DRAWS_PER_SEG
+        if not straight:
+            full[b] = compact[pos]
+            pos += 1
+        full[b + 1:b + 1 + E.N_FIT] = compact[pos:pos + E.N_FIT]
+        pos += E.N_FIT
+        full[b + 1 + E.N_FIT] = compact[pos]
+        pos += 1
+    assert pos == len(compact)
+    return full
+
+
+CASE_NAMES = ["s0_R64_c3_st0", "s1_R64_c3_st0", "s0_R224_c1_st0", "s3_R224_c3_st0", "s0_R256_c3_st0",
+              "s1_R256_c3_st0", "s4_R256_c1_st0", "s5_R256_c3_st1", "s6_R128_c3_st0", "s8_R64_c3_st0",
+              "s9_R256_c3_st0"]
+
+
+def test_case_list_matches_fixture(golden_dir):
+    g, names = _cases(golden_dir)
+    assert names == CASE_NAMES
+    # the reference itself never returns for this case (unbounded while loop, Path.py:478)
+    assert [str(x) for x in g["reference_nonterminating"]] == ["s2_R64_c1_st0"]
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+@pytest.mark.parametrize("mode", ["blas", "plain"])
+def test_path_chain(golden_dir, name, mode):
+    g, _ = _cases(golden_dir)
+    R, c, st = _parse(name)
+    G = lambda k: g[f"{name}/{k}"]
+    with E.arith(mode):
+        path = E.path_generate(_fixed_layout(G("draws"), st))
+        assert path["straight"] == st
+        _close([s["poly"] for s in path["segs"]], G("seg_poly"), 1e-13)
+        _close([s["endpoint"] for s in path["segs"]], G("seg_endpoint"), 0)
+        assert [int(s["straight"]) for s in path["segs"]] == G("seg_straight").tolist()
+        _close([s["length"] for s in path["segs"]], G("seg_length"), 1e-12)
+        _close(path["seg_rot"], G("seg_rotation"))
+        _close(path["seg_trans"], G("seg_translation"))
+        _close(path["segpoint"], G("segpoint"))
+        _close(path["pathpoint"], G("pathpoint_world"))
+        _close(path["length"], G("length")[0], 1e-10)
+
+        bnd = E.draw_boundary(path, c)
+        _close(bnd["boundarypoint"], G("boundarypoint_world"))
+        _close(bnd["up_dir"], G("up_dir"))
+        _close(bnd["up_point"], G("up_point"))
+        _close(bnd["down_point"], G("down_point"))
+        _close(bnd["init"], G("init_boundary"))
+        _close(bnd["end"], G("end_boundary"))
+
+        canvas = E.corridor_canvas(path, bnd, R, 50, c)
+        assert canvas.shape == (2 * R, 2 * R)
+        assert np.array_equal(np.argwhere(canvas), G("canvas_nz"))          # exact pixel set
+
+        hull = E.convexhull(path["pathpoint"], R, 50, order="scipy")
+        assert np.array_equal(hull, G("hull_raw"))                          # exact, Qhull order
+        canon = E.convexhull(path["pathpoint"], R, 50)
+        k = int(np.where((canon == hull[0]).all(1))[0][0])
+        assert np.array_equal(np.roll(canon, -k, axis=0), hull)             # same cycle
+
+        nrm = E.space_normalization(path, bnd, canvas, hull, R, 50)
+        _close(nrm["rotation"], G("rotation")[0])
+        _close(nrm["trans_rc"], G("translation")[::-1], 1e-10)              # stored [t_col, t_row]
+        _close(nrm["hull"], G("hull_norm"), 1e-10)
+        _close(nrm["segpoint_image"], G("segpoint_image"), 1e-10)
+        _close(nrm["pathpoint_image"], G("pathpoint_image"), 1e-10)
+        _close(nrm["boundarypoint_image"], G("boundarypoint_image"), 1e-10)
+        # the lattice part must be exact
+        assert np.array_equal(np.round(nrm["pathpoint_image"] - nrm["trans_rc"]),
+                              np.round(G("pathpoint_image") - G("translation")[::-1]))
+        assert nrm["space"].shape == (R, R) and nrm["space"].any()
+
+        if not st:
+            isles, fl = E.search_isle(nrm["pathpoint_image"], nrm["hull"], R, 50, c)
+            assert fl == 0
+            assert [list(i) for i in isles] == G("isle_bounds").tolist()    # exact slice bounds
+            feed = E._FloatFeed(G("torch_draws"))
+            obs, fl = E.set_obstacles(nrm["pathpoint_image"], isles, R, 50, c, feed)
+            assert fl == 0
+            _close(obs, G("obstacles"), 1e-10)
+
+
+# ------------------------------------------------------------------ G9 boundary_check
+def test_boundary_check(golden_dir):
+    g = _load(golden_dir, "g9_boundary_check.npz")
+    hull, R = g["hull_norm"], int(g["R"][0])
+    got = []
+    for a, t in zip(g["angles"], g["trans"]):
+        ok, h = E.boundary_check(hull, -a, [t[1], t[0]], R)
+        got.append(int(ok))
+    assert got == g["ok"].tolist()
+    assert 0 < sum(got) < len(got)
+    for i in range(16):
+        _, h = E.boundary_check(hull, -g["angles"][i], [g["trans"][i][1], g["trans"][i][0]], R)
+        _close(h, g["hull_out"][i], 1e-10)
+
+
+# ------------------------------------------------------------------ G10 config 1 end to end
+def test_config1_mt_stream_replay(golden_dir):
+    """BASELINE config 1: np.random.seed(0); torch.manual_seed(0);
+    MapGenerate(10, 64, 50, 5, 20, 3).generate(100) — the oracle, fed by the same global MT19937 /
+    torch streams in the reference's order, reproduces every label and obstacle list and leaves
+    the numpy stream at exactly the same position."""
+    torch = pytest.importorskip("torch")
+    g = _load(golden_dir, "g10_config1_R64.npz")
+    np.random.seed(0)
+    torch.manual_seed(0)
+    src = E.MTSource()
+    with E.arith("blas"):
+        precs = E.generate_paths(src, 10, 64, 50, 3, hull_order="scipy")
+        for j, p in enumerate(precs):
+            _close(p["hull"], g[f"p{j}/hull_norm"], 1e-10)
+            _close(p["segpoint_image"], g[f"p{j}/segpoint_image"], 1e-10)
+            _close(p["pathpoint_image"], g[f"p{j}/pathpoint_image"], 1e-10)
+            _close(p["obstacles"], g[f"p{j}/obstacles"], 1e-10)
+            _close(p["length"], g[f"p{j}/length"][0], 1e-10)
+            _close(p["rotation"], g[f"p{j}/rotation"][0])
+            assert int(p["straight"]) == int(g[f"p{j}/straight"][0]) and p["flags"] == 0
+        maps = E.generate_maps(src, precs, 64, 50, 5, 20, 3, placements=10)
+    assert len(maps) == 100
+    _close([m["angle"] for m in maps], g["angle"], 0)
+    assert np.array_equal(np.array([m["translation"] for m in maps]), g["translation"])
+    _close([m["segpoint"] for m in maps], g["segpoint"], 1e-10)
+    _close([m["pathpoint"] for m in maps], g["pathpoint"], 1e-10)
+    assert [len(m["obstacles"]) for m in maps] == g["n_obs"].tolist()
+    _close(np.concatenate([m["obstacles"] for m in maps]), g["obstacles"], 1e-10)
+    _close([m["length"] for m in maps], g["problem_length"], 1e-10)
+    _close([m["init"] for m in maps], g["problem_init"], 1e-10)
+    _close([m["end"] for m in maps], g["problem_end"], 1e-10)
+    assert np.array_equal(np.random.random(4), g["np_next_draws"])          # stream position
+    for m in maps:
+        assert m["grid"].shape == (64, 64) and set(np.unique(m["grid"])) <= {0, 128, 255}
+
+
+# ------------------------------------------------------------------ G12 markers + raster rules
+def test_paint_markers(golden_dir):
+    g = _load(golden_dir, "g12_init_end.npz")
+    ref = g["out"]                                          # [3,64,64], painted with [255,0,0]
+    grid = np.full([64, 64], E.GRID_FREE, np.uint8)
+    E.paint_markers(grid, g["init"], g["end"])
+    assert np.array_equal(grid == E.GRID_MARK, ref[0] == 255)
+    assert (ref[1][grid == E.GRID_MARK] == 0).all()
+
+
+def test_rotate_translate_rules():
+    img = np.zeros([9, 9], bool)
+    img[2, 6] = True
+    assert np.array_equal(E.rotate_nearest(img, 0.0), img)
+    r90 = E.rotate_nearest(img, 90.0)                       # counter-clockwise on the display
+    assert r90.sum() == 1 and r90[2, 2]
+    assert np.array_equal(E.rotate_nearest(E.rotate_nearest(img, 90.0), -90.0), img)
+    t = E.translate_nearest(img, 1, 2, 9, 9)                # tx -> columns, ty -> rows
+    assert t.sum() == 1 and t[4, 7]
+    assert E.translate_nearest(img, 5, 0, 9, 9).sum() == 0  # shifted out: zero fill
+
+
+def test_disc_raster_rule():
+    occ = E.disc_raster([[4.5, 2.5, 1.0]], 8)               # [col, row, r]: centre of pixel (2,4)
+    assert occ[2, 4] and occ[1, 4] and occ[3, 4] and occ[2, 3] and occ[2, 5]
+    assert occ.sum() == 5
+    assert E.disc_raster(np.zeros([0, 3]), 8).sum() == 0
