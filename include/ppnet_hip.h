@@ -1,0 +1,171 @@
+/* ppnet_hip.h — C ABI of libppnet_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the two data-parallel loops of AdamQLMeng/PPNet.  The reference has no
+ * FFI layer of its own (it is pure Python); each entry point below names the reference
+ * interface it replaces (paths relative to the reference repo).  INTEGRATION.md shows the
+ * ctypes binding a maintainer would add under EDaGe-PP/ and GenNet/.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless the comment says "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous
+ *     on that stream and never synchronise;
+ *   - return value: PPN_OK or a negative PPN_E_* code; nothing throws or aborts;
+ *   - no global mutable state: calls are re-entrant (constant tables are built once, lazily,
+ *     under a lock);
+ *   - points are (row, col) doubles; obstacles are [col, row, radius] doubles, as in the
+ *     reference (EDaGe-PP/Path.py:495, MapGenerate.py:143);
+ *   - R must be a multiple of 32 and 32 <= R <= 512.
+ */
+#ifndef PPNET_HIP_H
+#define PPNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPN_OK             0
+#define PPN_E_INVALID     -1   /* bad argument (NULL where required, R not a multiple of 32, ...) */
+#define PPN_E_HIP         -2   /* a HIP runtime call failed; see ppn_last_hip_error() */
+#define PPN_E_UNSUPPORTED -3
+
+/* fixed geometry of the generator (EDaGe-PP/MapGenerate.py:21-23, PathSeg.py:22-23) */
+#define PPN_SEGS            10
+#define PPN_POLY             5          /* degree-4 coefficients, highest power first */
+#define PPN_PATH_POINTS   1000
+#define PPN_BOUNDARY_POINTS 1100
+#define PPN_DRAWS_PER_SEG 1002          /* [straight flag][1000 samples][end abscissa] */
+#define PPN_DRAWS_PER_PATH (1 + PPN_SEGS * PPN_DRAWS_PER_SEG)
+#define PPN_MAX_HULL        64
+#define PPN_MAX_ISLES       16
+#define PPN_MAX_POCKET      64          /* pocket obstacles per path */
+#define PPN_POCKET_TRY_CAP 256          /* per-isle cap on set_obstacles iterations */
+#define PPN_PLACE_TRY_CAP 4096          /* per-map cap on placement attempts */
+#define PPN_MAX_WAYPOINTS 2048          /* extract_path step cap (replaces the 1 s wall-clock timeout) */
+
+/* occupancy grid codes (u8) */
+#define PPN_GRID_OBST   0
+#define PPN_GRID_FREE 255
+#define PPN_GRID_MARK 128               /* start / goal marker squares */
+
+/* per-instance flag bits */
+#define PPN_FLAG_POCKET_CAP   1u        /* reference would loop forever (Path.py:478) */
+#define PPN_FLAG_PLACE_CAP    2u        /* reference: "Repeated over 1000000 times" (MapGenerate.py:60-62) */
+#define PPN_FLAG_EMPTY_ISLE   4u        /* reference raises IndexError (Path.py:529) */
+#define PPN_FLAG_HULL_CAP     8u        /* more than PPN_MAX_HULL hull vertices */
+#define PPN_FLAG_ISLE_CAP    16u
+#define PPN_FLAG_POCKET_FULL 32u        /* more than PPN_MAX_POCKET pocket obstacles */
+
+int         ppn_version(void);
+const char* ppn_error_string(int code);
+int         ppn_last_hip_error(void);   /* hipError_t of the most recent PPN_E_HIP on this thread */
+
+/* Host-side constant: the 4 x 1000 least-squares operator W with Poly[0..3] = W . y for
+ * x = arange(1000)/100, degree 4 (replaces the per-call np.polyfit at PathSeg.py:24; the
+ * constant coefficient is overwritten with 0 at PathSeg.py:28 so its row is not needed).
+ * `out` is a HOST buffer of 4*1000 doubles. */
+int ppn_polyfit_table(double* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage A — target paths.  Replaces PathGroup.generate (PathGenerate.py:33-50) =
+ * Path.generate + Path.draw_boundary + Path.path_obstacles (Path.py:78-98, 318-356, 144-155,
+ * 113-142, 157-193, 388-404, 463-537) for n_paths independent paths.
+ * Optional outputs may be NULL. */
+typedef struct ppn_paths {
+    double*   seg_poly;         /* [n][10][5]                                          */
+    double*   seg_endpoint;     /* [n][10]                                             */
+    double*   seg_rotation;     /* [n][10]   PathSeg.Rotation after Path.transform      */
+    double*   seg_translation;  /* [n][10][2]                                          */
+    double*   seg_length;       /* [n][10]   optional                                  */
+    int32_t*  seg_straight;     /* [n][10]                                             */
+    double*   segpoint_world;   /* [n][11][2]                                          */
+    double*   pathpoint_world;  /* [n][1000][2]                                        */
+    double*   boundary_world;   /* [n][1100][2] optional (Path.BoundaryPoint)          */
+    uint32_t* canvas_bits;      /* [n][(2R*2R)/32] optional: pre-rotation corridor canvas, bit = row*2R+col */
+    double*   hull_raw;         /* [n][64][2] optional: integer hull before normalisation */
+    double*   hull;             /* [n][64][2] Path.ConvexHull after space_normalization */
+    int32_t*  hull_n;           /* [n]                                                 */
+    double*   rotation;         /* [n]  Path.Rotation (degrees)                        */
+    double*   trans_rc;         /* [n][2] (t_row, t_col); Path.Translation = [t_col, t_row] */
+    double*   segpoint_image;   /* [n][11][2]  Path.SegPointImage                      */
+    double*   pathpoint_image;  /* [n][1000][2] Path.PathPoint after normalisation      */
+    uint32_t* space_bits;       /* [n][R*R/32] Path.Space as a bit mask, bit = row*R+col */
+    int32_t*  isles;            /* [n][16][2] slice bounds into PathPoint              */
+    int32_t*  n_isles;          /* [n]                                                 */
+    double*   obstacles;        /* [n][64][3] Path.obstacles as [col,row,r]            */
+    int32_t*  n_obstacles;      /* [n]                                                 */
+    double*   length;           /* [n] Path.Length                                     */
+    int32_t*  straight;         /* [n] path-level is_straight                          */
+    uint32_t* flags;            /* [n] PPN_FLAG_*                                      */
+} ppn_paths_t;
+
+/* draws        : [n_paths][PPN_DRAWS_PER_PATH] uniform doubles in the fixed layout
+ *                [path straight][seg0: flag, 1000 samples, end]...[seg9] or NULL = Philox4x32-10
+ *                keyed by (seed, stream PATH, first_path_id + p, draw index);
+ * pocket_draws : [n_paths][pocket_stride] uniform floats consumed in torch.rand order by
+ *                set_obstacles, or NULL = Philox (stream POCKET). */
+int ppn_edage_paths(int32_t n_paths, uint64_t first_path_id, int32_t R, double map_size,
+                    double clearance, uint64_t seed,
+                    const double* draws, const float* pocket_draws, int32_t pocket_stride,
+                    const ppn_paths_t* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage B — maps.  Replaces the body of MapGenerate.generate (MapGenerate.py:48-124) incl.
+ * Path.boundary_check (Path.py:100-111), generate_map_randomly (MapGenerate.py:126-151), the
+ * obstacle raster (Path.plot_obstacles, Path.py:36-49 — explicit rule) and
+ * add_init_end_single (process_map.py:119-145).  Map m uses target path m / placements. */
+typedef struct ppn_maps {
+    uint8_t*  grid;             /* [n][R][R]  PPN_GRID_* codes                          */
+    double*   angle;            /* [n]  degrees, U(-180,180)                           */
+    int32_t*  translation;      /* [n][2] as drawn (MapGenerate.py:64-65)              */
+    int32_t*  attempts;         /* [n]  placement attempts used                        */
+    double*   segpoint;         /* [n][11][2] label                                     */
+    double*   pathpoint;        /* [n][1000][2] label, optional                         */
+    uint8_t*  accept;           /* [n][K] clearance-filter mask of the K random obstacles, optional */
+    double*   obstacles;        /* [n][K+64][3] kept random obstacles then pocket obstacles */
+    int32_t*  n_obstacles;      /* [n][2] (total, of which random)                      */
+    uint32_t* flags;            /* [n]                                                  */
+} ppn_maps_t;
+
+/* place_draws : [n_maps][3] (angle, t0, t1 uniforms of the ACCEPTED attempt) or NULL = Philox
+ *               rejection loop (stream PLACE, draw index 3*attempt+i);
+ * obst_draws  : [n_maps][3K] in the reference's draw order (K x, K y, K size) or NULL = Philox. */
+int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements,
+                   uint64_t first_map_id, int32_t R, double map_size, double obstacles_size,
+                   int32_t K, double clearance, uint64_t seed,
+                   const double* place_draws, const double* obst_draws,
+                   const ppn_maps_t* out, void* stream);
+
+/* Path.boundary_check (Path.py:100-111) for n (angle, translation) pairs against one hull.
+ * angle_deg[n] is the angle passed by the caller (MapGenerate passes -angle), translation_rc
+ * [n][2] is (row, col).  ok[n] u8. */
+int ppn_boundary_check(const double* hull, int32_t hull_n, const double* angle_deg,
+                       const double* translation_rc, int32_t n, int32_t R, uint8_t* ok,
+                       void* stream);
+
+/* Obstacle raster rule standing in for plot_obstacles (Path.py:36-49): n_maps grids of R x R,
+ * grid = PPN_GRID_OBST where the pixel centre lies in a disc, else PPN_GRID_FREE.
+ * obstacles [n_maps][stride][3], counts[n_maps]. */
+int ppn_disc_raster(const double* obstacles, const int32_t* counts, int32_t stride,
+                    int32_t n_maps, int32_t R, uint8_t* grid, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Planner tail (loop B).  collision_check_circle_edge (process_map.py:383-425) for n_seg
+ * segments; segment i belongs to problem prob[i] whose obstacles are
+ * obs[obs_off[p] .. obs_off[p+1]) as [ox, oy, size] floats.  hit[n_seg] u8. */
+int ppn_collision_segments(const float* s, const float* e, const int32_t* prob, int32_t n_seg,
+                           const float* obs, const int32_t* obs_off, float clearance,
+                           uint8_t* hit, void* stream);
+
+/* extract_path (process_map.py:293-365) on n heat maps `heat` [n][H][W] float32 already
+ * down-sampled; init/end [n][2] in down-sampled coordinates.  wp [n][max_wp][2] float32,
+ * wp_n[n], ok[n].  The 1 s wall-clock timeout becomes the max_wp step cap (<= PPN_MAX_WAYPOINTS). */
+int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const float* init,
+                      const float* end, int32_t max_wp, float* wp, int32_t* wp_n, uint8_t* ok,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPNET_HIP_H */

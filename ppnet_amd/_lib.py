@@ -1,0 +1,90 @@
+"""ctypes binding of libppnet_hip.so (C ABI in include/ppnet_hip.h).
+
+The HIP library is the product path: there is no CPU fallback.  If the shared object is missing
+the import fails loudly with the build command.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libppnet_hip.so")
+
+PPN_OK = 0
+SEGS = 10
+PATH_POINTS = 1000
+BOUNDARY_POINTS = 1100
+DRAWS_PER_SEG = 1002
+DRAWS_PER_PATH = 1 + SEGS * DRAWS_PER_SEG
+MAX_HULL = 64
+MAX_ISLES = 16
+MAX_POCKET = 64
+POCKET_TRY_CAP = 256
+PLACE_TRY_CAP = 4096
+MAX_WAYPOINTS = 2048
+GRID_OBST, GRID_FREE, GRID_MARK = 0, 255, 128
+FLAG_POCKET_CAP, FLAG_PLACE_CAP, FLAG_EMPTY_ISLE, FLAG_HULL_CAP, FLAG_ISLE_CAP, FLAG_POCKET_FULL = 1, 2, 4, 8, 16, 32
+
+_p = C.c_void_p
+
+
+class PathsStruct(C.Structure):
+    """ppn_paths_t"""
+    _fields_ = [(n, _p) for n in (
+        "seg_poly", "seg_endpoint", "seg_rotation", "seg_translation", "seg_length", "seg_straight",
+        "segpoint_world", "pathpoint_world", "boundary_world", "canvas_bits", "hull_raw", "hull", "hull_n",
+        "rotation", "trans_rc", "segpoint_image", "pathpoint_image", "space_bits", "isles", "n_isles",
+        "obstacles", "n_obstacles", "length", "straight", "flags")]
+
+
+class MapsStruct(C.Structure):
+    """ppn_maps_t"""
+    _fields_ = [(n, _p) for n in (
+        "grid", "angle", "translation", "attempts", "segpoint", "pathpoint", "accept", "obstacles",
+        "n_obstacles", "flags")]
+
+
+EXPORTS = ("ppn_version", "ppn_error_string", "ppn_last_hip_error", "ppn_polyfit_table", "ppn_edage_paths",
+           "ppn_edage_maps", "ppn_boundary_check", "ppn_disc_raster", "ppn_collision_segments",
+           "ppn_extract_paths")
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is the only implementation of this package "
+            f"(no CPU fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C ppnet_amd/csrc`.")
+    lib = C.CDLL(LIB_PATH)
+    lib.ppn_version.restype = C.c_int
+    lib.ppn_error_string.restype = C.c_char_p
+    lib.ppn_error_string.argtypes = [C.c_int]
+    lib.ppn_last_hip_error.restype = C.c_int
+    lib.ppn_polyfit_table.argtypes = [_p]
+    lib.ppn_edage_paths.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.c_double, C.c_double, C.c_uint64,
+                                    _p, _p, C.c_int32, C.POINTER(PathsStruct), _p]
+    lib.ppn_edage_maps.argtypes = [C.POINTER(PathsStruct), C.c_int32, C.c_int32, C.c_uint64, C.c_int32,
+                                   C.c_double, C.c_double, C.c_int32, C.c_double, C.c_uint64, _p, _p,
+                                   C.POINTER(MapsStruct), _p]
+    lib.ppn_boundary_check.argtypes = [_p, C.c_int32, _p, _p, C.c_int32, C.c_int32, _p, _p]
+    lib.ppn_disc_raster.argtypes = [_p, _p, C.c_int32, C.c_int32, C.c_int32, _p, _p]
+    lib.ppn_collision_segments.argtypes = [_p, _p, _p, C.c_int32, _p, _p, C.c_float, _p, _p]
+    lib.ppn_extract_paths.argtypes = [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, C.c_int32, _p, _p, _p, _p]
+    for name in EXPORTS:
+        getattr(lib, name)
+        if name not in ("ppn_error_string",):
+            getattr(lib, name).restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+
+class PpnError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != PPN_OK:
+        msg = lib.ppn_error_string(rc).decode()
+        extra = f" (hipError_t {lib.ppn_last_hip_error()})" if rc == -2 else ""
+        raise PpnError(f"{what}: {msg}{extra}")

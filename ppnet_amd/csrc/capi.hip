@@ -1,0 +1,216 @@
+// capi.hip — the extern "C" boundary of libppnet_hip.so (declared in include/ppnet_hip.h).
+// Argument validation, constant tables, kernel launches.  No torch types, no exceptions.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <mutex>
+#include <string.h>
+#include <vector>
+
+#include "ppn_kernels.h"
+
+namespace {
+
+thread_local int g_last_hip = 0;
+
+inline int hip_fail(hipError_t e) {
+    g_last_hip = (int)e;
+    return PPN_E_HIP;
+}
+#define PPN_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_); } while (0)
+
+inline bool bad_R(int R) { return R < 32 || R > 512 || (R % 32) != 0; }
+
+// Least-squares operator for np.polyfit(arange(1000)/100, y, 4): W = pinv(V)[0:4], V[i][k] = x_i^(4-k).
+// Built once in extended precision (modified Gram-Schmidt with re-orthogonalisation), so the
+// device fit is a constant 4 x 1000 matrix-vector product instead of a per-call LAPACK solve.
+void build_polyfit_table(double* out) {
+    const int N = PPN_PATH_POINTS, M = 5;
+    std::vector<long double> q((size_t)M * N);
+    long double Rm[5][5] = {};
+    for (int i = 0; i < N; ++i) {
+        const long double x = (long double)i / 100.0L;
+        long double pw = 1.0L;
+        for (int k = M - 1; k >= 0; --k) { q[(size_t)k * N + i] = pw; pw *= x; }
+    }
+    for (int k = 0; k < M; ++k) {
+        long double* qk = &q[(size_t)k * N];
+        for (int pass = 0; pass < 2; ++pass)
+            for (int j = 0; j < k; ++j) {
+                const long double* qj = &q[(size_t)j * N];
+                long double r = 0.0L;
+                for (int i = 0; i < N; ++i) r += qj[i] * qk[i];
+                for (int i = 0; i < N; ++i) qk[i] -= r * qj[i];
+                Rm[j][k] += r;
+            }
+        long double nn = 0.0L;
+        for (int i = 0; i < N; ++i) nn += qk[i] * qk[i];
+        nn = sqrtl(nn);
+        Rm[k][k] = nn;
+        for (int i = 0; i < N; ++i) qk[i] /= nn;
+    }
+    for (int i = 0; i < N; ++i) {                 // W[:, i] = R^-1 (Q^T e_i)
+        long double w[5];
+        for (int k = M - 1; k >= 0; --k) {
+            long double v = q[(size_t)k * N + i];
+            for (int j = k + 1; j < M; ++j) v -= Rm[k][j] * w[j];
+            w[k] = v / Rm[k][k];
+        }
+        for (int k = 0; k < 4; ++k) out[(size_t)k * N + i] = (double)w[k];
+    }
+}
+
+std::mutex g_tab_mu;
+double* g_tab_dev[64] = {};
+
+int polyfit_table_device(const double** out) {
+    int dev = 0;
+    PPN_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return PPN_E_INVALID;
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    if (!g_tab_dev[dev]) {
+        std::vector<double> host(4 * PPN_PATH_POINTS);
+        build_polyfit_table(host.data());
+        double* d = nullptr;
+        PPN_HIP(hipMalloc((void**)&d, host.size() * sizeof(double)));
+        hipError_t e = hipMemcpy(d, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e); }
+        g_tab_dev[dev] = d;
+    }
+    *out = g_tab_dev[dev];
+    return PPN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ppn_version(void) { return 100; }
+
+const char* ppn_error_string(int code) {
+    switch (code) {
+        case PPN_OK: return "ok";
+        case PPN_E_INVALID: return "invalid argument";
+        case PPN_E_HIP: return "HIP runtime error";
+        case PPN_E_UNSUPPORTED: return "unsupported";
+        default: return "unknown error";
+    }
+}
+
+int ppn_last_hip_error(void) { return g_last_hip; }
+
+int ppn_polyfit_table(double* out) {
+    if (!out) return PPN_E_INVALID;
+    build_polyfit_table(out);
+    return PPN_OK;
+}
+
+int ppn_edage_paths(int32_t n_paths, uint64_t first_path_id, int32_t R, double map_size, double clearance,
+                    uint64_t seed, const double* draws, const float* pocket_draws, int32_t pocket_stride,
+                    const ppn_paths_t* out, void* stream) {
+    if (n_paths < 0 || bad_R(R) || !out || !(map_size > 0.0) || !(clearance > 0.0)) return PPN_E_INVALID;
+    if (pocket_draws && pocket_stride <= 0) return PPN_E_INVALID;
+    const ppn_paths_t& o = *out;
+    if (!o.seg_poly || !o.seg_endpoint || !o.seg_rotation || !o.seg_translation || !o.seg_straight ||
+        !o.segpoint_world || !o.pathpoint_world || !o.hull || !o.hull_n || !o.rotation || !o.trans_rc ||
+        !o.segpoint_image || !o.pathpoint_image || !o.space_bits || !o.isles || !o.n_isles || !o.obstacles ||
+        !o.n_obstacles || !o.length || !o.straight || !o.flags)
+        return PPN_E_INVALID;
+    if (n_paths == 0) return PPN_OK;
+    ppn::PathsParams prm;
+    prm.out = o;
+    prm.n_paths = n_paths;
+    prm.first_id = first_path_id;
+    prm.R = R;
+    prm.map_size = map_size;
+    prm.clearance = clearance;
+    prm.seed = seed;
+    prm.draws = draws;
+    prm.pocket = pocket_draws;
+    prm.pocket_stride = pocket_stride;
+    int rc = polyfit_table_device(&prm.W);
+    if (rc != PPN_OK) return rc;
+    const size_t lds = (size_t)(2 * R) * (2 * R) / 8;
+    PPN_HIP(hipFuncSetAttribute((const void*)ppn::edage_paths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ppn::edage_paths_kernel, dim3(n_paths), dim3(256), lds, (hipStream_t)stream, prm);
+    PPN_HIP(hipGetLastError());
+    return PPN_OK;
+}
+
+int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements, uint64_t first_map_id, int32_t R,
+                   double map_size, double obstacles_size, int32_t K, double clearance, uint64_t seed,
+                   const double* place_draws, const double* obst_draws, const ppn_maps_t* out, void* stream) {
+    if (!paths || !out || n_paths < 0 || placements < 0 || bad_R(R) || K < 0 || K > 256 || !(map_size > 0.0))
+        return PPN_E_INVALID;
+    const ppn_paths_t& p = *paths;
+    const ppn_maps_t& o = *out;
+    if (!p.hull || !p.hull_n || !p.segpoint_image || !p.pathpoint_image || !p.space_bits || !p.obstacles ||
+        !p.n_obstacles || !p.flags)
+        return PPN_E_INVALID;
+    if (!o.grid || !o.angle || !o.translation || !o.attempts || !o.segpoint || !o.obstacles || !o.n_obstacles || !o.flags)
+        return PPN_E_INVALID;
+    const long long n_maps = (long long)n_paths * placements;
+    if (n_maps == 0) return PPN_OK;
+    if (n_maps > 0x7fffffffLL) return PPN_E_INVALID;
+    ppn::MapsParams prm;
+    prm.paths = p;
+    prm.out = o;
+    prm.n_paths = n_paths;
+    prm.placements = placements;
+    prm.n_maps = (int)n_maps;
+    prm.first_map_id = first_map_id;
+    prm.R = R;
+    prm.map_size = map_size;
+    prm.obstacles_size = obstacles_size;
+    prm.clearance = clearance;
+    prm.K = K;
+    prm.seed = seed;
+    prm.place_draws = place_draws;
+    prm.obst_draws = obst_draws;
+    const size_t lds = (size_t)R * R / 8;
+    hipLaunchKernelGGL(ppn::edage_maps_kernel, dim3((unsigned)n_maps), dim3(256), lds, (hipStream_t)stream, prm);
+    PPN_HIP(hipGetLastError());
+    return PPN_OK;
+}
+
+int ppn_boundary_check(const double* hull, int32_t hull_n, const double* angle_deg, const double* translation_rc,
+                       int32_t n, int32_t R, uint8_t* ok, void* stream) {
+    if (!hull || hull_n <= 0 || !angle_deg || !translation_rc || n < 0 || R <= 0 || !ok) return PPN_E_INVALID;
+    if (n == 0) return PPN_OK;
+    hipLaunchKernelGGL(ppn::boundary_check_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, hull, hull_n,
+                       angle_deg, translation_rc, n, R, ok);
+    PPN_HIP(hipGetLastError());
+    return PPN_OK;
+}
+
+int ppn_disc_raster(const double* obstacles, const int32_t* counts, int32_t stride, int32_t n_maps, int32_t R,
+                    uint8_t* grid, void* stream) {
+    if (!obstacles || !counts || stride <= 0 || n_maps < 0 || R <= 0 || (R % 16) != 0 || !grid) return PPN_E_INVALID;
+    if (n_maps == 0) return PPN_OK;
+    hipLaunchKernelGGL(ppn::disc_raster_kernel, dim3(n_maps), dim3(256), 0, (hipStream_t)stream, obstacles, counts,
+                       stride, n_maps, R, grid);
+    PPN_HIP(hipGetLastError());
+    return PPN_OK;
+}
+
+int ppn_collision_segments(const float* s, const float* e, const int32_t* prob, int32_t n_seg, const float* obs,
+                           const int32_t* obs_off, float clearance, uint8_t* hit, void* stream) {
+    if (!s || !e || !prob || n_seg < 0 || !obs || !obs_off || !hit) return PPN_E_INVALID;
+    if (n_seg == 0) return PPN_OK;
+    hipLaunchKernelGGL(ppn::collision_segments_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, (hipStream_t)stream, s,
+                       e, prob, n_seg, obs, obs_off, clearance, hit);
+    PPN_HIP(hipGetLastError());
+    return PPN_OK;
+}
+
+int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const float* init, const float* end,
+                      int32_t max_wp, float* wp, int32_t* wp_n, uint8_t* ok, void* stream) {
+    if (!heat || n < 0 || H <= 0 || W <= 0 || !init || !end || max_wp <= 0 || max_wp > PPN_MAX_WAYPOINTS || !wp || !wp_n || !ok)
+        return PPN_E_INVALID;
+    if (n == 0) return PPN_OK;
+    hipLaunchKernelGGL(ppn::extract_paths_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, heat, n, H, W, init, end,
+                       max_wp, wp, wp_n, ok);
+    PPN_HIP(hipGetLastError());
+    return PPN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,583 @@
+// edage_paths.hip — stage A of EDaGe-PP on gfx950: one 256-thread workgroup per target path.
+//
+// Replaces, per path (paths relative to the reference's EDaGe-PP/):
+//   PathSeg.__init__/random/translation/gradient/length     PathSeg.py:10-58
+//   Path.generate/transform/point_transform/plot            Path.py:78-98, 224-233, 253-316
+//   Path.draw_boundary                                      Path.py:318-356
+//   Path.path_space + free_space_bydirection                Path.py:113-142, 397-404
+//   Path.convexhull (Qhull -> exact integer gift wrapping)  Path.py:388-395
+//   Path.space_normalization (+ explicit nearest resample)  Path.py:157-193
+//   Path.search_isle / Path.set_obstacles                   Path.py:502-537, 463-500
+//
+// Data layout: everything a path needs lives in LDS for the life of the workgroup — the 2R x 2R
+// corridor canvas as a bit mask ((2R)^2/8 bytes: 32 KiB at R=256, 128 KiB at R=512), the 1000
+// path points (16 KiB), the integer lattice copy for the hull (8 KiB) — and each result is
+// written to HBM exactly once.  Reductions are wave64 shuffles + one LDS slot per wave.
+// Arithmetic is unfused double (file is built with -ffp-contract=off), matching oracle/edage_np.py.
+#include "ppn_device.h"
+#include "ppn_kernels.h"
+
+namespace ppn {
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int NW = NT / 64;
+
+struct SegLds {
+    double poly[PPN_SEGS][5];
+    double pder[PPN_SEGS][4];
+    double endpoint[PPN_SEGS];
+    double trans[PPN_SEGS][2];
+    double ang[PPN_SEGS];
+    double cs[PPN_SEGS], sn[PPN_SEGS];
+    double t0[PPN_SEGS][2];        // PathSeg.Translation before chaining: (E, p(E))
+    double grad[PPN_SEGS][2];      // GradSt, GradEnd
+    double segpoint[PPN_SEGS + 1][2];
+    int straight[PPN_SEGS];
+};
+
+__device__ __forceinline__ double horner3(const double* p, double x) {
+    double y = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y = y * x + p[k];
+    return y;
+}
+
+// one boundary sample of segment s at abscissa index j/50 (Path.py:320-333): centre-line point
+// after point_transform and the unit normal
+__device__ __forceinline__ void boundary_sample(const SegLds& S, int s, int j, double& px, double& py,
+                                                double& nx, double& ny) {
+    const double x = ((double)j / 50.0) * S.endpoint[s];
+    const double y = horner4(S.poly[s], x);
+    const double yd = horner3(S.pder[s], x);
+    rot2(S.cs[s], S.sn[s], x, y, px, py);
+    px = px + S.trans[s][0];
+    py = py + S.trans[s][1];
+    rot2(S.cs[s], S.sn[s], yd, -1.0, nx, ny);
+    const double n = sqrt(nx * nx + ny * ny);
+    nx = nx / n;
+    ny = ny / n;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
+    extern __shared__ uint32_t canvas[];          // (2R)^2 / 32 words
+    __shared__ SegLds S;
+    __shared__ double pp[PPN_PATH_POINTS][2];     // path points: world, later image
+    __shared__ int lat[PPN_PATH_POINTS][2];       // integer lattice (hull input)
+    __shared__ double hull[PPN_MAX_HULL][2];
+    __shared__ int hull_i[PPN_MAX_HULL][2];
+    __shared__ double fit_part[PPN_SEGS][4][NW];
+    __shared__ double red_v[NW];
+    __shared__ int red_i[NW];
+    __shared__ double bc[16];                     // broadcast scalars
+    __shared__ int bci[8];
+
+    const int p = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int R = prm.R;
+    const uint64_t pid = prm.first_id + (uint64_t)p;
+    const ppn_paths_t& O = prm.out;
+    const double* fed = prm.draws ? prm.draws + (size_t)p * PPN_DRAWS_PER_PATH : nullptr;
+    const double clearance = prm.clearance;
+    const double step_len = 1.0 / (double)R * prm.map_size;      // Path.py:118
+    const double step_c2i = prm.map_size / (double)R;            // Path.py:380
+    const double Rd = (double)R;
+    uint32_t flags = 0;
+
+    // zero the canvas
+    const int canvas_words = (2 * R) * (2 * R) / 32;
+    for (int w = tid; w < canvas_words; w += NT) canvas[w] = 0u;
+
+    // ------------------------------------------------------------------ A1: ten segment fits
+    const double d0 = fed ? fed[0] : philox_double(prm.seed, STREAM_PATH, pid, 0);
+    const bool path_straight = !(d0 > 0.01);                     // PathGenerate.py:36
+    for (int s = 0; s < PPN_SEGS; ++s) {
+        const uint32_t base = 1u + (uint32_t)s * PPN_DRAWS_PER_SEG + 1u;   // first sample draw (even)
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int q = tid; q < 500; q += NT) {
+            double u0, u1;
+            if (fed) { u0 = fed[base + 2 * q]; u1 = fed[base + 2 * q + 1]; }
+            else philox_double2(prm.seed, STREAM_PATH, pid, (base >> 1) + (uint32_t)q, u0, u1);
+            const double y0 = u0 * 10.0 - 5.0, y1 = u1 * 10.0 - 5.0;       // PathSeg.py:23
+            const int i0 = 2 * q, i1 = 2 * q + 1;
+            a0 += prm.W[0 * 1000 + i0] * y0; a0 += prm.W[0 * 1000 + i1] * y1;
+            a1 += prm.W[1 * 1000 + i0] * y0; a1 += prm.W[1 * 1000 + i1] * y1;
+            a2 += prm.W[2 * 1000 + i0] * y0; a2 += prm.W[2 * 1000 + i1] * y1;
+            a3 += prm.W[3 * 1000 + i0] * y0; a3 += prm.W[3 * 1000 + i1] * y1;
+        }
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+        if (lane == 0) {
+            fit_part[s][0][wv] = a0; fit_part[s][1][wv] = a1;
+            fit_part[s][2][wv] = a2; fit_part[s][3][wv] = a3;
+        }
+    }
+    __syncthreads();
+    if (tid < PPN_SEGS) {
+        const int s = tid;
+        const uint32_t b = 1u + (uint32_t)s * PPN_DRAWS_PER_SEG;
+        const double uf = fed ? fed[b] : philox_double(prm.seed, STREAM_PATH, pid, b);
+        const double ue = fed ? fed[b + 1001] : philox_double(prm.seed, STREAM_PATH, pid, b + 1001);
+        const bool st = path_straight || (uf < 0.2);             // PathSeg.py:19
+        double poly[5];
+        for (int k = 0; k < 4; ++k) {
+            double v = 0.0;
+            for (int w = 0; w < NW; ++w) v += fit_part[s][k][w];
+            poly[k] = v;
+        }
+        poly[4] = 0.0;                                           // PathSeg.py:28
+        if (st) { poly[0] = 0.0; poly[1] = 0.0; poly[2] = 0.0; } // PathSeg.py:29-31
+        const double E = ue * 7.0 + 0.0;                         // PathSeg.py:32
+        for (int k = 0; k < 5; ++k) S.poly[s][k] = poly[k];
+        S.pder[s][0] = poly[0] * 4.0; S.pder[s][1] = poly[1] * 3.0;
+        S.pder[s][2] = poly[2] * 2.0; S.pder[s][3] = poly[3] * 1.0;
+        S.endpoint[s] = E;
+        S.straight[s] = st ? 1 : 0;
+        const double yE = horner4(poly, E);
+        S.t0[s][0] = E; S.t0[s][1] = yE;
+        S.grad[s][0] = horner3(S.pder[s], 0.0);
+        S.grad[s][1] = horner3(S.pder[s], E);
+        // PathSeg.length (PathSeg.py:49-58): 100-sample polyline, sequential sum
+        double len = 0.0, xp = 0.0, yp = 0.0;
+        for (int j = 0; j < 100; ++j) {
+            const double x = ((double)j / 100.0) * (E - 0.0);
+            const double y = horner4(poly, x);
+            if (j) len = len + dist2d(x, y, xp, yp);
+            xp = x; yp = y;
+        }
+        len = len + dist2d(E, yE, xp, yp);
+        if (O.seg_length) O.seg_length[(size_t)p * PPN_SEGS + s] = len;
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ A2: chaining (serial, tiny)
+    if (tid == 0) {
+        double a = 0.0;
+        S.ang[0] = 0.0;
+        for (int i = 1; i < PPN_SEGS; ++i) {                     // angle_abs, Path.py:276-289
+            a = a + (atan(S.grad[i - 1][1]) - atan(S.grad[i][0]));
+            S.ang[i] = a;
+        }
+        for (int i = 0; i < PPN_SEGS; ++i) { S.cs[i] = cos(S.ang[i]); S.sn[i] = sin(S.ang[i]); }
+        double tx = 0.0, ty = 0.0;                               // translation_seg, Path.py:291-299
+        for (int i = 0; i < PPN_SEGS; ++i) {
+            S.trans[i][0] = tx; S.trans[i][1] = ty;
+            double rx, ry;
+            if (i != 0) rot2(S.cs[i], S.sn[i], S.t0[i][0], S.t0[i][1], rx, ry);
+            else { rx = S.t0[0][0]; ry = S.t0[0][1]; }
+            tx = tx + rx; ty = ty + ry;
+        }
+        S.segpoint[0][0] = 0.0; S.segpoint[0][1] = 0.0;
+        for (int i = 0; i < PPN_SEGS; ++i) {                     // Path.py:86-90
+            double x = S.t0[i][0], y = S.t0[i][1], rx, ry;
+            if (i != 0) rot2(S.cs[i], S.sn[i], x, y, rx, ry); else { rx = x; ry = y; }
+            S.segpoint[i + 1][0] = rx + S.trans[i][0];
+            S.segpoint[i + 1][1] = ry + S.trans[i][1];
+        }
+    }
+    __syncthreads();
+    if (tid < PPN_SEGS) {
+        const size_t o = (size_t)p * PPN_SEGS + tid;
+        for (int k = 0; k < 5; ++k) O.seg_poly[o * 5 + k] = S.poly[tid][k];
+        O.seg_endpoint[o] = S.endpoint[tid];
+        O.seg_rotation[o] = S.ang[tid];
+        O.seg_translation[o * 2] = S.trans[tid][0];
+        O.seg_translation[o * 2 + 1] = S.trans[tid][1];
+        O.seg_straight[o] = S.straight[tid];
+    }
+    if (tid < PPN_SEGS + 1) {
+        O.segpoint_world[((size_t)p * 11 + tid) * 2] = S.segpoint[tid][0];
+        O.segpoint_world[((size_t)p * 11 + tid) * 2 + 1] = S.segpoint[tid][1];
+    }
+
+    // path points (Path.plot, Path.py:256-260): 100 samples per segment
+    for (int q = tid; q < PPN_PATH_POINTS; q += NT) {
+        const int s = q / 100, j = q - s * 100;
+        const double x = ((double)j / 100.0) * S.endpoint[s];
+        const double y = horner4(S.poly[s], x);
+        double rx, ry;
+        if (s != 0) rot2(S.cs[s], S.sn[s], x, y, rx, ry); else { rx = x; ry = y; }
+        rx = rx + S.trans[s][0];
+        ry = ry + S.trans[s][1];
+        pp[q][0] = rx; pp[q][1] = ry;
+        O.pathpoint_world[((size_t)p * PPN_PATH_POINTS + q) * 2] = rx;
+        O.pathpoint_world[((size_t)p * PPN_PATH_POINTS + q) * 2 + 1] = ry;
+        lat[q][0] = (int)rint(rx / step_c2i + Rd);               // convexhull input, Path.py:390
+        lat[q][1] = (int)rint(ry / step_c2i + Rd);
+    }
+    __syncthreads();
+    {
+        double part = 0.0;                                       // Path.Length, Path.py:93-94
+        for (int q = tid; q < PPN_PATH_POINTS - 1; q += NT)
+            part += dist2d(pp[q][0], pp[q][1], pp[q + 1][0], pp[q + 1][1]);
+        const double len = block_sum<NW>(part, red_v);
+        if (tid == 0) {
+            O.length[p] = len;
+            O.straight[p] = path_straight ? 1 : 0;
+        }
+    }
+    const double Ex = S.segpoint[PPN_SEGS][0], Ey = S.segpoint[PPN_SEGS][1];
+
+    // ------------------------------------------------------------------ A3 + A4: boundary rays -> canvas
+    {
+        const int n_steps = (int)rint(0.8 * clearance / step_len);      // Path.py:119,398
+        double u0x, u0y, ulx, uly, tnx, tny;
+        {   // up.point[0][0] and up.point[9][49] seed the semicircular caps (Path.py:334-343)
+            double px, py;
+            boundary_sample(S, 0, 0, px, py, tnx, tny);
+            u0x = px - 0.5 * clearance * tnx; u0y = py - 0.5 * clearance * tny;
+            boundary_sample(S, PPN_SEGS - 1, 49, px, py, tnx, tny);
+            ulx = px - 0.5 * clearance * tnx; uly = py - 0.5 * clearance * tny;
+        }
+        for (int r = tid; r < PPN_BOUNDARY_POINTS; r += NT) {
+            double sx, sy, dx, dy;
+            int slot;
+            if (r < 50) {                                        // init cap
+                const double a = 3.141592653589793 / 50.0 * (double)(r + 1);
+                rot2(cos(a), sin(a), u0x, u0y, sx, sy);
+                const double n = sqrt(sx * sx + sy * sy);
+                dx = -step_len * sx / n; dy = -step_len * sy / n;       // Path.py:121
+                slot = 49 - r;
+            } else if (r < 100) {                                // end cap
+                const int i = r - 50;
+                const double a = -3.141592653589793 / 50.0 * (double)(i + 1);
+                double qx, qy;
+                rot2(cos(a), sin(a), ulx - Ex, uly - Ey, qx, qy);
+                sx = qx + Ex; sy = qy + Ey;
+                const double vx = Ex - sx, vy = Ey - sy;
+                const double n = sqrt(vx * vx + vy * vy);
+                dx = step_len * vx / n; dy = step_len * vy / n;         // Path.py:124-125
+                slot = 550 + i;
+            } else {
+                const bool up = r < 600;
+                const int q = up ? r - 100 : r - 600;
+                const int s = q / 50, j = q - s * 50;
+                double px, py, nx, ny;
+                boundary_sample(S, s, j, px, py, nx, ny);
+                if (up) {
+                    sx = px - 0.5 * clearance * nx; sy = py - 0.5 * clearance * ny;
+                    dx = step_len * nx; dy = step_len * ny;
+                    slot = 50 + q;
+                } else {
+                    sx = px + 0.5 * clearance * nx; sy = py + 0.5 * clearance * ny;
+                    dx = step_len * (-1.0 * nx); dy = step_len * (-1.0 * ny);
+                    slot = 600 + (499 - q);
+                }
+            }
+            if (O.boundary_world) {
+                O.boundary_world[((size_t)p * PPN_BOUNDARY_POINTS + slot) * 2] = sx;
+                O.boundary_world[((size_t)p * PPN_BOUNDARY_POINTS + slot) * 2 + 1] = sy;
+            }
+            for (int k = 0; k < n_steps; ++k) {                  // free_space_bydirection
+                const double qx = sx + (double)k * dx, qy = sy + (double)k * dy;
+                const int i0 = (int)rint(qx / step_c2i + Rd);
+                const int i1 = (int)rint(qy / step_c2i + Rd);
+                if (i0 > 0 && i0 < 2 * R && i1 > 0 && i1 < 2 * R) {     // strict, Path.py:400
+                    const int bit = i0 * 2 * R + i1;
+                    atomicOr(&canvas[bit >> 5], 1u << (bit & 31));
+                } else break;
+            }
+        }
+    }
+    __syncthreads();
+    if (O.canvas_bits)
+        for (int w = tid; w < canvas_words; w += NT) O.canvas_bits[(size_t)p * canvas_words + w] = canvas[w];
+
+    // ------------------------------------------------------------------ A5: exact integer hull (gift wrapping)
+    int hn = 0;
+    {
+        // start = lexicographically smallest lattice point
+        long long key = 0x7fffffffffffffffLL;
+        for (int q = tid; q < PPN_PATH_POINTS; q += NT) {
+            const long long k = ((long long)(lat[q][0] + 1048576) << 32) | (long long)(lat[q][1] + 1048576);
+            key = k < key ? k : key;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const long long t = __shfl_xor(key, o, 64); key = t < key ? t : key; }
+        __syncthreads();
+        if (lane == 0) { red_i[wv] = (int)(key >> 32); bci[4 + wv] = (int)(key & 0xffffffffLL); }
+        __syncthreads();
+        long long best = 0x7fffffffffffffffLL;
+        for (int w = 0; w < NW; ++w) {
+            const long long k = ((long long)red_i[w] << 32) | (long long)(uint32_t)bci[4 + w];
+            best = k < best ? k : best;
+        }
+        const int sx0 = (int)(best >> 32) - 1048576, sy0 = (int)(best & 0xffffffffLL) - 1048576;
+        int cx = sx0, cy = sy0;
+        __syncthreads();
+        while (true) {
+            if (tid == 0) { hull_i[hn][0] = cx; hull_i[hn][1] = cy; }
+            ++hn;
+            // candidate: the point with every other point on or to the left of cur -> cand
+            int bx = 0, by = 0, have = 0;
+            for (int q = tid; q < PPN_PATH_POINTS; q += NT) {
+                const int rx = lat[q][0], ry = lat[q][1];
+                if (rx == cx && ry == cy) continue;
+                if (!have) { bx = rx; by = ry; have = 1; continue; }
+                const long long cr = (long long)(bx - cx) * (ry - cy) - (long long)(by - cy) * (rx - cx);
+                if (cr < 0) { bx = rx; by = ry; }
+                else if (cr == 0) {
+                    const long long db = (long long)(bx - cx) * (bx - cx) + (long long)(by - cy) * (by - cy);
+                    const long long dr = (long long)(rx - cx) * (rx - cx) + (long long)(ry - cy) * (ry - cy);
+                    if (dr > db) { bx = rx; by = ry; }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int ox = __shfl_xor(bx, o, 64), oy = __shfl_xor(by, o, 64), oh = __shfl_xor(have, o, 64);
+                if (oh) {
+                    if (!have) { bx = ox; by = oy; have = 1; }
+                    else {
+                        const long long cr = (long long)(bx - cx) * (oy - cy) - (long long)(by - cy) * (ox - cx);
+                        if (cr < 0) { bx = ox; by = oy; }
+                        else if (cr == 0) {
+                            const long long db = (long long)(bx - cx) * (bx - cx) + (long long)(by - cy) * (by - cy);
+                            const long long dr = (long long)(ox - cx) * (ox - cx) + (long long)(oy - cy) * (oy - cy);
+                            if (dr > db) { bx = ox; by = oy; }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (lane == 0) { red_i[wv] = have; bci[wv] = bx; bci[4 + wv] = by; }
+            __syncthreads();
+            int fx = 0, fy = 0, fh = 0;
+            for (int w = 0; w < NW; ++w) {
+                if (!red_i[w]) continue;
+                const int ox = bci[w], oy = bci[4 + w];
+                if (!fh) { fx = ox; fy = oy; fh = 1; continue; }
+                const long long cr = (long long)(fx - cx) * (oy - cy) - (long long)(fy - cy) * (ox - cx);
+                if (cr < 0) { fx = ox; fy = oy; }
+                else if (cr == 0) {
+                    const long long db = (long long)(fx - cx) * (fx - cx) + (long long)(fy - cy) * (fy - cy);
+                    const long long dr = (long long)(ox - cx) * (ox - cx) + (long long)(oy - cy) * (oy - cy);
+                    if (dr > db) { fx = ox; fy = oy; }
+                }
+            }
+            __syncthreads();
+            if (!fh || (fx == sx0 && fy == sy0)) break;
+            if (hn >= PPN_MAX_HULL) { flags |= PPN_FLAG_HULL_CAP; break; }
+            cx = fx; cy = fy;
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ A6: normalisation
+    if (tid == 0) {
+        const double rotation = atan(Ey / Ex) / 3.141592653589793 * 180.0 + (-135.0);   // Path.py:159
+        const double rad = -rotation / 180.0 * 3.141592653589793;
+        const double c = cos(rad), s = sin(rad);
+        double mx = 0.0, my = 0.0;
+        for (int i = 0; i < hn; ++i) {                           // Path.py:162-164
+            double hx, hy;
+            rot2(c, s, (double)hull_i[i][0] - Rd, (double)hull_i[i][1] - Rd, hx, hy);
+            hull[i][0] = hx + Rd; hull[i][1] = hy + Rd;
+            mx += hull[i][0]; my += hull[i][1];
+        }
+        mx = mx / (double)hn; my = my / (double)hn;              // torch.mean, Path.py:167
+        const double t0 = Rd / 2.0 - mx, t1 = Rd / 2.0 - my;      // (t_row, t_col)
+        for (int i = 0; i < hn; ++i) { hull[i][0] = hull[i][0] + t0; hull[i][1] = hull[i][1] + t1; }
+        bc[0] = rotation; bc[1] = c; bc[2] = s; bc[3] = t0; bc[4] = t1;
+        const double b = (-rotation) * 3.141592653589793 / 180.0;       // rotate_nearest(canvas, -rotation)
+        bc[5] = cos(b); bc[6] = sin(b);
+        O.rotation[p] = rotation;
+        O.trans_rc[(size_t)p * 2] = t0; O.trans_rc[(size_t)p * 2 + 1] = t1;
+        O.hull_n[p] = hn;
+    }
+    __syncthreads();
+    const double nc = bc[1], ns = bc[2], t_row = bc[3], t_col = bc[4];
+    if (tid < PPN_MAX_HULL) {
+        const bool v = tid < hn;
+        O.hull[((size_t)p * PPN_MAX_HULL + tid) * 2] = v ? hull[tid][0] : 0.0;
+        O.hull[((size_t)p * PPN_MAX_HULL + tid) * 2 + 1] = v ? hull[tid][1] : 0.0;
+        if (O.hull_raw) {
+            O.hull_raw[((size_t)p * PPN_MAX_HULL + tid) * 2] = v ? (double)hull_i[tid][0] : 0.0;
+            O.hull_raw[((size_t)p * PPN_MAX_HULL + tid) * 2 + 1] = v ? (double)hull_i[tid][1] : 0.0;
+        }
+    }
+    if (tid < PPN_SEGS + 1) {                                    // Path.py:180-182
+        double rx, ry;
+        rot2(nc, ns, S.segpoint[tid][0], S.segpoint[tid][1], rx, ry);
+        O.segpoint_image[((size_t)p * 11 + tid) * 2] = rint(rx / step_c2i + Rd) + t_row;
+        O.segpoint_image[((size_t)p * 11 + tid) * 2 + 1] = rint(ry / step_c2i + Rd) + t_col;
+    }
+    for (int q = tid; q < PPN_PATH_POINTS; q += NT) {            // Path.py:183-185
+        double rx, ry;
+        rot2(nc, ns, pp[q][0], pp[q][1], rx, ry);
+        rx = rint(rx / step_c2i + Rd) + t_row;
+        ry = rint(ry / step_c2i + Rd) + t_col;
+        pp[q][0] = rx; pp[q][1] = ry;                            // each thread owns its q: no race
+        O.pathpoint_image[((size_t)p * PPN_PATH_POINTS + q) * 2] = rx;
+        O.pathpoint_image[((size_t)p * PPN_PATH_POINTS + q) * 2 + 1] = ry;
+    }
+
+    // corridor mask Path.Space: rotate (nearest, about the canvas centre) then translate + crop,
+    // composed per output pixel; 32 pixels (one mask word) per thread iteration
+    {
+        const double c2 = bc[5], s2 = bc[6];
+        const int words = R * R / 32, wpr = R / 32;
+        for (int w = tid; w < words; w += NT) {
+            const int i = w / wpr, j0 = (w - i * wpr) * 32;
+            const int i1 = (int)rint((double)i - t_row);         // translate_nearest: ty = t_row
+            uint32_t m = 0u;
+            if (i1 >= 0 && i1 < 2 * R) {
+                const double yo = ((double)i1 + 0.5) - Rd;
+                for (int b = 0; b < 32; ++b) {
+                    const int j1 = (int)rint((double)(j0 + b) - t_col);
+                    if (j1 < 0 || j1 >= 2 * R) continue;
+                    const double xo = ((double)j1 + 0.5) - Rd;
+                    const double xs = c2 * xo - s2 * yo, ys = s2 * xo + c2 * yo;
+                    const int jj = (int)rint(xs + (Rd - 0.5)), ii = (int)rint(ys + (Rd - 0.5));
+                    if (ii < 0 || ii >= 2 * R || jj < 0 || jj >= 2 * R) continue;
+                    const int bit = ii * 2 * R + jj;
+                    m |= ((canvas[bit >> 5] >> (bit & 31)) & 1u) << b;
+                }
+            }
+            O.space_bits[(size_t)p * words + w] = m;
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ A7: search_isle
+    __shared__ int isles[PPN_MAX_ISLES][2];
+    int n_isles = 0;
+    if (!path_straight) {
+        const int thr = (int)rint(clearance / step_len * 0.2);   // Path.py:533
+        for (int i = 0; i < hn; ++i) {
+            const int j = (i == hn - 1) ? 0 : i + 1;
+            const double ex = hull[j][0] - hull[i][0], ey = hull[j][1] - hull[i][1];
+            if (!(sqrt(ex * ex + ey * ey) > 5.0 / step_len)) continue;  // Path.py:512
+            MinIdx m0{1e300, 0x7fffffff}, m1{1e300, 0x7fffffff};
+            for (int q = tid; q < PPN_PATH_POINTS; q += NT) {
+                const double a = dist2d(pp[q][0], pp[q][1], hull[i][0], hull[i][1]);
+                const double b = dist2d(pp[q][0], pp[q][1], hull[j][0], hull[j][1]);
+                m0 = min_idx(m0, MinIdx{a, q});
+                m1 = min_idx(m1, MinIdx{b, q});
+            }
+            m0 = block_min_idx<NW>(m0, red_v, red_i);
+            m1 = block_min_idx<NW>(m1, red_v, red_i);
+            const int lo = min(m0.i, m1.i), hi = max(m0.i, m1.i);
+            if (hi == lo) { flags |= PPN_FLAG_EMPTY_ISLE; continue; }
+            const int len = hi - lo;
+            const double vx = pp[lo][0] - pp[hi - 1][0], vy = pp[lo][1] - pp[hi - 1][1];
+            const double nrm = sqrt(vx * vx + vy * vy);
+            if (nrm == 0.0) continue;
+            const double d0x = vx / nrm, d0y = vy / nrm;
+            const double dirx = d0y, diry = -d0x;
+            int first = 0x7fffffff;
+            for (int k = tid; k < len; k += NT) {
+                const double dis = fabs((pp[lo + k][0] - pp[lo][0]) * dirx + (pp[lo + k][1] - pp[lo][1]) * diry);
+                if (dis > (double)thr + PPN_TIE_EPS) { first = k; break; }
+            }
+            first = block_min_int<NW>(first, red_i);
+            const int k = first == 0x7fffffff ? len - 1 : first;
+            const bool isle = (pp[lo + k][0] != pp[hi - 1][0]) || (pp[lo + k][1] != pp[hi - 1][1]);   // Path.py:535
+            if (isle) {
+                if (n_isles < PPN_MAX_ISLES) {
+                    if (tid == 0) { isles[n_isles][0] = lo; isles[n_isles][1] = hi; }
+                    ++n_isles;
+                } else flags |= PPN_FLAG_ISLE_CAP;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < PPN_MAX_ISLES) {
+        O.isles[((size_t)p * PPN_MAX_ISLES + tid) * 2] = tid < n_isles ? isles[tid][0] : 0;
+        O.isles[((size_t)p * PPN_MAX_ISLES + tid) * 2 + 1] = tid < n_isles ? isles[tid][1] : 0;
+    }
+
+    // ------------------------------------------------------------------ A8: set_obstacles
+    int n_obs = 0;
+    {
+        const double c_px = clearance / prm.map_size * Rd;               // Path.py:490
+        const float size_clearance_f = (float)(clearance / prm.map_size * Rd * 1.1);   // Path.py:465
+        const float c_px_f = (float)c_px;
+        uint32_t fdraw = 0;                                              // torch.rand counter
+        const float* pfed = prm.pocket ? prm.pocket + (size_t)p * prm.pocket_stride : nullptr;
+        auto next_float = [&]() -> float {
+            float v;
+            if (pfed) v = (int)fdraw < prm.pocket_stride ? pfed[fdraw] : 0.5f;
+            else v = philox_float(prm.seed, STREAM_POCKET, pid, fdraw);
+            ++fdraw;
+            return v;
+        };
+        for (int is = 0; is < n_isles; ++is) {
+            const int lo = isles[is][0], hi = isles[is][1], len = hi - lo;
+            const double cxm = (pp[lo][0] + pp[hi - 1][0]) / 2.0, cym = (pp[lo][1] + pp[hi - 1][1]) / 2.0;
+            const double vx = pp[lo][0] - pp[hi - 1][0], vy = pp[lo][1] - pp[hi - 1][1];
+            const double vn = sqrt(vx * vx + vy * vy);
+            const double dtx = vx / vn, dty = vy / vn;
+            double dnx = dty, dny = -dtx;
+            const int mi = lo + len / 2;
+            const double mdx = pp[mi][0] - cxm, mdy = pp[mi][1] - cym;
+            if (!(mdx * dnx + mdy * dny < 0.0)) { dnx = -dnx; dny = -dny; }     // Path.py:470
+            double mymax = -1.0;
+            for (int k = tid; k < len; k += NT) {
+                const double dis = fabs((pp[lo + k][0] - pp[lo][0]) * dnx + (pp[lo + k][1] - pp[lo][1]) * dny);
+                mymax = fmax(mymax, dis);
+            }
+            const double dmax = block_max<NW>(mymax, red_v);
+            int first = 0x7fffffff;
+            for (int k = tid; k < len; k += NT) {
+                const double dis = fabs((pp[lo + k][0] - pp[lo][0]) * dnx + (pp[lo + k][1] - pp[lo][1]) * dny);
+                if (dis >= dmax - PPN_TIE_EPS) { first = k; break; }
+            }
+            first = block_min_int<NW>(first, red_i);
+            const double size_max = dmax * 2.0;
+            const float size_max_f = (float)size_max;
+            const double pkx = pp[lo + first][0], pky = pp[lo + first][1];
+            float obs_sum = 0.0f;
+            int cnt = 0, tries = 0;
+            float size_pre_f = 0.0f;
+            double coordx = 0.0, coordy = 0.0;
+            while ((double)obs_sum < size_max) {                         // Path.py:478
+                if (tries >= PPN_POCKET_TRY_CAP) { flags |= PPN_FLAG_POCKET_CAP; break; }
+                ++tries;
+                const float radius = (next_float() * size_max_f) / 2.0f;
+                const float rn = cnt ? next_float() : 1.0f;
+                float acc = radius + size_pre_f;
+                acc = acc + (cnt == 0 ? size_clearance_f : 0.0f);
+                float motion = rn * acc;
+                const float alt = radius - obs_sum;
+                if (alt > motion) motion = alt;                          // python max(motion, alt)
+                const double bx = cnt == 0 ? pkx : coordx, by = cnt == 0 ? pky : coordy;
+                coordx = bx + (double)motion * dnx;
+                coordy = by + (double)motion * dny;
+                if (cnt) {
+                    const float jit = ((((next_float() - 0.5f) / 0.5f) * radius) / 2.0f);
+                    coordx = coordx + (double)jit * dtx;
+                    coordy = coordy + (double)jit * dty;
+                }
+                double mymin = 1e300;
+                for (int q = tid; q < PPN_PATH_POINTS / 2; q += NT)         // odd-indexed points, Path.py:487-489
+                    mymin = fmin(mymin, dist2d(pp[2 * q + 1][0], pp[2 * q + 1][1], coordx, coordy));
+                const double md = block_min<NW>(mymin, red_v);
+                double rad_out = (double)radius;
+                bool clipped = false;
+                if (md < (double)(radius + c_px_f)) { rad_out = md - c_px; clipped = true; }    // Path.py:490-491
+                if (rad_out > 0.0) {
+                    obs_sum = obs_sum + motion;
+                    ++cnt;
+                    size_pre_f = clipped ? (float)rad_out : radius;
+                    if (n_obs < PPN_MAX_POCKET) {
+                        if (tid == 0) {
+                            double* o = O.obstacles + ((size_t)p * PPN_MAX_POCKET + n_obs) * 3;
+                            o[0] = coordy; o[1] = coordx; o[2] = rad_out;   // [col,row,r], Path.py:495
+                        }
+                        ++n_obs;
+                    } else flags |= PPN_FLAG_POCKET_FULL;
+                }
+            }
+        }
+    }
+    if (tid == 0) {
+        O.n_isles[p] = n_isles;
+        O.n_obstacles[p] = n_obs;
+        O.flags[p] = flags;
+    }
+}
+
+}  // namespace ppn

@@ -1,0 +1,119 @@
+// plan_tail.hip — planner tail of the PPNet inference path on gfx950 (reference: EDaGe-PP/process_map.py).
+//
+//   collision_segments_kernel : collision_check_circle_edge (process_map.py:383-425), one thread per
+//                               segment, float32 like the reference's torch tensors; the any-hit
+//                               over a problem's waypoint segments is a host-side reduce of `hit`.
+//   extract_paths_kernel      : extract_path's greedy 8-neighbour walk (process_map.py:293-365), one
+//                               wave64 per problem: candidates are scored by lanes 0..7, the revisit
+//                               test (<= 1.5 px to an earlier point) runs one history point per lane
+//                               with a ballot; the 1 s wall-clock timeout becomes the max_wp cap.
+#include "ppn_device.h"
+#include "ppn_kernels.h"
+
+namespace ppn {
+
+__global__ __launch_bounds__(256) void collision_segments_kernel(const float* s_in, const float* e_in,
+                                                                 const int32_t* prob, int n_seg, const float* obs,
+                                                                 const int32_t* obs_off, float clearance,
+                                                                 uint8_t* hit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_seg) return;
+    const float s0 = s_in[i * 2], s1 = s_in[i * 2 + 1], e0 = e_in[i * 2], e1 = e_in[i * 2 + 1];
+    if (s0 < 0.0f || s1 > 224.0f || e0 < 0.0f || e1 > 224.0f) { hit[i] = 1; return; }   // process_map.py:384-387
+    const float sx = s1, sy = s0, ex = e1, ey = e0;                       // swap to (x, y), :388-389
+    float dx = ex - sx, dy = ey - sy;
+    const float nrm = sqrtf(dx * dx + dy * dy);
+    float dirx = dy / nrm, diry = -dx / nrm;                              // :390-391
+    const double lim_add = (double)clearance / 2.0;
+    const int p = prob[i];
+    uint8_t h = 0;
+    for (int k = obs_off[p]; k < obs_off[p + 1]; ++k) {
+        const float ox = obs[k * 3], oy = obs[k * 3 + 1];
+        const double size = (double)obs[k * 3 + 2];
+        const double lim = size + lim_add;
+        // scipy euclidean on float32 inputs: float64 arithmetic
+        const double ddx = (double)ex - (double)ox, ddy = (double)ey - (double)oy;
+        if (sqrt(ddx * ddx + ddy * ddy) < lim) { h = 1; break; }         // :397 (tests e twice, never s)
+        const float qx = ox - sx, qy = oy - sy;
+        float dis = dirx * qx + diry * qy;                                // np.dot, float32
+        if (dis > 0.0f) { dirx = -dirx; diry = -diry; }                   // dir mutates across obstacles, :406-407
+        dis = fabsf(dis);
+        const float px = ox + dis * dirx, py = oy + dis * diry;
+        float ax = px - sx, ay = py - sy;
+        const float an = sqrtf(ax * ax + ay * ay);
+        ax = ax / an; ay = ay / an;
+        float bx = px - ex, by = py - ey;
+        const float bn = sqrtf(bx * bx + by * by);
+        bx = bx / bn; by = by / bn;
+        if ((double)dis < lim && (ax * bx + ay * by) < 0.0f) { h = 1; break; }   // :414
+    }
+    hit[i] = h;
+}
+
+__global__ __launch_bounds__(64) void extract_paths_kernel(const float* heat, int n, int H, int W, const float* init,
+                                                           const float* end, int max_wp, float* wp, int32_t* wp_n,
+                                                           uint8_t* ok) {
+    __shared__ short hist[PPN_MAX_WAYPOINTS][2];                         // offsets from init, exact small ints
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const float* hm = heat + (size_t)p * H * W;
+    float* out = wp + (size_t)p * max_wp * 2;
+    const double i0 = (double)init[p * 2], i1 = (double)init[p * 2 + 1];
+    const double g0 = (double)end[p * 2], g1 = (double)end[p * 2 + 1];
+    const int mr[8] = {0, 0, 1, -1, 1, 1, -1, -1};                        // motions, process_map.py:294-297
+    const int mc[8] = {1, -1, 0, 0, 1, -1, 1, -1};
+    // a waypoint is init + integer offset: keep the offsets exact in int, rebuild doubles on demand
+    int cr = 0, cc = 0, cnt = 0, success = 0;
+    while (cnt < max_wp) {
+        // lanes 0..7 score the candidates
+        float v = 0.0f;
+        int nr = 0, nc = 0;
+        if (lane < 8) {
+            nr = cr + mr[lane]; nc = cc + mc[lane];
+            const int ri = (int)rint(i0 + (double)nr), ci = (int)rint(i1 + (double)nc);
+            if (ri >= 0 && ri < W && ci >= 0 && ci < H) v = hm[(size_t)ri * W + ci];   // :318 (size[0] bounds c[0])
+        }
+        int chosen = -1;
+        while (true) {
+            // first maximum among lanes 0..7 with v > 0
+            float best = 0.0f; int bi = -1;
+            for (int k = 0; k < 8; ++k) {
+                const float vk = __shfl(v, k, 64);
+                if (vk > best) { best = vk; bi = k; }
+            }
+            if (bi < 0) break;                                            // max(candidate_v) == 0 -> fail
+            const int br = __shfl(nr, bi, 64), bcn = __shfl(nc, bi, 64);
+            // revisit test against history[0 .. cnt-3] (process_map.py:327: equal, or <=1.5 px and i < len-2)
+            bool rej = false;
+            for (int b = 0; b < cnt; b += 64) {
+                const int q = b + lane;
+                bool r = false;
+                if (q < cnt) {
+                    const int hr = hist[q][0], hc = hist[q][1];
+                    const int dr = hr - br, dc = hc - bcn;
+                    const bool same = (dr == 0 && dc == 0);
+                    const bool nearp = (dr * dr + dc * dc) <= 2;                // lattice distance <= 1.5
+                    r = same || (nearp && q < cnt - 2);
+                }
+                if (__ballot(r) != 0ull) { rej = true; break; }
+            }
+            if (!rej) { chosen = bi; break; }
+            if (lane == bi) v = 0.0f;                                      // candidate_v[candidate_i] = 0
+        }
+        if (chosen < 0) break;
+        cr = __shfl(nr, chosen, 64); cc = __shfl(nc, chosen, 64);
+        if (lane == 0) { hist[cnt][0] = (short)cr; hist[cnt][1] = (short)cc; }
+        ++cnt;
+        __syncthreads();                                                  // single wave: orders the LDS store
+        const double d0 = (i0 + (double)cr) - g0, d1 = (i1 + (double)cc) - g1;
+        if (sqrt(d0 * d0 + d1 * d1) <= 2.5) { success = 1; break; }       // :346
+    }
+    // offsets -> coordinates (still in down-sampled units; the host scales by the rate)
+    __syncthreads();
+    for (int q = lane; q < cnt; q += 64) {
+        out[q * 2] = (float)(i0 + (double)hist[q][0]);
+        out[q * 2 + 1] = (float)(i1 + (double)hist[q][1]);
+    }
+    if (lane == 0) { wp_n[p] = success ? cnt : 0; ok[p] = (uint8_t)success; }
+}
+
+}  // namespace ppn

@@ -1,0 +1,174 @@
+// ppn_device.h — device helpers shared by the gfx950 kernels: Philox4x32-10 draws, wave64 /
+// workgroup reductions, strict (unfused) double arithmetic.
+//
+// All kernels in this library are compiled with -ffp-contract=off: the parity contract with
+// the oracle (oracle/edage_np.py, ARITH="plain") is rn(a*b) then rn(+), never an fma.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PPN_WAVE 64
+#define PPN_TIE_EPS 1e-9
+
+namespace ppn {
+
+// ------------------------------------------------------------------------------------ Philox
+// Salmon et al. SC'11, Random123 constants; counter = (block, inst_hi, inst_lo, stream).
+enum : uint32_t { STREAM_PATH = 1, STREAM_POCKET = 2, STREAM_PLACE = 3, STREAM_OBST = 4 };
+
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        if (r) { k0 += W0; k1 += W1; }
+        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    }
+    return {c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
+    // numpy random_sample recipe: (a>>5, b>>6) -> (a*2^26 + b) / 2^53; every step exact
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// draw index d of (stream, instance): block d>>1, even -> words (0,1), odd -> (2,3)
+__device__ __forceinline__ double philox_double(uint64_t seed, uint32_t stream, uint64_t inst, uint32_t d) {
+    u32x4 o = philox4x32_10(d >> 1, (uint32_t)(inst >> 32), (uint32_t)inst, stream,
+                            (uint32_t)seed, (uint32_t)(seed >> 32));
+    return (d & 1) ? u53(o.z, o.w) : u53(o.x, o.y);
+}
+
+// both doubles of block b (draws 2b and 2b+1)
+__device__ __forceinline__ void philox_double2(uint64_t seed, uint32_t stream, uint64_t inst, uint32_t b,
+                                               double& d0, double& d1) {
+    u32x4 o = philox4x32_10(b, (uint32_t)(inst >> 32), (uint32_t)inst, stream,
+                            (uint32_t)seed, (uint32_t)(seed >> 32));
+    d0 = u53(o.x, o.y);
+    d1 = u53(o.z, o.w);
+}
+
+// torch.rand recipe: (w & 0xFFFFFF) / 2^24; draw d: block d>>2, word d&3
+__device__ __forceinline__ float philox_float(uint64_t seed, uint32_t stream, uint64_t inst, uint32_t d) {
+    u32x4 o = philox4x32_10(d >> 2, (uint32_t)(inst >> 32), (uint32_t)inst, stream,
+                            (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint32_t w = (d & 3) == 0 ? o.x : (d & 3) == 1 ? o.y : (d & 3) == 2 ? o.z : o.w;
+    return (float)(w & 0xFFFFFFu) * (1.0f / 16777216.0f);
+}
+
+// ------------------------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;   // valid in lane 0
+}
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;   // valid in every lane
+}
+
+struct MinIdx { double v; int i; };
+
+// (value, index) lexicographic minimum: smallest value, then smallest index ("first strict minimum")
+__device__ __forceinline__ MinIdx min_idx(MinIdx a, MinIdx b) {
+    return (b.v < a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+
+__device__ __forceinline__ MinIdx wave_min_idx(MinIdx m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        MinIdx t;
+        t.v = __shfl_xor(m.v, o, 64);
+        t.i = __shfl_xor(m.i, o, 64);
+        m = min_idx(m, t);
+    }
+    return m;
+}
+
+// Workgroup-wide reductions through a small LDS scratch (one slot per wave).  Every thread of
+// the workgroup must call; the result is returned to every thread.  NW = waves per workgroup.
+template <int NW>
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += scratch[i];   // fixed order -> deterministic
+    return s;
+}
+
+template <int NW>
+__device__ __forceinline__ double block_min(double v, double* scratch) {
+    v = wave_min(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double s = scratch[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) s = fmin(s, scratch[i]);
+    return s;
+}
+
+template <int NW>
+__device__ __forceinline__ double block_max(double v, double* scratch) {
+    return -block_min<NW>(-v, scratch);
+}
+
+template <int NW>
+__device__ __forceinline__ MinIdx block_min_idx(MinIdx m, double* scratch_v, int* scratch_i) {
+    m = wave_min_idx(m);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { scratch_v[w] = m.v; scratch_i[w] = m.i; }
+    __syncthreads();
+    MinIdx r{scratch_v[0], scratch_i[0]};
+#pragma unroll
+    for (int i = 1; i < NW; ++i) r = min_idx(r, MinIdx{scratch_v[i], scratch_i[i]});
+    return r;
+}
+
+template <int NW>
+__device__ __forceinline__ int block_min_int(int v, int* scratch_i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch_i[w] = v;
+    __syncthreads();
+    int r = scratch_i[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) r = min(r, scratch_i[i]);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------ geometry
+// coord_rotation (EDaGe-PP/Path.py:271-274), unfused: (c*x - s*y, s*x + c*y)
+__device__ __forceinline__ void rot2(double c, double s, double x, double y, double& ox, double& oy) {
+    ox = c * x - s * y;
+    oy = s * x + c * y;
+}
+
+__device__ __forceinline__ double horner4(const double* p, double x) {   // np.polyval, degree 4
+    double y = 0.0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) y = y * x + p[k];
+    return y;
+}
+
+__device__ __forceinline__ double dist2d(double ax, double ay, double bx, double by) {
+    double dx = ax - bx, dy = ay - by;
+    return sqrt(dx * dx + dy * dy);
+}
+
+}  // namespace ppn

@@ -1,0 +1,47 @@
+// ppn_kernels.h — kernel parameter blocks and launch prototypes (internal to libppnet_hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ppnet_hip.h"
+
+namespace ppn {
+
+struct PathsParams {
+    ppn_paths_t out;
+    int n_paths;
+    uint64_t first_id;
+    int R;
+    double map_size, clearance;
+    uint64_t seed;
+    const double* draws;       // [n][PPN_DRAWS_PER_PATH] or null
+    const float* pocket;       // [n][pocket_stride] or null
+    int pocket_stride;
+    const double* W;           // [4][1000] least-squares operator (device)
+};
+
+struct MapsParams {
+    ppn_paths_t paths;
+    ppn_maps_t out;
+    int n_paths, placements, n_maps;
+    uint64_t first_map_id;
+    int R;
+    double map_size, obstacles_size, clearance;
+    int K;
+    uint64_t seed;
+    const double* place_draws; // [n_maps][3] or null
+    const double* obst_draws;  // [n_maps][3K] or null
+};
+
+__global__ void edage_paths_kernel(PathsParams prm);
+__global__ void edage_maps_kernel(MapsParams prm);
+__global__ void boundary_check_kernel(const double* hull, int hull_n, const double* angle_deg,
+                                      const double* trans_rc, int n, int R, uint8_t* ok);
+__global__ void disc_raster_kernel(const double* obstacles, const int32_t* counts, int stride,
+                                   int n_maps, int R, uint8_t* grid);
+__global__ void collision_segments_kernel(const float* s, const float* e, const int32_t* prob, int n_seg,
+                                          const float* obs, const int32_t* obs_off, float clearance,
+                                          uint8_t* hit);
+__global__ void extract_paths_kernel(const float* heat, int n, int H, int W, const float* init,
+                                     const float* end, int max_wp, float* wp, int32_t* wp_n, uint8_t* ok);
+
+}  // namespace ppn

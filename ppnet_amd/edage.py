@@ -1,0 +1,155 @@
+"""Batched EDaGe-PP on MI355X: device buffers (torch) + calls through the C ABI.
+
+`generate_paths` = PathGroup.generate for n independent paths (reference EDaGe-PP/PathGenerate.py:33-50);
+`generate_maps`  = the body of MapGenerate.generate for n_paths x placements maps (MapGenerate.py:48-124).
+All results stay resident in HBM as torch tensors; nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _check_R(R):
+    if R % 32 != 0 or not (32 <= R <= 512):
+        raise ValueError(f"resolution must be a multiple of 32 in [32, 512], got {R}")
+
+
+class PathsBatch:
+    """Device-resident results of stage A (one row per target path); field names follow ppn_paths_t."""
+
+    def __init__(self, n, R, map_size, clearance, device, debug=False):
+        _check_R(R)
+        self.n, self.R, self.map_size, self.clearance, self.device = n, R, float(map_size), float(clearance), device
+        f64 = dict(dtype=torch.float64, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
+        z = torch.zeros
+        self.seg_poly = z(n, 10, 5, **f64)
+        self.seg_endpoint = z(n, 10, **f64)
+        self.seg_rotation = z(n, 10, **f64)
+        self.seg_translation = z(n, 10, 2, **f64)
+        self.seg_length = z(n, 10, **f64)
+        self.seg_straight = z(n, 10, **i32)
+        self.segpoint_world = z(n, 11, 2, **f64)
+        self.pathpoint_world = z(n, L.PATH_POINTS, 2, **f64)
+        self.boundary_world = z(n, L.BOUNDARY_POINTS, 2, **f64) if debug else None
+        self.canvas_bits = z(n, (2 * R) * (2 * R) // 32, **i32) if debug else None
+        self.hull_raw = z(n, L.MAX_HULL, 2, **f64) if debug else None
+        self.hull = z(n, L.MAX_HULL, 2, **f64)
+        self.hull_n = z(n, **i32)
+        self.rotation = z(n, **f64)
+        self.trans_rc = z(n, 2, **f64)
+        self.segpoint_image = z(n, 11, 2, **f64)
+        self.pathpoint_image = z(n, L.PATH_POINTS, 2, **f64)
+        self.space_bits = z(n, R * R // 32, **i32)
+        self.isles = z(n, L.MAX_ISLES, 2, **i32)
+        self.n_isles = z(n, **i32)
+        self.obstacles = z(n, L.MAX_POCKET, 3, **f64)
+        self.n_obstacles = z(n, **i32)
+        self.length = z(n, **f64)
+        self.straight = z(n, **i32)
+        self.flags = z(n, **i32)
+        self.struct = L.PathsStruct(**{name: _ptr(getattr(self, name)) for name, _ in L.PathsStruct._fields_})
+
+    def space_mask(self):
+        """Path.Space as a bool tensor [n, R, R] (unpacked on the device)."""
+        return _unpack_bits(self.space_bits, self.R, self.R)
+
+    def canvas_mask(self):
+        return _unpack_bits(self.canvas_bits, 2 * self.R, 2 * self.R)
+
+
+def _unpack_bits(words, h, w):
+    shifts = torch.arange(32, device=words.device, dtype=torch.int32)
+    bits = (words.unsqueeze(-1) >> shifts) & 1
+    return bits.reshape(words.shape[0], h, w).bool()
+
+
+class MapsBatch:
+    """Device-resident results of stage B (one row per map); field names follow ppn_maps_t."""
+
+    def __init__(self, n, R, K, device, want_pathpoint=True, want_accept=True):
+        self.n, self.R, self.K, self.device = n, R, K, device
+        f64 = dict(dtype=torch.float64, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
+        e = torch.empty
+        self.grid = e(n, R, R, dtype=torch.uint8, device=device)
+        self.angle = e(n, **f64)
+        self.translation = e(n, 2, **i32)
+        self.attempts = e(n, **i32)
+        self.segpoint = e(n, 11, 2, **f64)
+        self.pathpoint = e(n, L.PATH_POINTS, 2, **f64) if want_pathpoint else None
+        self.accept = e(n, max(K, 1), dtype=torch.uint8, device=device) if want_accept else None
+        self.obstacles = torch.zeros(n, K + L.MAX_POCKET, 3, **f64)
+        self.n_obstacles = e(n, 2, **i32)
+        self.flags = e(n, **i32)
+        self.struct = L.MapsStruct(**{name: _ptr(getattr(self, name)) for name, _ in L.MapsStruct._fields_})
+
+
+def generate_paths(n_paths, resolution=224, map_size=50, clearance=1, seed=0, first_path_id=0, device="cuda:0",
+                   draws=None, pocket_draws=None, debug=False, out=None):
+    """Stage A for `n_paths` paths. draws / pocket_draws: optional device tensors that replace the
+    Philox streams ([n, 10021] float64 in the fixed layout; [n, stride] float32 in torch.rand order)."""
+    device = torch.device(device)
+    pb = out if out is not None else PathsBatch(n_paths, resolution, map_size, clearance, device, debug=debug)
+    stride = 0
+    if draws is not None:
+        assert draws.dtype == torch.float64 and draws.is_contiguous() and tuple(draws.shape) == (n_paths, L.DRAWS_PER_PATH)
+    if pocket_draws is not None:
+        assert pocket_draws.dtype == torch.float32 and pocket_draws.is_contiguous() and pocket_draws.shape[0] == n_paths
+        stride = pocket_draws.shape[1]
+    with torch.cuda.device(device):
+        rc = L.lib.ppn_edage_paths(n_paths, first_path_id, resolution, float(map_size), float(clearance), seed,
+                                   _ptr(draws), _ptr(pocket_draws), stride, C.byref(pb.struct), _stream_ptr(device))
+    L.check(rc, "ppn_edage_paths")
+    return pb
+
+
+def generate_maps(paths, placements, obstacles_size=5, obstacles_num=50, seed=0, first_map_id=0, place_draws=None,
+                  obst_draws=None, want_pathpoint=True, want_accept=True, out=None):
+    """Stage B: `placements` maps for each target path in `paths` (a PathsBatch)."""
+    n = paths.n * placements
+    K = int(obstacles_num)
+    mb = out if out is not None else MapsBatch(n, paths.R, K, paths.device, want_pathpoint, want_accept)
+    if place_draws is not None:
+        assert place_draws.dtype == torch.float64 and place_draws.is_contiguous() and tuple(place_draws.shape) == (n, 3)
+    if obst_draws is not None:
+        assert obst_draws.dtype == torch.float64 and obst_draws.is_contiguous() and tuple(obst_draws.shape) == (n, 3 * K)
+    with torch.cuda.device(paths.device):
+        rc = L.lib.ppn_edage_maps(C.byref(paths.struct), paths.n, placements, first_map_id, paths.R, paths.map_size,
+                                  float(obstacles_size), K, paths.clearance, seed, _ptr(place_draws), _ptr(obst_draws),
+                                  C.byref(mb.struct), _stream_ptr(paths.device))
+    L.check(rc, "ppn_edage_maps")
+    return mb
+
+
+def boundary_check(hull, angle_deg, translation_rc, resolution):
+    """Path.boundary_check for n (angle, translation) pairs against one hull [h,2] (device tensors)."""
+    n = angle_deg.shape[0]
+    ok = torch.empty(n, dtype=torch.uint8, device=hull.device)
+    hull = hull.contiguous()
+    with torch.cuda.device(hull.device):
+        rc = L.lib.ppn_boundary_check(_ptr(hull), hull.shape[0], _ptr(angle_deg.contiguous()),
+                                      _ptr(translation_rc.contiguous()), n, resolution, _ptr(ok), _stream_ptr(hull.device))
+    L.check(rc, "ppn_boundary_check")
+    return ok.bool()
+
+
+def disc_raster(obstacles, counts, resolution):
+    """Explicit obstacle raster (stands in for Path.plot_obstacles): obstacles [n, stride, 3] f64, counts [n] i32."""
+    n, stride = obstacles.shape[0], obstacles.shape[1]
+    grid = torch.empty(n, resolution, resolution, dtype=torch.uint8, device=obstacles.device)
+    with torch.cuda.device(obstacles.device):
+        rc = L.lib.ppn_disc_raster(_ptr(obstacles.contiguous()), _ptr(counts.contiguous()), stride, n, resolution,
+                                   _ptr(grid), _stream_ptr(obstacles.device))
+    L.check(rc, "ppn_disc_raster")
+    return grid

@@ -1,0 +1,71 @@
+"""CPU-side checks of the C-ABI shared library: it loads, exports every function that
+include/ppnet_hip.h declares, rejects bad arguments without touching a GPU, and its host-side
+polyfit operator reproduces np.polyfit (the per-call LAPACK solve at PathSeg.py:24)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "ppnet_amd", "libppnet_hip.so")
+
+
+def _ensure_built():
+    if not os.path.exists(LIB):
+        import __graft_entry__ as g
+        g.build()
+    return C.CDLL(LIB)
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "ppnet_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ppn_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_functions_are_exported():
+    lib = _ensure_built()
+    names = _declared()
+    assert {"ppn_edage_paths", "ppn_edage_maps", "ppn_boundary_check", "ppn_disc_raster", "ppn_collision_segments",
+            "ppn_extract_paths", "ppn_polyfit_table", "ppn_version"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ppnet_hip.h but not exported"
+
+
+def test_binding_matches_header():
+    from ppnet_amd import _lib
+    assert sorted(_lib.EXPORTS) == _declared()
+    assert _lib.lib.ppn_version() >= 100
+    assert _lib.lib.ppn_error_string(-1) == b"invalid argument"
+    assert C.sizeof(_lib.PathsStruct) == 25 * C.sizeof(C.c_void_p)
+    assert C.sizeof(_lib.MapsStruct) == 10 * C.sizeof(C.c_void_p)
+
+
+def test_invalid_arguments_return_codes_without_gpu():
+    from ppnet_amd import _lib
+    L = _lib.lib
+    assert L.ppn_polyfit_table(None) == -1
+    ps, ms = _lib.PathsStruct(), _lib.MapsStruct()
+    assert L.ppn_edage_paths(1, 0, 100, 50.0, 3.0, 0, None, None, 0, C.byref(ps), None) == -1     # R % 32
+    assert L.ppn_edage_paths(1, 0, 64, 50.0, 3.0, 0, None, None, 0, C.byref(ps), None) == -1      # NULL outputs
+    assert L.ppn_edage_maps(C.byref(ps), 1, 1, 0, 64, 50.0, 5.0, 300, 3.0, 0, None, None, C.byref(ms), None) == -1
+    assert L.ppn_boundary_check(None, 0, None, None, 0, 64, None, None) == -1
+    assert L.ppn_extract_paths(None, 1, 8, 8, None, None, 16, None, None, None, None) == -1
+
+
+def test_polyfit_operator_matches_numpy():
+    from ppnet_amd import _lib
+    W = np.zeros((4, 1000))
+    assert _lib.lib.ppn_polyfit_table(W.ctypes.data_as(C.c_void_p)) == 0
+    x = np.arange(1000) / 100
+    rng = np.random.RandomState(0)
+    for _ in range(5):
+        y = rng.random_sample(1000) * 10 - 5
+        ref = np.polyfit(x, y, 4)
+        got = W @ y
+        assert np.abs(got - ref[:4]).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    # exactness on polynomials: fitting p(x) returns p
+    p = np.array([0.01, -0.2, 0.5, 1.5, 0.0])
+    assert np.abs(W @ np.polyval(p, x) - p[:4]).max() < 1e-11
