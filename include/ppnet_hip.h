@@ -98,6 +98,9 @@ typedef struct ppn_paths {
     double*   length;           /* [n] Path.Length                                     */
     int32_t*  straight;         /* [n] path-level is_straight                          */
     uint32_t* flags;            /* [n] PPN_FLAG_*                                      */
+    double*   max_step_px;      /* [n] largest distance between consecutive path points (and the last one to
+                                   the end point), in pixels; stage B uses it to prove that an obstacle cannot
+                                   touch the corridor and skip the compose for it */
 } ppn_paths_t;
 
 /* draws        : [n_paths][PPN_DRAWS_PER_PATH] uniform doubles in the fixed layout

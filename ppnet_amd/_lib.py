@@ -33,7 +33,7 @@ class PathsStruct(C.Structure):
         "seg_poly", "seg_endpoint", "seg_rotation", "seg_translation", "seg_length", "seg_straight",
         "segpoint_world", "pathpoint_world", "boundary_world", "canvas_bits", "hull_raw", "hull", "hull_n",
         "rotation", "trans_rc", "segpoint_image", "pathpoint_image", "space_bits", "isles", "n_isles",
-        "obstacles", "n_obstacles", "length", "straight", "flags")]
+        "obstacles", "n_obstacles", "length", "straight", "flags", "max_step_px")]
 
 
 class MapsStruct(C.Structure):

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <mutex>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -113,7 +114,7 @@ int ppn_edage_paths(int32_t n_paths, uint64_t first_path_id, int32_t R, double m
     if (!o.seg_poly || !o.seg_endpoint || !o.seg_rotation || !o.seg_translation || !o.seg_straight ||
         !o.segpoint_world || !o.pathpoint_world || !o.hull || !o.hull_n || !o.rotation || !o.trans_rc ||
         !o.segpoint_image || !o.pathpoint_image || !o.space_bits || !o.isles || !o.n_isles || !o.obstacles ||
-        !o.n_obstacles || !o.length || !o.straight || !o.flags)
+        !o.n_obstacles || !o.length || !o.straight || !o.flags || !o.max_step_px)
         return PPN_E_INVALID;
     if (n_paths == 0) return PPN_OK;
     ppn::PathsParams prm;
@@ -144,7 +145,7 @@ int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements
     const ppn_paths_t& p = *paths;
     const ppn_maps_t& o = *out;
     if (!p.hull || !p.hull_n || !p.segpoint_image || !p.pathpoint_image || !p.space_bits || !p.obstacles ||
-        !p.n_obstacles || !p.flags)
+        !p.n_obstacles || !p.flags || !p.max_step_px)
         return PPN_E_INVALID;
     if (!o.grid || !o.angle || !o.translation || !o.attempts || !o.segpoint || !o.obstacles || !o.n_obstacles || !o.flags)
         return PPN_E_INVALID;
@@ -166,7 +167,14 @@ int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements
     prm.seed = seed;
     prm.place_draws = place_draws;
     prm.obst_draws = obst_draws;
-    const size_t lds = (size_t)R * R / 8;
+    {   // validation knob: always run the corridor compose pass (tests compare it with the proven skip)
+        const char* f = getenv("PPN_FORCE_COMPOSE");
+        prm.force_compose = (f && f[0] == '1') ? 1 : 0;
+    }
+    // dynamic LDS: corridor mask + shared region (odd path points, then occupancy bits) + candidates + obstacles
+    const size_t shareA = (size_t)R * R / 8 > 8000 ? (size_t)R * R / 8 : 8000;
+    const size_t lds = (size_t)R * R / 8 + shareA + (size_t)K * 24 + (size_t)(K + PPN_MAX_POCKET) * 24;
+    PPN_HIP(hipFuncSetAttribute((const void*)ppn::edage_maps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(ppn::edage_maps_kernel, dim3((unsigned)n_maps), dim3(256), lds, (hipStream_t)stream, prm);
     PPN_HIP(hipGetLastError());
     return PPN_OK;

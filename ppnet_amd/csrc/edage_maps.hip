@@ -18,6 +18,17 @@
 
 namespace ppn {
 
+#ifdef PPN_PHASE_TIMING
+// diagnostic build only (make timing): per-phase s_memtime sums, never read by the kernel itself
+__device__ unsigned long long g_phase_cycles[16];
+#define PPN_STAMP(idx) do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        atomicAdd(&g_phase_cycles[idx], t_ - t_prev_); t_prev_ = t_; } } while (0)
+#define PPN_STAMP_INIT unsigned long long t_prev_ = __builtin_amdgcn_s_memtime()
+#else
+#define PPN_STAMP(idx) do {} while (0)
+#define PPN_STAMP_INIT do {} while (0)
+#endif
+
 namespace {
 constexpr int NT = 256;
 constexpr int NW = NT / 64;
@@ -25,15 +36,28 @@ constexpr int MAX_OBS = 256 + PPN_MAX_POCKET;     // K <= 256
 constexpr double PI = 3.141592653589793;
 }
 
+// exact predicate of the obstacle raster rule for pixel column j of a row at squared row offset dy2
+__device__ __forceinline__ bool disc_pred(int j, double cx, double dy2, double rr) {
+    const double dx = ((double)j + 0.5) - cx;
+    return dx * dx + dy2 <= rr;
+}
+
+// 4 mask bits -> 4 bytes (0x00 / 0xFF)
+__device__ __forceinline__ uint32_t expand4(uint32_t b) {
+    return (((b & 1u) | ((b & 2u) << 7) | ((b & 4u) << 14) | ((b & 8u) << 21))) * 255u;
+}
+
 __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
-    extern __shared__ uint32_t space[];           // R*R/32 words: the target path's corridor mask
-    __shared__ double podd[PPN_PATH_POINTS / 2][2];
-    __shared__ double hull[PPN_MAX_HULL][2];
-    __shared__ double obs[MAX_OBS][4];            // cx(col), cy(row), r, r*r
-    __shared__ double cand[256][3];               // K candidates: row, col, r
-    __shared__ uint8_t acc[256];
-    __shared__ double bc[8];
-    __shared__ int bci[8];
+    // dynamic LDS carve (all 8-byte aligned):
+    //   space [R*R/32 u32]  the target path's corridor mask
+    //   shareA [max(R*R/8, 8000) B]  odd path points (500 x 2 f64) until the filter is done, then the
+    //                                 occupancy bit mask (R*R bits)
+    //   cand  [K][3] f64   candidates (row, col, r)
+    //   obs   [K+64][3] f64  kept + pocket obstacles (col, row, r)
+    extern __shared__ uint64_t lds_raw[];
+    __shared__ double hullc[PPN_MAX_HULL][2];     // hull - R/2
+    __shared__ double bc[12];
+    __shared__ int bci[16];                       // [0..3] placement, [4..11] filter ballots, [12] corridor-touch flag
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // XCD-aware block -> map assignment: blocks b and b+8 share an XCD (round-robin dispatch), so
@@ -52,77 +76,117 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
     const ppn_paths_t& P = prm.paths;
     const ppn_maps_t& O = prm.out;
     const int words = R * R / 32;
+    const int shareA_bytes = max(R * R / 8, (PPN_PATH_POINTS / 2) * 16);
+    uint32_t* space = reinterpret_cast<uint32_t*>(lds_raw);
+    unsigned char* shareA = reinterpret_cast<unsigned char*>(lds_raw) + (size_t)words * 4;
+    double (*podd)[2] = reinterpret_cast<double (*)[2]>(shareA);
+    uint32_t* occw = reinterpret_cast<uint32_t*>(shareA);
+    double (*cand)[3] = reinterpret_cast<double (*)[3]>(shareA + shareA_bytes);
+    double (*obs)[3] = reinterpret_cast<double (*)[3]>(shareA + shareA_bytes + (size_t)K * 24);
     uint32_t flags = 0;
+    PPN_STAMP_INIT;
 
     for (int w = tid; w < words; w += NT) space[w] = P.space_bits[(size_t)pj * words + w];
     const int hn = P.hull_n[pj];
     if (tid < PPN_MAX_HULL) {
-        hull[tid][0] = P.hull[((size_t)pj * PPN_MAX_HULL + tid) * 2];
-        hull[tid][1] = P.hull[((size_t)pj * PPN_MAX_HULL + tid) * 2 + 1];
+        hullc[tid][0] = P.hull[((size_t)pj * PPN_MAX_HULL + tid) * 2] - half;
+        hullc[tid][1] = P.hull[((size_t)pj * PPN_MAX_HULL + tid) * 2 + 1] - half;
+    }
+    if (tid == 0) bci[12] = prm.force_compose;                            // "some obstacle may touch the corridor"
+    // K random obstacle candidates (MapGenerate.py:128-136) do not depend on the placement: waves 1..3
+    // draw them while wave 0 runs the placement loop
+    if (wv > 0 || K > 192) {
+        for (int k = (K > 192 ? tid : tid - 64); k < K; k += (K > 192 ? NT : NT - 64)) {
+            double ux, uy, us;
+            if (prm.obst_draws) {
+                const double* d = prm.obst_draws + (size_t)m * 3 * K;
+                ux = d[k]; uy = d[K + k]; us = d[2 * K + k];
+            } else {
+                ux = philox_double(prm.seed, STREAM_OBST, mid, (uint32_t)k);
+                uy = philox_double(prm.seed, STREAM_OBST, mid, (uint32_t)(K + k));
+                us = philox_double(prm.seed, STREAM_OBST, mid, (uint32_t)(2 * K + k));
+            }
+            cand[k][0] = ux * prm.map_size / prm.map_size * Rd;
+            cand[k][1] = uy * prm.map_size / prm.map_size * Rd;
+            cand[k][2] = us * prm.obstacles_size / prm.map_size * Rd;
+        }
     }
     __syncthreads();
+    PPN_STAMP(0);
 
-    // ------------------------------------------------------------------ placement (wave 0)
+    // ------------------------------------------------------------------ placement: wave 0, one attempt per lane
     if (wv == 0) {
-        int attempts = 0, t0 = 0, t1 = 0;
-        double angle = 0.0;
         const double* fed = prm.place_draws ? prm.place_draws + (size_t)m * 3 : nullptr;
-        while (true) {
+        int attempts = 0, t0 = 0, t1 = 0;
+        double angle = 0.0, ca = 1.0, sa = 0.0;
+        for (int round = 0;; ++round) {
+            const int a = round * 64 + lane;                              // this lane's attempt index
             double u0, u1, u2;
             if (fed) { u0 = fed[0]; u1 = fed[1]; u2 = fed[2]; }
             else {
-                const uint32_t d = 3u * (uint32_t)attempts;
-                u0 = philox_double(prm.seed, STREAM_PLACE, mid, d);
-                u1 = philox_double(prm.seed, STREAM_PLACE, mid, d + 1);
-                u2 = philox_double(prm.seed, STREAM_PLACE, mid, d + 2);
+                // draws 3a, 3a+1, 3a+2 live in Philox blocks (3a)>>1 and (3a)>>1 + 1
+                const uint32_t d = 3u * (uint32_t)a;
+                double p0, p1, p2, p3;
+                philox_double2(prm.seed, STREAM_PLACE, mid, d >> 1, p0, p1);
+                philox_double2(prm.seed, STREAM_PLACE, mid, (d >> 1) + 1u, p2, p3);
+                if (d & 1u) { u0 = p1; u1 = p2; u2 = p3; } else { u0 = p0; u1 = p1; u2 = p2; }
             }
-            ++attempts;
-            angle = u0 * 360.0 - 180.0;                                   // MapGenerate.py:63
-            t0 = (int)(u1 * Rd - half);                                   // MapGenerate.py:64 (trunc)
-            t1 = (int)(u2 * Rd - half);
+            const double ang = u0 * 360.0 - 180.0;                        // MapGenerate.py:63
+            const int a0 = (int)(u1 * Rd - half);                         // MapGenerate.py:64 (trunc)
+            const int a1 = (int)(u2 * Rd - half);
             // boundary_check(-angle, [t1, t0]), Path.py:100-111, MapOffset = R/2
-            const double rad = (-angle) / 180.0 * PI;
-            const double c = cos(rad), s = sin(rad);
+            const double rad = (-ang) / 180.0 * PI;
+            double c, s;
+            sincos_small(rad, s, c);
+            const double o1 = (double)a1, o0 = (double)a0;
             bool out = false;
-            if (lane < hn) {
+            for (int v = 0; v < hn; ++v) {
                 double hx, hy;
-                rot2(c, s, hull[lane][0] - half, hull[lane][1] - half, hx, hy);
-                hx = hx + (double)t1 + half;
-                hy = hy + (double)t0 + half;
-                out = (hx < 0.0) || (hx >= Rd) || (hy < 0.0) || (hy >= Rd);
+                rot2(c, s, hullc[v][0], hullc[v][1], hx, hy);
+                hx = hx + o1 + half;
+                hy = hy + o0 + half;
+                out = out || (hx < 0.0) || (hx >= Rd) || (hy < 0.0) || (hy >= Rd);
             }
-            const bool ok = __ballot(out) == 0ull;
-            if (ok) break;
-            if (fed || attempts >= PPN_PLACE_TRY_CAP) { flags |= PPN_FLAG_PLACE_CAP; break; }
+            unsigned long long okm = __ballot(!out);
+            if (fed) okm &= 1ull;
+            int src;
+            if (okm) { src = __ffsll((long long)okm) - 1; attempts = round * 64 + src + 1; }
+            else if (fed) { src = 0; attempts = 1; flags |= PPN_FLAG_PLACE_CAP; }
+            else if ((round + 1) * 64 >= PPN_PLACE_TRY_CAP) { src = 63; attempts = PPN_PLACE_TRY_CAP; flags |= PPN_FLAG_PLACE_CAP; }
+            else continue;
+            angle = __shfl(ang, src, 64);
+            ca = __shfl(c, src, 64);
+            sa = __shfl(s, src, 64);
+            t0 = __shfl(a0, src, 64);
+            t1 = __shfl(a1, src, 64);
+            break;
         }
+        double c3, s3;
+        sincos_small((-angle) * PI / 180.0, s3, c3);                      // rotate_nearest(space, -angle)
         if (lane == 0) {
-            bc[0] = angle; bci[0] = t0; bci[1] = t1; bci[2] = attempts; bci[3] = (int)flags;
+            bc[0] = angle; bc[6] = ca; bc[7] = sa; bc[8] = c3; bc[9] = s3;
+            bci[0] = t0; bci[1] = t1; bci[2] = attempts; bci[3] = (int)flags;
             O.angle[m] = angle;
             O.translation[(size_t)m * 2] = t0; O.translation[(size_t)m * 2 + 1] = t1;
             O.attempts[m] = attempts;
         }
     }
     __syncthreads();
-    const double angle = bc[0];
+    PPN_STAMP(1);
     const int t0 = bci[0], t1 = bci[1];
     flags = (uint32_t)bci[3];
-    const double rad = (-angle) / 180.0 * PI;                             // MapGenerate.py:72
-    const double c = cos(rad), s = sin(rad);
+    const double c = bc[6], s = bc[7];                                    // cos/sin(-angle/180*pi), MapGenerate.py:72
     const double tr0 = (double)t1, tr1 = (double)t0;                      // [translation[1], translation[0]]
 
     // ------------------------------------------------------------------ labels
     for (int q = tid; q < PPN_PATH_POINTS; q += NT) {                     // MapGenerate.py:76-80
-        const double x = P.pathpoint_image[((size_t)pj * PPN_PATH_POINTS + q) * 2] - half;
-        const double y = P.pathpoint_image[((size_t)pj * PPN_PATH_POINTS + q) * 2 + 1] - half;
+        const double2 pq = *reinterpret_cast<const double2*>(P.pathpoint_image + ((size_t)pj * PPN_PATH_POINTS + q) * 2);
         double rx, ry;
-        rot2(c, s, x, y, rx, ry);
+        rot2(c, s, pq.x - half, pq.y - half, rx, ry);
         rx = rx + half + tr0;
         ry = ry + half + tr1;
         if (q & 1) { podd[q >> 1][0] = rx; podd[q >> 1][1] = ry; }
-        if (O.pathpoint) {
-            O.pathpoint[((size_t)m * PPN_PATH_POINTS + q) * 2] = rx;
-            O.pathpoint[((size_t)m * PPN_PATH_POINTS + q) * 2 + 1] = ry;
-        }
+        if (O.pathpoint) *reinterpret_cast<double2*>(O.pathpoint + ((size_t)m * PPN_PATH_POINTS + q) * 2) = make_double2(rx, ry);
     }
     if (tid < PPN_SEGS + 1) {                                             // MapGenerate.py:70-74
         const double x = P.segpoint_image[((size_t)pj * 11 + tid) * 2] - half;
@@ -136,47 +200,62 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
         if (tid == 0) { bc[2] = rx; bc[3] = ry; }
         if (tid == PPN_SEGS) { bc[4] = rx; bc[5] = ry; }                  // end = segpoint[10]
     }
-    // K random obstacle candidates (MapGenerate.py:128-136)
-    if (tid < K) {
-        double ux, uy, us;
-        if (prm.obst_draws) {
-            const double* d = prm.obst_draws + (size_t)m * 3 * K;
-            ux = d[tid]; uy = d[K + tid]; us = d[2 * K + tid];
-        } else {
-            ux = philox_double(prm.seed, STREAM_OBST, mid, (uint32_t)tid);
-            uy = philox_double(prm.seed, STREAM_OBST, mid, (uint32_t)(K + tid));
-            us = philox_double(prm.seed, STREAM_OBST, mid, (uint32_t)(2 * K + tid));
-        }
-        cand[tid][0] = ux * prm.map_size / prm.map_size * Rd;
-        cand[tid][1] = uy * prm.map_size / prm.map_size * Rd;
-        cand[tid][2] = us * prm.obstacles_size / prm.map_size * Rd;
-    }
     __syncthreads();
+    PPN_STAMP(2);
 
-    // ------------------------------------------------------------------ clearance filter: one wave per obstacle
+    // ------------------------------------------------------------------ clearance filter: one wave per obstacle,
+    // shuffle min-reduce over the 500 odd path points (squared distances, one sqrt: sqrt is monotone and
+    // correctly rounded, so sqrt(min d2) == min sqrt(d2) bit for bit), ballot compaction in draw order
     {
         const double c_px = prm.clearance / prm.map_size * Rd;            // MapGenerate.py:142
-        for (int k = wv; k < K; k += NW) {
-            const double ox = cand[k][0], oy = cand[k][1];
-            double mn = 1e300;
-            for (int q = lane; q < PPN_PATH_POINTS / 2; q += 64)
-                mn = fmin(mn, dist2d(podd[q][0], podd[q][1], ox, oy));
-            mn = wave_min(mn);
-            if (lane == 0) acc[k] = (mn > cand[k][2] + c_px) ? 1 : 0;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {                                                       // ordered compaction
-        int n = 0;
-        for (int k = 0; k < K; ++k) {
-            if (acc[k]) {
-                obs[n][0] = cand[k][1]; obs[n][1] = cand[k][0]; obs[n][2] = cand[k][2];   // [col,row,r]
-                ++n;
+        // Corridor-touch margin.  Every corridor pixel of the map lies within
+        //   0.5*c_px (ray reach from the centre line, Path.py:119-134) + max_step (next odd path point)
+        //   + 4.3 px (five nearest-neighbour roundings of <= 0.71 px: canvas, point lattice, two rotations,
+        //     one fractional translation; + the half-pixel offset between the label and the disc frames)
+        // of an odd path point, and a pixel of obstacle k lies >= md_k - r_k - 0.71 from every odd path point.
+        // So an obstacle with md_k - r_k > touch_margin cannot meet the corridor; if none can, the compose
+        // pass below is a no-op and is skipped (tests/test_gpu_edage.py checks this against a forced run).
+        const double touch_margin = 0.5 * c_px + P.max_step_px[pj] + 5.0;
+        int n_rand = 0;
+        for (int k0 = 0; k0 < K; k0 += 64) {                              // K <= 256: at most 4 groups of 64
+            unsigned long long accm = 0ull;                              // accept bits of this wave's obstacles
+            for (int k = k0 + wv; k < min(K, k0 + 64); k += NW) {
+                const double ox = cand[k][0], oy = cand[k][1];
+                double mn = 1e300;
+                for (int q = lane; q < PPN_PATH_POINTS / 2; q += 64) {
+                    const double dx = podd[q][0] - ox, dy = podd[q][1] - oy;
+                    mn = fmin(mn, dx * dx + dy * dy);
+                }
+                mn = sqrt(wave_min(mn));
+                if (mn > cand[k][2] + c_px) {
+                    accm |= 1ull << (k - k0);
+                    if (!(mn - cand[k][2] > touch_margin) && lane == 0) bci[12] = 1;
+                }
             }
+            if (lane == 0) { bci[4 + wv] = (int)(uint32_t)accm; bci[8 + wv] = (int)(uint32_t)(accm >> 32); }
+            __syncthreads();
+            unsigned long long all = 0ull;
+            for (int w = 0; w < NW; ++w) all |= ((unsigned long long)(uint32_t)bci[4 + w]) | ((unsigned long long)(uint32_t)bci[8 + w] << 32);
+            const int k = k0 + lane;
+            if (wv == 0 && k < K) {
+                const bool a = (all >> lane) & 1ull;
+                if (O.accept) O.accept[(size_t)m * K + k] = a ? 1 : 0;
+                if (a) {
+                    const int pos = n_rand + __popcll(all & ((1ull << lane) - 1ull));
+                    obs[pos][0] = cand[k][1]; obs[pos][1] = cand[k][0]; obs[pos][2] = cand[k][2];   // [col,row,r]
+                }
+            }
+            n_rand += __popcll(all);
+            __syncthreads();
         }
-        bci[4] = n;
+        if (tid == 0) {
+            bci[4] = n_rand;
+            // pocket obstacles keep >= c_px from the odd path points by construction (Path.py:490-491)
+            if (P.n_obstacles[pj] > 0 && !(c_px > touch_margin)) bci[12] = 1;
+        }
     }
     __syncthreads();
+    PPN_STAMP(3);
     const int n_rand = bci[4];
     const int n_pocket = P.n_obstacles[pj];
     if (tid < n_pocket) {                                                 // MapGenerate.py:83-89
@@ -187,89 +266,127 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
         ry = ry + half + tr1;
         obs[n_rand + tid][0] = ry; obs[n_rand + tid][1] = rx; obs[n_rand + tid][2] = o[2];
     }
+    // podd is dead from here: its bytes become the occupancy bit mask
+    for (int w = tid; w < words; w += NT) occw[w] = 0u;
     __syncthreads();
     const int n_obs = n_rand + n_pocket;
     for (int n = tid; n < n_obs; n += NT) {
-        obs[n][3] = obs[n][2] * obs[n][2];
         double* o = O.obstacles + ((size_t)m * (K + PPN_MAX_POCKET) + n) * 3;
         o[0] = obs[n][0]; o[1] = obs[n][1]; o[2] = obs[n][2];
     }
-    if (O.accept && tid < K) O.accept[(size_t)m * K + tid] = acc[tid];
     if (tid == 0) {
         O.n_obstacles[(size_t)m * 2] = n_obs;
         O.n_obstacles[(size_t)m * 2 + 1] = n_rand;
         O.flags[m] = flags | P.flags[pj];
     }
-    __syncthreads();
+    PPN_STAMP(4);
 
-    // ------------------------------------------------------------------ raster: 16 pixels (one 16-byte store) per step
+    // ------------------------------------------------------------------ raster 1: exact row spans -> LDS bit mask.
+    // One wave per obstacle, one lane per row of its bounding box.  The pixel rule "centre inside the
+    // closed disc" is monotone in |dx| under IEEE rounding, so the columns of a row form an interval:
+    // estimate it with a float sqrt, then settle both ends with the exact double predicate.
+    const int wpr = R / 32;
+    const double c3 = bc[8], s3 = bc[9];
+    for (int n = wv; n < n_obs; n += NW) {
+        const double cx = obs[n][0], cy = obs[n][1], r = obs[n][2];
+        const double rr = r * r;
+        const int i_lo = max((int)floor(cy - r - 0.5), 0), i_hi = min((int)ceil(cy + r - 0.5), R - 1);
+        for (int i = i_lo + lane; i <= i_hi; i += 64) {
+            const double dy = ((double)i + 0.5) - cy;
+            const double dy2 = dy * dy;
+            if (dy2 > rr) continue;                                       // dx*dx + dy2 >= dy2 > rr for every column
+            const int jc = (int)floor(cx);                                // nearest pixel centre
+            if (!disc_pred(jc, cx, dy2, rr)) continue;                    // not even the nearest column
+            const float w = sqrtf((float)(rr - dy2));
+            int jl = min(jc, (int)ceilf((float)cx - w - 0.5f)), jh = max(jc, (int)floorf((float)cx + w - 0.5f));
+            while (disc_pred(jl - 1, cx, dy2, rr)) --jl;
+            while (jl < jc && !disc_pred(jl, cx, dy2, rr)) ++jl;
+            while (disc_pred(jh + 1, cx, dy2, rr)) ++jh;
+            while (jh > jc && !disc_pred(jh, cx, dy2, rr)) --jh;
+            jl = max(jl, 0); jh = min(jh, R - 1);
+            if (jl > jh) continue;
+            uint32_t* row = occw + (size_t)i * wpr;
+            for (int ww = jl >> 5; ww <= (jh >> 5); ++ww) {
+                const int lo = max(jl - ww * 32, 0), hi = min(jh - ww * 32, 31);
+                const uint32_t msk = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+                atomicOr(&row[ww], msk);
+            }
+        }
+    }
+    __syncthreads();
+    PPN_STAMP(5);
+
+    // ------------------------------------------------------------------ raster 2: the corridor wins over obstacles
+    // (MapGenerate.py:111 saturating sum): inverse-map the occupied pixels into the target path's mask,
+    // one lane per pixel, 64 consecutive pixels per wave step.  Skipped when no obstacle can touch it.
+    if (bci[12]) {
+        for (int base = wv * 64; base < R * R; base += NT) {
+            const int px = base + lane;
+            const int i = px / R, j = px - i * R;
+            const uint32_t wbits = occw[px >> 5];
+            bool clr = false;
+            if ((wbits >> (px & 31)) & 1u) {
+                const int i1 = i - t1, j1 = j - t0;                       // translate: (tx, ty) = (translation[0], [1])
+                if (i1 >= 0 && i1 < R && j1 >= 0 && j1 < R) {
+                    const double yo = ((double)i1 + 0.5) - half, xo = ((double)j1 + 0.5) - half;
+                    const double xs = c3 * xo - s3 * yo, ys = s3 * xo + c3 * yo;
+                    const int jj = (int)rint(xs + (half - 0.5)), ii = (int)rint(ys + (half - 0.5));
+                    if (ii >= 0 && ii < R && jj >= 0 && jj < R) {
+                        const int bit = ii * R + jj;
+                        clr = (space[bit >> 5] >> (bit & 31)) & 1u;
+                    }
+                }
+            }
+            const unsigned long long cm = __ballot(clr);
+            if (cm) {
+                if (lane == 0 && (uint32_t)cm) occw[px >> 5] = wbits & ~(uint32_t)cm;
+                if (lane == 32 && (uint32_t)(cm >> 32)) occw[px >> 5] = wbits & ~(uint32_t)(cm >> 32);
+            }
+        }
+        __syncthreads();
+    }
+    PPN_STAMP(6);
+
+    // ------------------------------------------------------------------ raster 3: bits -> bytes, 16-byte stores
     {
-        const double b = (-angle) * PI / 180.0;                           // rotate_nearest(space, -angle)
-        const double c3 = cos(b), s3 = sin(b);
         const int r_init = (int)rint(bc[2]), c_init = (int)rint(bc[3]);   // process_map.py:127-135
         const int r_end = (int)rint(bc[4]), c_end = (int)rint(bc[5]);
         const int cpr = R / 16;
         uint8_t* g = O.grid + (size_t)m * R * R;
         for (int ch = tid; ch < R * cpr; ch += NT) {
-            const int i = ch / cpr, j0 = (ch - i * cpr) * 16;
-            const double yc = (double)i + 0.5;
-            uint32_t occ = 0u;
-            for (int n = 0; n < n_obs; ++n) {
-                const double dy = yc - obs[n][1];
-                const double rr = obs[n][3];
-                const double dy2 = dy * dy;
-                if (dy2 > rr) continue;                                   // row misses the disc
-                const double r = obs[n][2], cx = obs[n][0];
-                if ((double)j0 + 16.0 < cx - r || (double)j0 > cx + r) continue;   // conservative column cull
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const double dx = ((double)(j0 + k) + 0.5) - cx;
-                    if (dx * dx + dy2 <= rr) occ |= 1u << k;
-                }
-            }
-            if (occ) {                                                    // corridor wins over obstacles
-                const int i1 = i - t1;                                    // translate: ty = translation[1]
-                if (i1 >= 0 && i1 < R) {
-                    const double yo = ((double)i1 + 0.5) - half;
-                    for (int k = 0; k < 16; ++k) {
-                        if (!((occ >> k) & 1u)) continue;
-                        const int j1 = j0 + k - t0;
-                        if (j1 < 0 || j1 >= R) continue;
-                        const double xo = ((double)j1 + 0.5) - half;
-                        const double xs = c3 * xo - s3 * yo, ys = s3 * xo + c3 * yo;
-                        const int jj = (int)rint(xs + (half - 0.5)), ii = (int)rint(ys + (half - 0.5));
-                        if (ii < 0 || ii >= R || jj < 0 || jj >= R) continue;
-                        const int bit = ii * R + jj;
-                        if ((space[bit >> 5] >> (bit & 31)) & 1u) occ &= ~(1u << k);
-                    }
-                }
-            }
+            const int i = ch / cpr, jc16 = ch - i * cpr, j0 = jc16 * 16;
+            const uint32_t occ = (occw[(size_t)i * wpr + (jc16 >> 1)] >> ((jc16 & 1) * 16)) & 0xffffu;
             uint32_t mark = 0u;
             const bool ri = (i >= r_init - 3) && (i <= r_init + 3), re = (i >= r_end - 3) && (i <= r_end + 3);
-            if (ri || re) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int j = j0 + k;
-                    if ((ri && j >= c_init - 3 && j <= c_init + 3) || (re && j >= c_end - 3 && j <= c_end + 3))
-                        mark |= 1u << k;
-                }
+            if (ri) {
+                const int lo = max(c_init - 3 - j0, 0), hi = min(c_init + 3 - j0, 15);
+                if (lo <= hi) mark |= ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
             }
-            uint32_t w[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint32_t v = 0u;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int bit = q * 4 + k;
-                    const uint32_t px = ((mark >> bit) & 1u) ? PPN_GRID_MARK : (((occ >> bit) & 1u) ? PPN_GRID_OBST : PPN_GRID_FREE);
-                    v |= px << (8 * k);
-                }
-                w[q] = v;
+            if (re) {
+                const int lo = max(c_end - 3 - j0, 0), hi = min(c_end + 3 - j0, 15);
+                if (lo <= hi) mark |= ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
             }
-            *reinterpret_cast<uint4*>(g + (size_t)i * R + j0) = make_uint4(w[0], w[1], w[2], w[3]);
+            const uint32_t fre = ~occ & ~mark & 0xffffu;                  // FREE = 0xFF, OBST = 0x00, MARK = 0x80
+            uint32_t w4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w4[q] = expand4((fre >> (4 * q)) & 15u) | (expand4((mark >> (4 * q)) & 15u) & 0x80808080u);
+            *reinterpret_cast<uint4*>(g + (size_t)i * R + j0) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
     }
+    PPN_STAMP(7);
 }
+
+#ifdef PPN_PHASE_TIMING
+extern "C" int ppn_debug_phase_cycles(unsigned long long* out_host, int reset) {
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif
 
 // Path.boundary_check (Path.py:100-111): one wave per (angle, translation) pair
 __global__ __launch_bounds__(NT) void boundary_check_kernel(const double* hull, int hull_n, const double* angle_deg,

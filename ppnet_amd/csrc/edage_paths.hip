@@ -214,9 +214,16 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
         for (int q = tid; q < PPN_PATH_POINTS - 1; q += NT)
             part += dist2d(pp[q][0], pp[q][1], pp[q + 1][0], pp[q + 1][1]);
         const double len = block_sum<NW>(part, red_v);
+        double mstep = 0.0;
+        for (int q = tid; q < PPN_PATH_POINTS - 1; q += NT)
+            mstep = fmax(mstep, dist2d(pp[q][0], pp[q][1], pp[q + 1][0], pp[q + 1][1]));
+        if (tid == 0) mstep = fmax(mstep, dist2d(pp[PPN_PATH_POINTS - 1][0], pp[PPN_PATH_POINTS - 1][1],
+                                                  S.segpoint[PPN_SEGS][0], S.segpoint[PPN_SEGS][1]));
+        mstep = block_max<NW>(mstep, red_v);
         if (tid == 0) {
             O.length[p] = len;
             O.straight[p] = path_straight ? 1 : 0;
+            O.max_step_px[p] = mstep / step_c2i;
         }
     }
     const double Ex = S.segpoint[PPN_SEGS][0], Ey = S.segpoint[PPN_SEGS][1];

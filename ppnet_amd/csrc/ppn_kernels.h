@@ -30,6 +30,7 @@ struct MapsParams {
     uint64_t seed;
     const double* place_draws; // [n_maps][3] or null
     const double* obst_draws;  // [n_maps][3K] or null
+    int force_compose;         // validation: never skip the corridor compose
 };
 
 __global__ void edage_paths_kernel(PathsParams prm);

@@ -58,6 +58,7 @@ class PathsBatch:
         self.length = z(n, **f64)
         self.straight = z(n, **i32)
         self.flags = z(n, **i32)
+        self.max_step_px = z(n, **f64)
         self.struct = L.PathsStruct(**{name: _ptr(getattr(self, name)) for name, _ in L.PathsStruct._fields_})
 
     def space_mask(self):

@@ -264,6 +264,27 @@ def test_config2_full_size_properties(dev):
     assert torch.equal(torch.cat([pa.space_bits, pb2.space_bits]), pb.space_bits)
 
 
+@pytest.mark.parametrize("R,clearance", [(256, 3), (256, 1), (64, 3), (128, 2)])
+def test_corridor_compose_skip_is_exact(dev, R, clearance):
+    """Stage B skips the corridor-wins compose pass when it can prove no obstacle touches the corridor
+    (margin argument in edage_maps.hip).  PPN_FORCE_COMPOSE=1 disables the skip: both must give
+    identical grids on thousands of maps, including small-clearance cases where the pass does run."""
+    import torch
+    from ppnet_amd import edage
+    P, placements, K = 40, 50, 30
+    pb = edage.generate_paths(P, R, 50, clearance, seed=11, device=dev)
+    a = edage.generate_maps(pb, placements, 5, K, seed=11)
+    torch.cuda.synchronize()
+    os.environ["PPN_FORCE_COMPOSE"] = "1"
+    try:
+        b = edage.generate_maps(pb, placements, 5, K, seed=11)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["PPN_FORCE_COMPOSE"]
+    assert torch.equal(a.grid, b.grid)
+    assert torch.equal(a.pathpoint, b.pathpoint)
+
+
 def test_invalid_arguments_are_reported_not_fatal(dev):
     from ppnet_amd import edage, _lib
     with pytest.raises(ValueError):
