@@ -26,9 +26,24 @@ MAP_SIZE, CLEARANCE, OBST_SIZE, SEED = 50, 3, 5, 0
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes_per_map(k_tot):
-    """SURVEY.md §8(d) A_B(R) = 2*R^2 + 16384 + 12*K_tot (grid write + corridor mask read + labels + obstacles)."""
-    return 2 * R * R + 16384 + 12.0 * k_tot
+def algorithmic_bytes_per_map(k_tot, k_pocket):
+    """Compulsory HBM bytes per map for this build's data layout: every output written once,
+    every per-path input read once per PLACEMENTS maps.  (SURVEY.md §8(d) priced a byte-per-pixel corridor mask
+    and float32 labels: 2*R^2 + 16384 + 12*K_tot = 147.7 KB; the build reads an R^2/8 bit mask shared by all
+    placements of a path and writes float64 labels, so its true figure is smaller — the smaller one is used.)"""
+    out = R * R + 16000 + 176 + 24.0 * k_tot + K + 8 + 8 + 4 + 8 + 4      # grid, pathpoint, segpoint, obstacles, accept, scalars
+    inp = (R * R / 8 + 16000 + 64 * 16 + 176 + 24.0 * k_pocket + 32) / PLACEMENTS
+    return out + inp
+
+
+def measured_traffic():
+    """HBM bytes per edage_maps_kernel launch from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
+    correction, WRITE_SIZE as read), committed under profiles/ by tools/collect_traffic.py."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_maps_kernel.json")) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline():
@@ -73,23 +88,46 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    # buffers are allocated once and reused every step (resident in HBM)
-    pb = edage.PathsBatch(PATHS, R, MAP_SIZE, CLEARANCE, dev)
+    # buffers are allocated once and reused every step (resident in HBM).  Stage A of batch i+1 runs on its
+    # own HIP stream while stage B of batch i writes its maps: two path buffers, events for the hand-off.
+    pbs = [edage.PathsBatch(PATHS, R, MAP_SIZE, CLEARANCE, dev) for _ in range(2)]
     mb = edage.MapsBatch(PATHS * PLACEMENTS, R, K, dev)
+    s_paths = torch.cuda.Stream(dev)
+    s_maps = torch.cuda.current_stream(dev)
+    ready = [None, None]          # paths of buffer b are complete
+    consumed = [None, None]       # maps kernel reading buffer b has finished
+
+    def launch_paths(it):
+        b = it % 2
+        first_path = (it * world + rank) * PATHS
+        with torch.cuda.stream(s_paths):
+            if consumed[b] is not None:
+                s_paths.wait_event(consumed[b])
+            edage.generate_paths(PATHS, R, MAP_SIZE, CLEARANCE, seed=SEED, first_path_id=first_path, device=dev, out=pbs[b])
+            ready[b] = torch.cuda.Event()
+            ready[b].record(s_paths)
     n_local = PATHS * PLACEMENTS
     rec_w = 2 + 2 + 22                       # angle, flags/n_obs, translation, segpoint[11,2] -> float64 record
     rec = torch.empty(n_local, rec_w, dtype=torch.float64, device=dev)
     gathered = torch.empty(world * n_local, rec_w, dtype=torch.float64, device=dev) if world > 1 else None
 
-    def step(it):
+    def step(it, last=False):
         # a fresh batch every step: path / map ids advance so no two steps generate the same instances
+        b = it % 2
         first_path = (it * world + rank) * PATHS
-        edage.generate_paths(PATHS, R, MAP_SIZE, CLEARANCE, seed=SEED, first_path_id=first_path, device=dev, out=pb)
+        if ready[b] is None:
+            launch_paths(it)                  # pipeline fill (first step only)
+        if not last:
+            launch_paths(it + 1)              # stage A of the next batch, overlapped with this batch's stage B
+        s_maps.wait_event(ready[b])
+        ready[b] = None
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record()
-        edage.generate_maps(pb, PLACEMENTS, OBST_SIZE, K, seed=SEED, first_map_id=first_path * PLACEMENTS, out=mb)
+        edage.generate_maps(pbs[b], PLACEMENTS, OBST_SIZE, K, seed=SEED, first_map_id=first_path * PLACEMENTS, out=mb)
         ev1.record()
+        consumed[b] = torch.cuda.Event()
+        consumed[b].record(s_maps)
         if world > 1:                         # end-of-batch gather of the fixed-size records (RCCL over xGMI)
             rec[:, 0] = mb.angle
             rec[:, 1] = mb.flags.to(torch.float64)
@@ -104,7 +142,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    evs = [step(args.warmup + it) for it in range(args.steps)]
+    evs = [step(args.warmup + it, last=(it == args.steps - 1)) for it in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -116,12 +154,13 @@ def main():
 
     maps_kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
     k_tot = float(mb.n_obstacles[:, 0].double().mean().item())
+    k_pocket = float(pbs[0].n_obstacles.double().mean().item())
     placed = float(((mb.flags & 2) == 0).double().mean().item())
     total_instances = world * n_local * args.steps
     value = total_instances / elapsed
 
     if rank == 0:
-        bytes_per_launch = algorithmic_bytes_per_map(k_tot) * n_local
+        bytes_per_launch = algorithmic_bytes_per_map(k_tot, k_pocket) * n_local
         achieved = bytes_per_launch / (maps_kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "edage_pp_map_path_instances_per_sec",
@@ -140,9 +179,10 @@ def main():
                        "resolution": R, "obstacles_num": K, "clearance": CLEARANCE, "map_size": MAP_SIZE,
                        "rng": "philox4x32-10", "parallelism": f"instances sharded over {world} GPU(s), end-of-batch all-gather"},
             "roofline": {"bound": "hbm", "kernel": "edage_maps_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel_ms": round(maps_kernel_ms, 4),
-                         "algorithmic_bytes_per_map": round(algorithmic_bytes_per_map(k_tot), 1)},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(),
+                         "kernel_ms": round(maps_kernel_ms, 4), "units_per_launch": n_local,
+                         "algorithmic_bytes_per_map": round(algorithmic_bytes_per_map(k_tot, k_pocket), 1),
+                         "survey_bytes_per_map": round(2 * R * R + 16384 + 12.0 * k_tot, 1)},
             "placement_success": round(placed, 4),
             "mean_obstacles_per_map": round(k_tot, 2),
         }

@@ -173,7 +173,8 @@ int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements
     }
     // dynamic LDS: corridor mask + shared region (odd path points, then occupancy bits) + candidates + obstacles
     const size_t shareA = (size_t)R * R / 8 > 8000 ? (size_t)R * R / 8 : 8000;
-    const size_t lds = (size_t)R * R / 8 + shareA + (size_t)K * 24 + (size_t)(K + PPN_MAX_POCKET) * 24;
+    const size_t lds = (size_t)R * R / 8 + shareA + (size_t)K * 24 + (size_t)(K + PPN_MAX_POCKET) * 24 +
+                       (PPN_PATH_POINTS / 2) * 8 + 256 * 8;
     PPN_HIP(hipFuncSetAttribute((const void*)ppn::edage_maps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(ppn::edage_maps_kernel, dim3((unsigned)n_maps), dim3(256), lds, (hipStream_t)stream, prm);
     PPN_HIP(hipGetLastError());

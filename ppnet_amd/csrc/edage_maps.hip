@@ -54,6 +54,8 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
     //                                 occupancy bit mask (R*R bits)
     //   cand  [K][3] f64   candidates (row, col, r)
     //   obs   [K+64][3] f64  kept + pocket obstacles (col, row, r)
+    //   poddf [500][2] f32  float copy of the odd path points (filter pre-pass)
+    //   lut   [256] u64     8 occupancy bits -> 8 grid bytes
     extern __shared__ uint64_t lds_raw[];
     __shared__ double hullc[PPN_MAX_HULL][2];     // hull - R/2
     __shared__ double bc[12];
@@ -83,6 +85,8 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
     uint32_t* occw = reinterpret_cast<uint32_t*>(shareA);
     double (*cand)[3] = reinterpret_cast<double (*)[3]>(shareA + shareA_bytes);
     double (*obs)[3] = reinterpret_cast<double (*)[3]>(shareA + shareA_bytes + (size_t)K * 24);
+    float2* poddf = reinterpret_cast<float2*>(shareA + shareA_bytes + (size_t)K * 24 + (size_t)(K + PPN_MAX_POCKET) * 24);
+    uint64_t* lut = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(poddf) + (PPN_PATH_POINTS / 2) * 8);
     uint32_t flags = 0;
     PPN_STAMP_INIT;
 
@@ -93,6 +97,12 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
         hullc[tid][1] = P.hull[((size_t)pj * PPN_MAX_HULL + tid) * 2 + 1] - half;
     }
     if (tid == 0) bci[12] = prm.force_compose;                            // "some obstacle may touch the corridor"
+    {   // byte-expansion table: bit k of the index set (= occupied) -> byte k 0x00, clear -> 0xFF
+        uint64_t v = 0ull;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v |= ((tid >> k) & 1) ? 0ull : (0xFFull << (8 * k));
+        lut[tid] = v;
+    }
     // K random obstacle candidates (MapGenerate.py:128-136) do not depend on the placement: waves 1..3
     // draw them while wave 0 runs the placement loop
     if (wv > 0 || K > 192) {
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
         rot2(c, s, pq.x - half, pq.y - half, rx, ry);
         rx = rx + half + tr0;
         ry = ry + half + tr1;
-        if (q & 1) { podd[q >> 1][0] = rx; podd[q >> 1][1] = ry; }
+        if (q & 1) { podd[q >> 1][0] = rx; podd[q >> 1][1] = ry; poddf[q >> 1] = make_float2((float)rx, (float)ry); }
         if (O.pathpoint) *reinterpret_cast<double2*>(O.pathpoint + ((size_t)m * PPN_PATH_POINTS + q) * 2) = make_double2(rx, ry);
     }
     if (tid < PPN_SEGS + 1) {                                             // MapGenerate.py:70-74
@@ -221,13 +231,28 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
             unsigned long long accm = 0ull;                              // accept bits of this wave's obstacles
             for (int k = k0 + wv; k < min(K, k0 + 64); k += NW) {
                 const double ox = cand[k][0], oy = cand[k][1];
-                double mn = 1e300;
+                const double thr = cand[k][2] + c_px;
+                // float pre-pass: |error| of the float minimum distance is < 1e-3 px for coordinates < 2^10,
+                // so it decides every case that is not within 0.01 px of a threshold; those fall back to double
+                const float oxf = (float)ox, oyf = (float)oy;
+                float mf = 3.0e38f;
                 for (int q = lane; q < PPN_PATH_POINTS / 2; q += 64) {
-                    const double dx = podd[q][0] - ox, dy = podd[q][1] - oy;
-                    mn = fmin(mn, dx * dx + dy * dy);
+                    const float2 pt = poddf[q];
+                    const float dx = pt.x - oxf, dy = pt.y - oyf;
+                    mf = fminf(mf, __fmaf_rn(dx, dx, dy * dy));
                 }
-                mn = sqrt(wave_min(mn));
-                if (mn > cand[k][2] + c_px) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mf = fminf(mf, __shfl_xor(mf, o, 64));
+                double mn = (double)sqrtf(mf);
+                if (fabs(mn - thr) < 0.01 || fabs(mn - cand[k][2] - touch_margin) < 0.01) {
+                    double md = 1e300;
+                    for (int q = lane; q < PPN_PATH_POINTS / 2; q += 64) {
+                        const double dx = podd[q][0] - ox, dy = podd[q][1] - oy;
+                        md = fmin(md, dx * dx + dy * dy);
+                    }
+                    mn = sqrt(wave_min(md));
+                }
+                if (mn > thr) {
                     accm |= 1ull << (k - k0);
                     if (!(mn - cand[k][2] > touch_margin) && lane == 0) bci[12] = 1;
                 }
@@ -295,14 +320,22 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
             const double dy = ((double)i + 0.5) - cy;
             const double dy2 = dy * dy;
             if (dy2 > rr) continue;                                       // dx*dx + dy2 >= dy2 > rr for every column
-            const int jc = (int)floor(cx);                                // nearest pixel centre
-            if (!disc_pred(jc, cx, dy2, rr)) continue;                    // not even the nearest column
+            // real-valued ends of the interval in column units: j + 0.5 in [cx - w, cx + w]
             const float w = sqrtf((float)(rr - dy2));
-            int jl = min(jc, (int)ceilf((float)cx - w - 0.5f)), jh = max(jc, (int)floorf((float)cx + w - 0.5f));
-            while (disc_pred(jl - 1, cx, dy2, rr)) --jl;
-            while (jl < jc && !disc_pred(jl, cx, dy2, rr)) ++jl;
-            while (disc_pred(jh + 1, cx, dy2, rr)) ++jh;
-            while (jh > jc && !disc_pred(jh, cx, dy2, rr)) --jh;
+            const float xl = (float)cx - w - 0.5f, xr = (float)cx + w - 0.5f;
+            int jl = (int)ceilf(xl), jh = (int)floorf(xr);
+            // the float estimate is good to < 1e-3 column; an end closer than that to an integer is settled
+            // with the exact double predicate (monotone in |dx|, so one step either way suffices)
+            if (fabsf(xl - rintf(xl)) < 2e-3f) {
+                jl = (int)rintf(xl);
+                while (disc_pred(jl - 1, cx, dy2, rr)) --jl;
+                while (jl <= jh + 1 && !disc_pred(jl, cx, dy2, rr)) ++jl;
+            }
+            if (fabsf(xr - rintf(xr)) < 2e-3f) {
+                jh = (int)rintf(xr);
+                while (disc_pred(jh + 1, cx, dy2, rr)) ++jh;
+                while (jh >= jl - 1 && !disc_pred(jh, cx, dy2, rr)) --jh;
+            }
             jl = max(jl, 0); jh = min(jh, R - 1);
             if (jl > jh) continue;
             uint32_t* row = occw + (size_t)i * wpr;
@@ -348,30 +381,37 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
     PPN_STAMP(6);
 
     // ------------------------------------------------------------------ raster 3: bits -> bytes, 16-byte stores
+    // (8 bits -> 8 bytes through the LDS table; the two 7x7 marker squares touch at most 28 chunks)
     {
         const int r_init = (int)rint(bc[2]), c_init = (int)rint(bc[3]);   // process_map.py:127-135
         const int r_end = (int)rint(bc[4]), c_end = (int)rint(bc[5]);
         const int cpr = R / 16;
+        const int sh = (cpr & (cpr - 1)) == 0 ? 31 - __clz(cpr) : -1;     // log2(cpr) when R/16 is a power of two
         uint8_t* g = O.grid + (size_t)m * R * R;
         for (int ch = tid; ch < R * cpr; ch += NT) {
-            const int i = ch / cpr, jc16 = ch - i * cpr, j0 = jc16 * 16;
+            const int i = sh >= 0 ? (ch >> sh) : (ch / cpr);
+            const int jc16 = ch - i * cpr, j0 = jc16 * 16;
             const uint32_t occ = (occw[(size_t)i * wpr + (jc16 >> 1)] >> ((jc16 & 1) * 16)) & 0xffffu;
-            uint32_t mark = 0u;
+            uint64_t lo8 = lut[occ & 0xffu], hi8 = lut[occ >> 8];
             const bool ri = (i >= r_init - 3) && (i <= r_init + 3), re = (i >= r_end - 3) && (i <= r_end + 3);
-            if (ri) {
-                const int lo = max(c_init - 3 - j0, 0), hi = min(c_init + 3 - j0, 15);
-                if (lo <= hi) mark |= ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
+            if (ri || re) {
+                uint32_t mark = 0u;
+                if (ri) {
+                    const int lo = max(c_init - 3 - j0, 0), hi = min(c_init + 3 - j0, 15);
+                    if (lo <= hi) mark |= ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
+                }
+                if (re) {
+                    const int lo = max(c_end - 3 - j0, 0), hi = min(c_end + 3 - j0, 15);
+                    if (lo <= hi) mark |= ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
+                }
+                if (mark) {                                               // MARK = 0x80 over whatever is there
+                    const uint64_t ml = ~lut[mark & 0xffu], mh = ~lut[mark >> 8];    // 0xFF where marked
+                    lo8 = (lo8 & ~ml) | (ml & 0x8080808080808080ull);
+                    hi8 = (hi8 & ~mh) | (mh & 0x8080808080808080ull);
+                }
             }
-            if (re) {
-                const int lo = max(c_end - 3 - j0, 0), hi = min(c_end + 3 - j0, 15);
-                if (lo <= hi) mark |= ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
-            }
-            const uint32_t fre = ~occ & ~mark & 0xffffu;                  // FREE = 0xFF, OBST = 0x00, MARK = 0x80
-            uint32_t w4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                w4[q] = expand4((fre >> (4 * q)) & 15u) | (expand4((mark >> (4 * q)) & 15u) & 0x80808080u);
-            *reinterpret_cast<uint4*>(g + (size_t)i * R + j0) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            *reinterpret_cast<uint4*>(g + (size_t)i * R + j0) =
+                make_uint4((uint32_t)lo8, (uint32_t)(lo8 >> 32), (uint32_t)hi8, (uint32_t)(hi8 >> 32));
         }
     }
     PPN_STAMP(7);

@@ -1,7 +1,7 @@
 """Diagnostic: per-phase cycle shares of edage_maps_kernel (build: make -C ppnet_amd/csrc timing)."""
 import ctypes as C, os, sys
 import torch
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import ppnet_amd._lib as L
 tl = C.CDLL(os.path.join(ROOT, "ppnet_amd", "libppnet_hip_timing.so"))
 for n in ("ppn_edage_paths", "ppn_edage_maps"):
