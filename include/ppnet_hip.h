@@ -101,6 +101,8 @@ typedef struct ppn_paths {
     double*   max_step_px;      /* [n] largest distance between consecutive path points (and the last one to
                                    the end point), in pixels; stage B uses it to prove that an obstacle cannot
                                    touch the corridor and skip the compose for it */
+    double*   seg_grad;         /* [n][10][2] optional: PathSeg.GradSt, GradEnd (PathSeg.py:43-47)      */
+    int32_t*  pocket_draws_used;/* [n] optional: torch.rand draws consumed by set_obstacles           */
 } ppn_paths_t;
 
 /* draws        : [n_paths][PPN_DRAWS_PER_PATH] uniform doubles in the fixed layout
@@ -112,6 +114,13 @@ int ppn_edage_paths(int32_t n_paths, uint64_t first_path_id, int32_t R, double m
                     double clearance, uint64_t seed,
                     const double* draws, const float* pocket_draws, int32_t pocket_stride,
                     const ppn_paths_t* out, void* stream);
+
+/* Same, with the path-level is_straight flag supplied by the caller (Path(is_straight=...), Path.py:53):
+ * force_straight[n] int8, -1 = decide from draw 0 as PathGroup.generate does, 0 / 1 = forced. May be NULL. */
+int ppn_edage_paths_ex(int32_t n_paths, uint64_t first_path_id, int32_t R, double map_size,
+                       double clearance, uint64_t seed,
+                       const double* draws, const float* pocket_draws, int32_t pocket_stride,
+                       const int8_t* force_straight, const ppn_paths_t* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage B — maps.  Replaces the body of MapGenerate.generate (MapGenerate.py:48-124) incl.
@@ -146,6 +155,22 @@ int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements
 int ppn_boundary_check(const double* hull, int32_t hull_n, const double* angle_deg,
                        const double* translation_rc, int32_t n, int32_t R, uint8_t* ok,
                        void* stream);
+/* same, also returning the transformed hulls hull_out[n][hull_n][2] (second element of the reference's tuple) */
+int ppn_boundary_check_ex(const double* hull, int32_t hull_n, const double* angle_deg,
+                          const double* translation_rc, int32_t n, int32_t R, uint8_t* ok,
+                          double* hull_out, void* stream);
+
+/* The accept loop of MapGenerate.generate_map_randomly (MapGenerate.py:128-143) on its own: draws[n][3K]
+ * (K x, K y, K size uniforms), pathpoint[n][1000][2]; accept[n][K] u8, obstacles[n][K][3] kept ones
+ * compacted in draw order as [col,row,r], counts[n]. */
+int ppn_obstacle_filter(const double* pathpoint, const double* draws, int32_t n, int32_t K, int32_t R,
+                        double map_size, double obstacles_size, double clearance, uint8_t* accept,
+                        double* obstacles, int32_t* counts, void* stream);
+
+/* add_init_end_single (process_map.py:119-145) on n u8 grids [n][R][R]: PPN_GRID_MARK in the 7x7 squares
+ * centred on the rounded init[n][2] and end[n][2] (row, col), clipped. */
+int ppn_paint_markers(uint8_t* grid, int32_t n, int32_t R, const double* init, const double* end,
+                      void* stream);
 
 /* Obstacle raster rule standing in for plot_obstacles (Path.py:36-49): n_maps grids of R x R,
  * grid = PPN_GRID_OBST where the pixel centre lies in a disc, else PPN_GRID_FREE.
@@ -162,11 +187,23 @@ int ppn_collision_segments(const float* s, const float* e, const int32_t* prob, 
                            uint8_t* hit, void* stream);
 
 /* extract_path (process_map.py:293-365) on n heat maps `heat` [n][H][W] float32 already
- * down-sampled; init/end [n][2] in down-sampled coordinates.  wp [n][max_wp][2] float32,
+ * down-sampled; init/end [n][2] doubles in down-sampled coordinates.  wp [n][max_wp][2] doubles,
  * wp_n[n], ok[n].  The 1 s wall-clock timeout becomes the max_wp step cap (<= PPN_MAX_WAYPOINTS). */
-int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const float* init,
-                      const float* end, int32_t max_wp, float* wp, int32_t* wp_n, uint8_t* ok,
+int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const double* init,
+                      const double* end, int32_t max_wp, double* wp, int32_t* wp_n, uint8_t* ok,
                       void* stream);
+
+/* PIL.Image.resize(size, BILINEAR) for 8-bit single-channel images, bit-exact: Pillow's ImagingResample
+ * (support = max(scale,1), 22-bit fixed-point coefficients, horizontal pass then vertical pass, each rounded
+ * to 8 bits).  Used by extract_path's down-sampling (process_map.py:301).  in [n][H][W], tmp [n][H][outW],
+ * out [n][outH][outW], all u8. */
+int ppn_resize_bilinear_u8(const uint8_t* in, int32_t n, int32_t H, int32_t W, int32_t outH, int32_t outW,
+                           uint8_t* tmp, uint8_t* out, void* stream);
+
+/* `count` uniform doubles of Philox4x32-10 stream (seed, stream, instance), draw indices first..first+count-1,
+ * exactly as the generator kernels draw them (tests pin this against oracle/philox_np.py). out[count] device. */
+int ppn_philox_doubles(uint64_t seed, uint32_t stream_id, uint64_t instance, uint32_t first, int32_t count,
+                       double* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,7 @@ class PathsStruct(C.Structure):
         "seg_poly", "seg_endpoint", "seg_rotation", "seg_translation", "seg_length", "seg_straight",
         "segpoint_world", "pathpoint_world", "boundary_world", "canvas_bits", "hull_raw", "hull", "hull_n",
         "rotation", "trans_rc", "segpoint_image", "pathpoint_image", "space_bits", "isles", "n_isles",
-        "obstacles", "n_obstacles", "length", "straight", "flags", "max_step_px")]
+        "obstacles", "n_obstacles", "length", "straight", "flags", "max_step_px", "seg_grad", "pocket_draws_used")]
 
 
 class MapsStruct(C.Structure):
@@ -44,8 +44,9 @@ class MapsStruct(C.Structure):
 
 
 EXPORTS = ("ppn_version", "ppn_error_string", "ppn_last_hip_error", "ppn_polyfit_table", "ppn_edage_paths",
-           "ppn_edage_maps", "ppn_boundary_check", "ppn_disc_raster", "ppn_collision_segments",
-           "ppn_extract_paths")
+           "ppn_edage_paths_ex", "ppn_edage_maps", "ppn_boundary_check", "ppn_boundary_check_ex",
+           "ppn_obstacle_filter", "ppn_paint_markers", "ppn_disc_raster", "ppn_collision_segments",
+           "ppn_extract_paths", "ppn_resize_bilinear_u8", "ppn_philox_doubles")
 
 
 def _load():
@@ -62,6 +63,12 @@ def _load():
     lib.ppn_polyfit_table.argtypes = [_p]
     lib.ppn_edage_paths.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.c_double, C.c_double, C.c_uint64,
                                     _p, _p, C.c_int32, C.POINTER(PathsStruct), _p]
+    lib.ppn_edage_paths_ex.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.c_double, C.c_double, C.c_uint64,
+                                       _p, _p, C.c_int32, _p, C.POINTER(PathsStruct), _p]
+    lib.ppn_boundary_check_ex.argtypes = [_p, C.c_int32, _p, _p, C.c_int32, C.c_int32, _p, _p, _p]
+    lib.ppn_obstacle_filter.argtypes = [_p, _p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                        _p, _p, _p, _p]
+    lib.ppn_paint_markers.argtypes = [_p, C.c_int32, C.c_int32, _p, _p, _p]
     lib.ppn_edage_maps.argtypes = [C.POINTER(PathsStruct), C.c_int32, C.c_int32, C.c_uint64, C.c_int32,
                                    C.c_double, C.c_double, C.c_int32, C.c_double, C.c_uint64, _p, _p,
                                    C.POINTER(MapsStruct), _p]
@@ -69,6 +76,8 @@ def _load():
     lib.ppn_disc_raster.argtypes = [_p, _p, C.c_int32, C.c_int32, C.c_int32, _p, _p]
     lib.ppn_collision_segments.argtypes = [_p, _p, _p, C.c_int32, _p, _p, C.c_float, _p, _p]
     lib.ppn_extract_paths.argtypes = [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, C.c_int32, _p, _p, _p, _p]
+    lib.ppn_resize_bilinear_u8.argtypes = [_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p, _p, _p]
+    lib.ppn_philox_doubles.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int32, _p, _p]
     for name in EXPORTS:
         getattr(lib, name)
         if name not in ("ppn_error_string",):

@@ -108,6 +108,13 @@ int ppn_polyfit_table(double* out) {
 int ppn_edage_paths(int32_t n_paths, uint64_t first_path_id, int32_t R, double map_size, double clearance,
                     uint64_t seed, const double* draws, const float* pocket_draws, int32_t pocket_stride,
                     const ppn_paths_t* out, void* stream) {
+    return ppn_edage_paths_ex(n_paths, first_path_id, R, map_size, clearance, seed, draws, pocket_draws, pocket_stride,
+                              nullptr, out, stream);
+}
+
+int ppn_edage_paths_ex(int32_t n_paths, uint64_t first_path_id, int32_t R, double map_size, double clearance,
+                       uint64_t seed, const double* draws, const float* pocket_draws, int32_t pocket_stride,
+                       const int8_t* force_straight, const ppn_paths_t* out, void* stream) {
     if (n_paths < 0 || bad_R(R) || !out || !(map_size > 0.0) || !(clearance > 0.0)) return PPN_E_INVALID;
     if (pocket_draws && pocket_stride <= 0) return PPN_E_INVALID;
     const ppn_paths_t& o = *out;
@@ -128,6 +135,7 @@ int ppn_edage_paths(int32_t n_paths, uint64_t first_path_id, int32_t R, double m
     prm.draws = draws;
     prm.pocket = pocket_draws;
     prm.pocket_stride = pocket_stride;
+    prm.force_straight = force_straight;
     int rc = polyfit_table_device(&prm.W);
     if (rc != PPN_OK) return rc;
     const size_t lds = (size_t)(2 * R) * (2 * R) / 8;
@@ -183,10 +191,35 @@ int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements
 
 int ppn_boundary_check(const double* hull, int32_t hull_n, const double* angle_deg, const double* translation_rc,
                        int32_t n, int32_t R, uint8_t* ok, void* stream) {
+    return ppn_boundary_check_ex(hull, hull_n, angle_deg, translation_rc, n, R, ok, nullptr, stream);
+}
+
+int ppn_boundary_check_ex(const double* hull, int32_t hull_n, const double* angle_deg, const double* translation_rc,
+                          int32_t n, int32_t R, uint8_t* ok, double* hull_out, void* stream) {
     if (!hull || hull_n <= 0 || !angle_deg || !translation_rc || n < 0 || R <= 0 || !ok) return PPN_E_INVALID;
     if (n == 0) return PPN_OK;
     hipLaunchKernelGGL(ppn::boundary_check_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, hull, hull_n,
-                       angle_deg, translation_rc, n, R, ok);
+                       angle_deg, translation_rc, n, R, ok, hull_out);
+    PPN_HIP(hipGetLastError());
+    return PPN_OK;
+}
+
+int ppn_obstacle_filter(const double* pathpoint, const double* draws, int32_t n, int32_t K, int32_t R, double map_size,
+                        double obstacles_size, double clearance, uint8_t* accept, double* obstacles, int32_t* counts,
+                        void* stream) {
+    if (!pathpoint || !draws || n < 0 || K <= 0 || K > 256 || R <= 0 || !(map_size > 0.0) || !obstacles || !counts)
+        return PPN_E_INVALID;
+    if (n == 0) return PPN_OK;
+    hipLaunchKernelGGL(ppn::obstacle_filter_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, pathpoint, draws, n, K, R,
+                       map_size, obstacles_size, clearance, accept, obstacles, counts);
+    PPN_HIP(hipGetLastError());
+    return PPN_OK;
+}
+
+int ppn_paint_markers(uint8_t* grid, int32_t n, int32_t R, const double* init, const double* end, void* stream) {
+    if (!grid || n < 0 || R <= 0 || !init || !end) return PPN_E_INVALID;
+    if (n == 0) return PPN_OK;
+    hipLaunchKernelGGL(ppn::paint_markers_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, grid, n, R, init, end);
     PPN_HIP(hipGetLastError());
     return PPN_OK;
 }
@@ -211,13 +244,36 @@ int ppn_collision_segments(const float* s, const float* e, const int32_t* prob, 
     return PPN_OK;
 }
 
-int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const float* init, const float* end,
-                      int32_t max_wp, float* wp, int32_t* wp_n, uint8_t* ok, void* stream) {
+int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const double* init, const double* end,
+                      int32_t max_wp, double* wp, int32_t* wp_n, uint8_t* ok, void* stream) {
     if (!heat || n < 0 || H <= 0 || W <= 0 || !init || !end || max_wp <= 0 || max_wp > PPN_MAX_WAYPOINTS || !wp || !wp_n || !ok)
         return PPN_E_INVALID;
     if (n == 0) return PPN_OK;
     hipLaunchKernelGGL(ppn::extract_paths_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, heat, n, H, W, init, end,
                        max_wp, wp, wp_n, ok);
+    PPN_HIP(hipGetLastError());
+    return PPN_OK;
+}
+
+int ppn_resize_bilinear_u8(const uint8_t* in, int32_t n, int32_t H, int32_t W, int32_t outH, int32_t outW, uint8_t* tmp,
+                           uint8_t* out, void* stream) {
+    if (!in || n < 0 || H <= 0 || W <= 0 || outH <= 0 || outW <= 0 || !tmp || !out) return PPN_E_INVALID;
+    if (n == 0) return PPN_OK;
+    const long long t1 = (long long)n * H * outW, t2 = (long long)n * outH * outW;
+    hipLaunchKernelGGL(ppn::resize_pass_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, n, H, W,
+                       H, outW, 1, tmp);
+    hipLaunchKernelGGL(ppn::resize_pass_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)tmp, n, H, outW, outH, outW, 0, out);
+    PPN_HIP(hipGetLastError());
+    return PPN_OK;
+}
+
+int ppn_philox_doubles(uint64_t seed, uint32_t stream_id, uint64_t instance, uint32_t first, int32_t count, double* out,
+                       void* stream) {
+    if (count < 0 || !out) return PPN_E_INVALID;
+    if (count == 0) return PPN_OK;
+    hipLaunchKernelGGL(ppn::philox_doubles_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed,
+                       stream_id, instance, first, count, out);
     PPN_HIP(hipGetLastError());
     return PPN_OK;
 }

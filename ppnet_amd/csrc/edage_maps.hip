@@ -430,7 +430,8 @@ extern "C" int ppn_debug_phase_cycles(unsigned long long* out_host, int reset) {
 
 // Path.boundary_check (Path.py:100-111): one wave per (angle, translation) pair
 __global__ __launch_bounds__(NT) void boundary_check_kernel(const double* hull, int hull_n, const double* angle_deg,
-                                                            const double* trans_rc, int n, int R, uint8_t* ok) {
+                                                            const double* trans_rc, int n, int R, uint8_t* ok,
+                                                            double* hull_out) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * NW + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -443,10 +444,66 @@ __global__ __launch_bounds__(NT) void boundary_check_kernel(const double* hull, 
         rot2(c, s, hull[v * 2] - half, hull[v * 2 + 1] - half, hx, hy);
         hx = hx + trans_rc[i * 2] + half;
         hy = hy + trans_rc[i * 2 + 1] + half;
+        if (hull_out) { hull_out[((size_t)i * hull_n + v) * 2] = hx; hull_out[((size_t)i * hull_n + v) * 2 + 1] = hy; }
         out = out || (hx < 0.0) || (hx >= Rd) || (hy < 0.0) || (hy >= Rd);
     }
     const bool good = __ballot(out) == 0ull;
     if (lane == 0) ok[i] = good ? 1 : 0;
+}
+
+// generate_map_randomly's accept loop on its own (MapGenerate.py:128-143): one workgroup per map,
+// one wave per candidate, shuffle min-reduce over the 500 odd path points
+__global__ __launch_bounds__(NT) void obstacle_filter_kernel(const double* pathpoint, const double* draws, int n, int K,
+                                                             int R, double map_size, double obstacles_size,
+                                                             double clearance, uint8_t* accept, double* obstacles,
+                                                             int32_t* counts) {
+    __shared__ double podd[PPN_PATH_POINTS / 2][2];
+    __shared__ uint8_t acc[256];
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double Rd = (double)R;
+    for (int q = tid; q < PPN_PATH_POINTS / 2; q += NT) {
+        podd[q][0] = pathpoint[((size_t)m * PPN_PATH_POINTS + 2 * q + 1) * 2];
+        podd[q][1] = pathpoint[((size_t)m * PPN_PATH_POINTS + 2 * q + 1) * 2 + 1];
+    }
+    __syncthreads();
+    const double* d = draws + (size_t)m * 3 * K;
+    const double c_px = clearance / map_size * Rd;
+    for (int k = wv; k < K; k += NW) {
+        const double ox = d[k] * map_size / map_size * Rd, oy = d[K + k] * map_size / map_size * Rd;
+        const double r = d[2 * K + k] * obstacles_size / map_size * Rd;
+        double mn = 1e300;
+        for (int q = lane; q < PPN_PATH_POINTS / 2; q += 64) {
+            const double dx = podd[q][0] - ox, dy = podd[q][1] - oy;
+            mn = fmin(mn, dx * dx + dy * dy);
+        }
+        mn = sqrt(wave_min(mn));
+        if (lane == 0) acc[k] = mn > r + c_px ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int cnt = 0;
+        for (int k = 0; k < K; ++k) {
+            if (accept) accept[(size_t)m * K + k] = acc[k];
+            if (acc[k]) {
+                double* o = obstacles + ((size_t)m * K + cnt) * 3;
+                o[0] = d[K + k] * map_size / map_size * Rd;
+                o[1] = d[k] * map_size / map_size * Rd;
+                o[2] = d[2 * K + k] * obstacles_size / map_size * Rd;
+                ++cnt;
+            }
+        }
+        counts[m] = cnt;
+    }
+}
+
+// add_init_end_single (process_map.py:119-145): 2 x 49 pixels per grid
+__global__ __launch_bounds__(128) void paint_markers_kernel(uint8_t* grid, int n, int R, const double* init, const double* end) {
+    const int m = blockIdx.x, t = threadIdx.x;
+    if (t >= 98) return;
+    const double* p = t < 49 ? init + (size_t)m * 2 : end + (size_t)m * 2;
+    const int q = t % 49;
+    const int i = (int)rint(p[0]) + q / 7 - 3, j = (int)rint(p[1]) + q % 7 - 3;
+    if (i >= 0 && i < R && j >= 0 && j < R) grid[(size_t)m * R * R + (size_t)i * R + j] = PPN_GRID_MARK;
 }
 
 // explicit obstacle raster rule (stands in for Path.plot_obstacles, Path.py:36-49)

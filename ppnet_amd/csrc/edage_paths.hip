@@ -94,7 +94,8 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
 
     // ------------------------------------------------------------------ A1: ten segment fits
     const double d0 = fed ? fed[0] : philox_double(prm.seed, STREAM_PATH, pid, 0);
-    const bool path_straight = !(d0 > 0.01);                     // PathGenerate.py:36
+    const int forced = prm.force_straight ? (int)prm.force_straight[p] : -1;
+    const bool path_straight = forced >= 0 ? (forced != 0) : !(d0 > 0.01);    // PathGenerate.py:36 / Path.py:53
     for (int s = 0; s < PPN_SEGS; ++s) {
         const uint32_t base = 1u + (uint32_t)s * PPN_DRAWS_PER_SEG + 1u;   // first sample draw (even)
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
         O.seg_translation[o * 2] = S.trans[tid][0];
         O.seg_translation[o * 2 + 1] = S.trans[tid][1];
         O.seg_straight[o] = S.straight[tid];
+        if (O.seg_grad) { O.seg_grad[o * 2] = S.grad[tid][0]; O.seg_grad[o * 2 + 1] = S.grad[tid][1]; }
     }
     if (tid < PPN_SEGS + 1) {
         O.segpoint_world[((size_t)p * 11 + tid) * 2] = S.segpoint[tid][0];
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
     }
 
     // ------------------------------------------------------------------ A8: set_obstacles
-    int n_obs = 0;
+    int n_obs = 0, n_pocket_draws = 0;
     {
         const double c_px = clearance / prm.map_size * Rd;               // Path.py:490
         const float size_clearance_f = (float)(clearance / prm.map_size * Rd * 1.1);   // Path.py:465
@@ -579,11 +581,13 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
                 }
             }
         }
+        n_pocket_draws = (int)fdraw;
     }
     if (tid == 0) {
         O.n_isles[p] = n_isles;
         O.n_obstacles[p] = n_obs;
         O.flags[p] = flags;
+        if (O.pocket_draws_used) O.pocket_draws_used[p] = n_pocket_draws;
     }
 }
 

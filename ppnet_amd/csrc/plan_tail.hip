@@ -31,9 +31,9 @@ __global__ __launch_bounds__(256) void collision_segments_kernel(const float* s_
         const float ox = obs[k * 3], oy = obs[k * 3 + 1];
         const double size = (double)obs[k * 3 + 2];
         const double lim = size + lim_add;
-        // scipy euclidean on float32 inputs: float64 arithmetic
-        const double ddx = (double)ex - (double)ox, ddy = (double)ey - (double)oy;
-        if (sqrt(ddx * ddx + ddy * ddy) < lim) { h = 1; break; }         // :397 (tests e twice, never s)
+        // scipy euclidean keeps the float32 of its inputs
+        const float ddx = ex - ox, ddy = ey - oy;
+        if ((double)sqrtf(ddx * ddx + ddy * ddy) < lim) { h = 1; break; }   // :397 (tests e twice, never s)
         const float qx = ox - sx, qy = oy - sy;
         float dis = dirx * qx + diry * qy;                                // np.dot, float32
         if (dis > 0.0f) { dirx = -dirx; diry = -diry; }                   // dir mutates across obstacles, :406-407
@@ -50,15 +50,15 @@ __global__ __launch_bounds__(256) void collision_segments_kernel(const float* s_
     hit[i] = h;
 }
 
-__global__ __launch_bounds__(64) void extract_paths_kernel(const float* heat, int n, int H, int W, const float* init,
-                                                           const float* end, int max_wp, float* wp, int32_t* wp_n,
+__global__ __launch_bounds__(64) void extract_paths_kernel(const float* heat, int n, int H, int W, const double* init,
+                                                           const double* end, int max_wp, double* wp, int32_t* wp_n,
                                                            uint8_t* ok) {
     __shared__ short hist[PPN_MAX_WAYPOINTS][2];                         // offsets from init, exact small ints
     const int p = blockIdx.x, lane = threadIdx.x;
     const float* hm = heat + (size_t)p * H * W;
-    float* out = wp + (size_t)p * max_wp * 2;
-    const double i0 = (double)init[p * 2], i1 = (double)init[p * 2 + 1];
-    const double g0 = (double)end[p * 2], g1 = (double)end[p * 2 + 1];
+    double* out = wp + (size_t)p * max_wp * 2;
+    const double i0 = init[p * 2], i1 = init[p * 2 + 1];
+    const double g0 = end[p * 2], g1 = end[p * 2 + 1];
     const int mr[8] = {0, 0, 1, -1, 1, 1, -1, -1};                        // motions, process_map.py:294-297
     const int mc[8] = {1, -1, 0, 0, 1, -1, 1, -1};
     // a waypoint is init + integer offset: keep the offsets exact in int, rebuild doubles on demand
@@ -110,10 +110,61 @@ __global__ __launch_bounds__(64) void extract_paths_kernel(const float* heat, in
     // offsets -> coordinates (still in down-sampled units; the host scales by the rate)
     __syncthreads();
     for (int q = lane; q < cnt; q += 64) {
-        out[q * 2] = (float)(i0 + (double)hist[q][0]);
-        out[q * 2 + 1] = (float)(i1 + (double)hist[q][1]);
+        out[q * 2] = i0 + (double)hist[q][0];
+        out[q * 2 + 1] = i1 + (double)hist[q][1];
     }
     if (lane == 0) { wp_n[p] = success ? cnt : 0; ok[p] = (uint8_t)success; }
+}
+
+// One pass of Pillow's ImagingResample for 8-bit pixels with the bilinear (triangle) filter.
+// horizontal != 0: in [n][inH][inW] -> out [n][inH][outW]; else in [n][inH][inW] -> out [n][outH][inW].
+// Coefficients are recomputed per output sample in double with Pillow's operation order
+// (precompute_coeffs + normalize_coeffs_8bpc, PRECISION_BITS = 22).
+__global__ __launch_bounds__(256) void resize_pass_kernel(const uint8_t* in, int n, int inH, int inW, int outH, int outW,
+                                                          int horizontal, uint8_t* out) {
+    const int oH = horizontal ? inH : outH, oW = horizontal ? outW : inW;
+    const long long total = (long long)n * oH * oW;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % oW), y = (int)((idx / oW) % oH), img = (int)(idx / ((long long)oW * oH));
+    const int inSize = horizontal ? inW : inH, outSize = horizontal ? outW : outH, xx = horizontal ? x : y;
+    const double scale = (double)inSize / (double)outSize;
+    double filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 1.0 * filterscale;
+    const double center = 0.0 + ((double)xx + 0.5) * scale;
+    const double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > inSize) xmax = inSize;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int t = 0; t < xmax; ++t) {
+        double a = ((double)(t + xmin) - center + 0.5) * ss;
+        if (a < 0.0) a = -a;
+        ww += a < 1.0 ? 1.0 - a : 0.0;
+    }
+    int acc = 1 << 21;
+    const uint8_t* base = in + (size_t)img * inH * inW;
+    for (int t = 0; t < xmax; ++t) {
+        double a = ((double)(t + xmin) - center + 0.5) * ss;
+        if (a < 0.0) a = -a;
+        double w = a < 1.0 ? 1.0 - a : 0.0;
+        if (ww != 0.0) w = w / ww;
+        const int kq = w < 0.0 ? (int)(-0.5 + w * 4194304.0) : (int)(0.5 + w * 4194304.0);
+        const int pix = horizontal ? base[(size_t)y * inW + xmin + t] : base[(size_t)(xmin + t) * inW + x];
+        acc += pix * kq;
+    }
+    int v = acc >> 22;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    out[idx] = (uint8_t)v;
+}
+
+__global__ __launch_bounds__(256) void philox_doubles_kernel(uint64_t seed, uint32_t stream_id, uint64_t instance,
+                                                             uint32_t first, int count, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = philox_double(seed, stream_id, instance, first + (uint32_t)i);
 }
 
 }  // namespace ppn

@@ -17,6 +17,7 @@ struct PathsParams {
     const float* pocket;       // [n][pocket_stride] or null
     int pocket_stride;
     const double* W;           // [4][1000] least-squares operator (device)
+    const int8_t* force_straight;  // [n] or null
 };
 
 struct MapsParams {
@@ -36,13 +37,22 @@ struct MapsParams {
 __global__ void edage_paths_kernel(PathsParams prm);
 __global__ void edage_maps_kernel(MapsParams prm);
 __global__ void boundary_check_kernel(const double* hull, int hull_n, const double* angle_deg,
-                                      const double* trans_rc, int n, int R, uint8_t* ok);
+                                      const double* trans_rc, int n, int R, uint8_t* ok, double* hull_out);
+__global__ void obstacle_filter_kernel(const double* pathpoint, const double* draws, int n, int K, int R,
+                                       double map_size, double obstacles_size, double clearance, uint8_t* accept,
+                                       double* obstacles, int32_t* counts);
+__global__ void paint_markers_kernel(uint8_t* grid, int n, int R, const double* init, const double* end);
 __global__ void disc_raster_kernel(const double* obstacles, const int32_t* counts, int stride,
                                    int n_maps, int R, uint8_t* grid);
 __global__ void collision_segments_kernel(const float* s, const float* e, const int32_t* prob, int n_seg,
                                           const float* obs, const int32_t* obs_off, float clearance,
                                           uint8_t* hit);
-__global__ void extract_paths_kernel(const float* heat, int n, int H, int W, const float* init,
-                                     const float* end, int max_wp, float* wp, int32_t* wp_n, uint8_t* ok);
+__global__ void extract_paths_kernel(const float* heat, int n, int H, int W, const double* init,
+                                     const double* end, int max_wp, double* wp, int32_t* wp_n, uint8_t* ok);
+
+__global__ void resize_pass_kernel(const uint8_t* in, int n, int inH, int inW, int outH, int outW, int horizontal,
+                                   uint8_t* out);
+__global__ void philox_doubles_kernel(uint64_t seed, uint32_t stream_id, uint64_t instance, uint32_t first, int count,
+                                      double* out);
 
 }  // namespace ppn

@@ -59,6 +59,8 @@ class PathsBatch:
         self.straight = z(n, **i32)
         self.flags = z(n, **i32)
         self.max_step_px = z(n, **f64)
+        self.seg_grad = z(n, 10, 2, **f64)
+        self.pocket_draws_used = z(n, **i32)
         self.struct = L.PathsStruct(**{name: _ptr(getattr(self, name)) for name, _ in L.PathsStruct._fields_})
 
     def space_mask(self):
@@ -97,7 +99,7 @@ class MapsBatch:
 
 
 def generate_paths(n_paths, resolution=224, map_size=50, clearance=1, seed=0, first_path_id=0, device="cuda:0",
-                   draws=None, pocket_draws=None, debug=False, out=None):
+                   draws=None, pocket_draws=None, debug=False, out=None, force_straight=None):
     """Stage A for `n_paths` paths. draws / pocket_draws: optional device tensors that replace the
     Philox streams ([n, 10021] float64 in the fixed layout; [n, stride] float32 in torch.rand order)."""
     device = torch.device(device)
@@ -108,9 +110,12 @@ def generate_paths(n_paths, resolution=224, map_size=50, clearance=1, seed=0, fi
     if pocket_draws is not None:
         assert pocket_draws.dtype == torch.float32 and pocket_draws.is_contiguous() and pocket_draws.shape[0] == n_paths
         stride = pocket_draws.shape[1]
+    if force_straight is not None:
+        assert force_straight.dtype == torch.int8 and force_straight.is_contiguous() and force_straight.shape[0] == n_paths
     with torch.cuda.device(device):
-        rc = L.lib.ppn_edage_paths(n_paths, first_path_id, resolution, float(map_size), float(clearance), seed,
-                                   _ptr(draws), _ptr(pocket_draws), stride, C.byref(pb.struct), _stream_ptr(device))
+        rc = L.lib.ppn_edage_paths_ex(n_paths, first_path_id, resolution, float(map_size), float(clearance), seed,
+                                      _ptr(draws), _ptr(pocket_draws), stride, _ptr(force_straight),
+                                      C.byref(pb.struct), _stream_ptr(device))
     L.check(rc, "ppn_edage_paths")
     return pb
 
@@ -133,16 +138,51 @@ def generate_maps(paths, placements, obstacles_size=5, obstacles_num=50, seed=0,
     return mb
 
 
-def boundary_check(hull, angle_deg, translation_rc, resolution):
+def boundary_check(hull, angle_deg, translation_rc, resolution, return_hull=False):
     """Path.boundary_check for n (angle, translation) pairs against one hull [h,2] (device tensors)."""
     n = angle_deg.shape[0]
     ok = torch.empty(n, dtype=torch.uint8, device=hull.device)
     hull = hull.contiguous()
+    hull_out = torch.empty(n, hull.shape[0], 2, dtype=torch.float64, device=hull.device) if return_hull else None
     with torch.cuda.device(hull.device):
-        rc = L.lib.ppn_boundary_check(_ptr(hull), hull.shape[0], _ptr(angle_deg.contiguous()),
-                                      _ptr(translation_rc.contiguous()), n, resolution, _ptr(ok), _stream_ptr(hull.device))
+        rc = L.lib.ppn_boundary_check_ex(_ptr(hull), hull.shape[0], _ptr(angle_deg.contiguous()),
+                                         _ptr(translation_rc.contiguous()), n, resolution, _ptr(ok), _ptr(hull_out),
+                                         _stream_ptr(hull.device))
     L.check(rc, "ppn_boundary_check")
-    return ok.bool()
+    return (ok.bool(), hull_out) if return_hull else ok.bool()
+
+
+def obstacle_filter(pathpoint, draws, K, resolution, map_size, obstacles_size, clearance):
+    """generate_map_randomly's accept loop (MapGenerate.py:128-143): pathpoint [n,1000,2], draws [n,3K] (device f64).
+    Returns (accept [n,K] bool, obstacles [n,K,3] as [col,row,r], counts [n])."""
+    n = pathpoint.shape[0]
+    dev = pathpoint.device
+    accept = torch.empty(n, K, dtype=torch.uint8, device=dev)
+    obstacles = torch.zeros(n, K, 3, dtype=torch.float64, device=dev)
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib.ppn_obstacle_filter(_ptr(pathpoint.contiguous()), _ptr(draws.contiguous()), n, K, resolution,
+                                       float(map_size), float(obstacles_size), float(clearance), _ptr(accept),
+                                       _ptr(obstacles), _ptr(counts), _stream_ptr(dev))
+    L.check(rc, "ppn_obstacle_filter")
+    return accept.bool(), obstacles, counts
+
+
+def paint_markers(grid, init, end):
+    """add_init_end_single on u8 grids [n,R,R] in place; init / end [n,2] f64 (row, col)."""
+    with torch.cuda.device(grid.device):
+        rc = L.lib.ppn_paint_markers(_ptr(grid), grid.shape[0], grid.shape[1], _ptr(init.contiguous()),
+                                     _ptr(end.contiguous()), _stream_ptr(grid.device))
+    L.check(rc, "ppn_paint_markers")
+    return grid
+
+
+def grid_to_rgb(grid):
+    """u8 codes [n,R,R] -> float image [n,3,R,R] in [0,1] as the reference saves it: free white, obstacle black,
+    start/goal red (the [255,0,0] paint saturates to (1,0,0), process_map.py:120,128)."""
+    free = (grid == L.GRID_FREE).to(torch.float32)
+    mark = (grid == L.GRID_MARK).to(torch.float32)
+    return torch.stack([free + mark, free, free], dim=1)
 
 
 def disc_raster(obstacles, counts, resolution):

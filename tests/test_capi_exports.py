@@ -39,7 +39,7 @@ def test_binding_matches_header():
     assert sorted(_lib.EXPORTS) == _declared()
     assert _lib.lib.ppn_version() >= 100
     assert _lib.lib.ppn_error_string(-1) == b"invalid argument"
-    assert C.sizeof(_lib.PathsStruct) == 26 * C.sizeof(C.c_void_p)
+    assert C.sizeof(_lib.PathsStruct) == 28 * C.sizeof(C.c_void_p)
     assert C.sizeof(_lib.MapsStruct) == 10 * C.sizeof(C.c_void_p)
 
 

@@ -1,0 +1,95 @@
+"""GPU parity for the planner tail (rows B9/B10) and the Philox draw kernel: the HIP path against golden
+vectors from the reference's process_map.py, against Pillow (resize), and against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import philox_np as px
+from oracle import plan_np as PN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_philox_device_matches_oracle(dev):
+    from ppnet_amd import philox
+    for seed, stream, inst, first, n in [(0, 1, 0, 0, 10021), (123456789012345, 3, 77, 5, 999), (7, 4, 2 ** 33 + 5, 0, 61)]:
+        got = philox.doubles_device(seed, stream, inst, first, n, dev).cpu().numpy()
+        assert np.array_equal(got, px.doubles(seed, stream, inst, first, n))          # bit-exact
+
+
+def test_collision_segments_vs_reference_golden(dev, golden_dir):
+    import torch
+    from ppnet_amd import plan
+    g = np.load(os.path.join(golden_dir, "g11_collision.npz"))
+    n = len(g["hit"])
+    off = np.concatenate([[0], np.cumsum(g["n_obs"])]).astype(np.int32)
+    hit = plan.collision_segments(torch.tensor(g["s"], device=dev), torch.tensor(g["e"], device=dev),
+                                  torch.arange(n, dtype=torch.int32, device=dev),
+                                  torch.tensor(g["obs"].astype(np.float32), device=dev), torch.tensor(off, device=dev),
+                                  float(g["clearance"][0]))
+    assert hit.cpu().numpy().astype(np.int8).tolist() == g["hit"].tolist()              # bit-exact mask
+
+
+def test_resize_matches_pillow(dev):
+    import torch
+    from PIL import Image
+    from ppnet_amd import plan
+    rng = np.random.RandomState(1)
+    for (h, w, oh, ow) in [(224, 224, 112, 112), (256, 256, 128, 128), (64, 96, 16, 48), (50, 70, 25, 35), (33, 47, 11, 15)]:
+        a = rng.randint(0, 256, size=(3, h, w)).astype(np.uint8)
+        got = plan.resize_bilinear_u8(torch.tensor(a, device=dev), oh, ow).cpu().numpy()
+        for i in range(3):
+            want = np.asarray(Image.fromarray(a[i], mode="L").resize((ow, oh), Image.BILINEAR))
+            assert np.array_equal(got[i], want)
+
+
+def test_extract_paths_vs_reference_golden(dev, golden_dir):
+    import torch
+    from ppnet_amd import plan
+    g = np.load(os.path.join(golden_dir, "g11_extract_path.npz"))
+    for R in (224, 256):
+        cases = [c for c in range(int(g["ncase"][0])) if g[f"c{c}_img"].shape[0] == R]
+        heat = torch.tensor(np.stack([g[f"c{c}_img"] for c in cases]), device=dev)
+        init = torch.tensor(np.stack([g[f"c{c}_init"] for c in cases]), device=dev)
+        end = torch.tensor(np.stack([g[f"c{c}_end"] for c in cases]), device=dev)
+        ok, full, cnt = plan.extract_paths(heat, init, end, down_sample_rate=2)
+        for k, c in enumerate(cases):
+            assert int(ok[k]) == int(g[f"c{c}_ok"][0])
+            if int(ok[k]):
+                want = g[f"c{c}_path"]
+                assert int(cnt[k]) == len(want)                                          # same waypoint count
+                assert np.abs(full[k, :len(want)].cpu().numpy() - want).max() < 1e-5     # fixture passed through float32
+
+
+def test_extract_paths_vs_oracle_random_heat(dev):
+    import torch
+    from ppnet_amd import plan
+    rng = np.random.RandomState(4)
+    R, n = 128, 6
+    yy, xx = np.mgrid[0:R, 0:R].astype(np.float64)
+    heats, inits, ends = [], [], []
+    for t in range(n):
+        init = rng.random_sample(2) * 30 + 10
+        end = rng.random_sample(2) * 30 + 85
+        ts = np.linspace(0, 1, 300)[:, None]
+        ctrl = rng.random_sample(2) * 90 + 20
+        curve = (1 - ts) ** 2 * init + 2 * ts * (1 - ts) * ctrl + ts ** 2 * end
+        d2 = np.min((yy[None] - curve[:, 0, None, None]) ** 2 + (xx[None] - curve[:, 1, None, None]) ** 2, axis=0)
+        h = np.exp(-d2 / (2 * 3.0 ** 2)) + rng.random_sample((R, R)) * 0.02
+        heats.append((np.clip(h, 0, 1) * 255).astype(np.uint8)); inits.append(init); ends.append(end)
+    ok, full, cnt = plan.extract_paths(torch.tensor(np.stack(heats), device=dev), torch.tensor(np.stack(inits), device=dev),
+                                       torch.tensor(np.stack(ends), device=dev), down_sample_rate=2)
+    for t in range(n):
+        o_ok, o_path = PN.extract_path(heats[t], inits[t], ends[t], down_sample_rate=2)
+        assert bool(ok[t]) == bool(o_ok)
+        if o_ok:
+            assert int(cnt[t]) == len(o_path)
+            assert np.abs(full[t, :len(o_path)].cpu().numpy() - o_path).max() < 1e-9     # waypoints are exact lattice sums
