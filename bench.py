@@ -75,7 +75,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from ppnet_amd import edage
+    from ppnet_amd import edage, shard
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -99,7 +99,7 @@ def main():
 
     def launch_paths(it):
         b = it % 2
-        first_path = (it * world + rank) * PATHS
+        first_path, _, _ = shard.local_ids(PATHS * world, PLACEMENTS, rank, world, batch_index=it)
         with torch.cuda.stream(s_paths):
             if consumed[b] is not None:
                 s_paths.wait_event(consumed[b])
@@ -107,14 +107,11 @@ def main():
             ready[b] = torch.cuda.Event()
             ready[b].record(s_paths)
     n_local = PATHS * PLACEMENTS
-    rec_w = 2 + 2 + 22                       # angle, flags/n_obs, translation, segpoint[11,2] -> float64 record
-    rec = torch.empty(n_local, rec_w, dtype=torch.float64, device=dev)
-    gathered = torch.empty(world * n_local, rec_w, dtype=torch.float64, device=dev) if world > 1 else None
 
     def step(it, last=False):
         # a fresh batch every step: path / map ids advance so no two steps generate the same instances
         b = it % 2
-        first_path = (it * world + rank) * PATHS
+        first_path, _, first_map = shard.local_ids(PATHS * world, PLACEMENTS, rank, world, batch_index=it)
         if ready[b] is None:
             launch_paths(it)                  # pipeline fill (first step only)
         if not last:
@@ -124,16 +121,12 @@ def main():
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record()
-        edage.generate_maps(pbs[b], PLACEMENTS, OBST_SIZE, K, seed=SEED, first_map_id=first_path * PLACEMENTS, out=mb)
+        edage.generate_maps(pbs[b], PLACEMENTS, OBST_SIZE, K, seed=SEED, first_map_id=first_map, out=mb)
         ev1.record()
         consumed[b] = torch.cuda.Event()
         consumed[b].record(s_maps)
         if world > 1:                         # end-of-batch gather of the fixed-size records (RCCL over xGMI)
-            rec[:, 0] = mb.angle
-            rec[:, 1] = mb.flags.to(torch.float64)
-            rec[:, 2:4] = mb.translation.to(torch.float64)
-            rec[:, 4:] = mb.segpoint.reshape(n_local, 22)
-            dist.all_gather_into_tensor(gathered, rec)
+            shard.gather_records(shard.pack_records(mb.angle, mb.flags, mb.translation, mb.segpoint), world)
         return ev0, ev1
 
     for it in range(args.warmup):

@@ -1,0 +1,51 @@
+"""Instance sharding over the GPUs of one node (one process per GPU, torch.distributed).
+
+Problem instances are independent: rank r of W owns a contiguous range of target paths and all of their
+placements, and every random draw is keyed by the *global* path / map id, so results do not depend on W.
+There is no data-path collective; the only exchange is the end-of-batch all-gather of fixed-size
+per-instance records (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+RECORD_WIDTH = 26      # angle, flags, translation[2], segpoint[11,2] as float64
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous, balanced split of range(n_total): the first n_total % world ranks get one extra."""
+    q, r = divmod(n_total, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def local_ids(n_paths_total, placements, rank, world, batch_index=0):
+    """(first_path_id, n_local_paths, first_map_id) of this rank for batch `batch_index`."""
+    lo, hi = shard_range(n_paths_total, rank, world)
+    base = batch_index * n_paths_total
+    return base + lo, hi - lo, (base + lo) * placements
+
+
+def pack_records(angle, flags, translation, segpoint):
+    n = angle.shape[0]
+    rec = torch.empty(n, RECORD_WIDTH, dtype=torch.float64, device=angle.device)
+    rec[:, 0] = angle
+    rec[:, 1] = flags.to(torch.float64)
+    rec[:, 2:4] = translation.to(torch.float64)
+    rec[:, 4:] = segpoint.reshape(n, 22)
+    return rec
+
+
+def gather_records(rec, world, sizes=None, group=None):
+    """All-gather of per-instance records; `sizes` = rows per rank when shards are uneven."""
+    if world == 1:
+        return rec
+    if sizes is None or len(set(sizes)) == 1:
+        out = torch.empty(world * rec.shape[0], rec.shape[1], dtype=rec.dtype, device=rec.device)
+        dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
+        return out
+    m = max(sizes)
+    pad = torch.zeros(m, rec.shape[1], dtype=rec.dtype, device=rec.device)
+    pad[:rec.shape[0]] = rec
+    out = torch.empty(world * m, rec.shape[1], dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return torch.cat([out[r * m:r * m + sizes[r]] for r in range(world)])
