@@ -193,6 +193,14 @@ int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const 
                       const double* end, int32_t max_wp, double* wp, int32_t* wp_n, uint8_t* ok,
                       void* stream);
 
+/* Fused neighbourhood attention forward (replaces natten2dqkrpb + softmax + natten2dav behind
+ * natten.NeighborhoodAttention2D, SegNet/nat.py:111-120,144).  qkv is the qkv Linear's output viewed as
+ * [B][H][W][3][heads][32]; rpb [heads][13][13] float32; out [B][H][W][heads*32] (what `proj` consumes).
+ * kernel size 7, head dim 32, dilation >= 1 with H, W >= 7*dilation (the module pads first, as NATTEN does).
+ * dtype: 0 = float32, 1 = bfloat16 (float32 accumulation). q is multiplied by `scale` before QK. */
+int ppn_na2d_fwd(const void* qkv, const float* rpb, void* out, int32_t B, int32_t H, int32_t W, int32_t heads,
+                 int32_t dilation, float scale, int32_t dtype, void* stream);
+
 /* PIL.Image.resize(size, BILINEAR) for 8-bit single-channel images, bit-exact: Pillow's ImagingResample
  * (support = max(scale,1), 22-bit fixed-point coefficients, horizontal pass then vertical pass, each rounded
  * to 8 bits).  Used by extract_path's down-sampling (process_map.py:301).  in [n][H][W], tmp [n][H][outW],

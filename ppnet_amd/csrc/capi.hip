@@ -255,6 +255,16 @@ int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const 
     return PPN_OK;
 }
 
+int ppn_na2d_fwd(const void* qkv, const float* rpb, void* out, int32_t B, int32_t H, int32_t W, int32_t heads,
+                 int32_t dilation, float scale, int32_t dtype, void* stream) {
+    if (!qkv || !rpb || !out || B <= 0 || heads <= 0 || dilation < 1 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
+    if (H < 7 * dilation || W < 7 * dilation) return PPN_E_INVALID;      // caller pads, like NATTEN's module
+    if ((long long)B * dilation * dilation > 65535) return PPN_E_INVALID;
+    const int e = ppn::na2d_launch(qkv, rpb, out, B, H, W, heads, dilation, scale, dtype, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_resize_bilinear_u8(const uint8_t* in, int32_t n, int32_t H, int32_t W, int32_t outH, int32_t outW, uint8_t* tmp,
                            uint8_t* out, void* stream) {
     if (!in || n < 0 || H <= 0 || W <= 0 || outH <= 0 || outW <= 0 || !tmp || !out) return PPN_E_INVALID;

@@ -1,0 +1,180 @@
+// na2d.hip — fused 2-D neighbourhood attention forward for gfx950:  QK^T + relative position bias ->
+// softmax over the k x k (dilated) neighbourhood -> AV, in one kernel, reading q/k/v straight out of the
+// qkv projection's output layout and writing the layout the output projection consumes.
+//
+// Replaces the two NATTEN CUDA kernels the reference calls through natten.NeighborhoodAttention2D
+// (SegNet/nat.py:111-120,144): natten2dqkrpb + softmax + natten2dav.  NATTEN's source is not part of the
+// reference; the semantics implemented here are stated in oracle/na_np.py ("parity unpinned"):
+// a query at position i of an axis of length L belongs to dilation group i mod d; inside the group (positions
+// g, g+d, ...; n of them) its window is the k consecutive group members starting at clamp(i/d - k/2, 0, n-k),
+// and the bias index of window member t is (start + t - i/d) + (k-1).
+//
+// Dilated attention is plain (d = 1) attention on each of the d*d sub-sampled images, so one workgroup
+// handles a 16x16 tile of queries of one (batch, head, dilation group): the (16+k-1)^2 halo of K rows is
+// staged in LDS (rows padded to a conflict-free stride for ds_read_b128), each lane keeps its 49 logits in
+// registers, then the same LDS buffer is refilled with V.  HBM traffic is q, k, v read once (+ halo overlap)
+// and out written once; head_dim = 32 (every NAT/DiNAT level), kernel 7.
+#include <hip/hip_bf16.h>
+#include "ppn_device.h"
+#include "ppn_kernels.h"
+
+namespace ppn {
+
+namespace {
+constexpr int KS = 7, NS = 3, HD = 32, TILE = 16, HALO = TILE + KS - 1;   // 22
+
+template <typename T> struct Row;
+template <> struct Row<float> { static constexpr int STRIDE = 36; };          // 144 B: 16 lanes x b128 hit 64 distinct banks
+template <> struct Row<__hip_bfloat16> { static constexpr int STRIDE = 40; }; // 80 B
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__hip_bfloat16 v) { return __bfloat162float(v); }
+__device__ __forceinline__ void store_out(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store_out(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// one 32-element row (LDS or global) -> 32 floats, with 16-byte accesses
+__device__ __forceinline__ void load_row(const float* row, float (&r)[HD]) {
+#pragma unroll
+    for (int p = 0; p < HD / 4; ++p) {
+        const float4 v = *reinterpret_cast<const float4*>(row + 4 * p);
+        r[4 * p] = v.x; r[4 * p + 1] = v.y; r[4 * p + 2] = v.z; r[4 * p + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void load_row(const __hip_bfloat16* row, float (&r)[HD]) {
+#pragma unroll
+    for (int p = 0; p < HD / 8; ++p) {
+        const uint4 v = *reinterpret_cast<const uint4*>(row + 8 * p);       // 8 bf16; f32 bits = bf16 bits << 16
+        r[8 * p] = __uint_as_float(v.x << 16);     r[8 * p + 1] = __uint_as_float(v.x & 0xffff0000u);
+        r[8 * p + 2] = __uint_as_float(v.y << 16); r[8 * p + 3] = __uint_as_float(v.y & 0xffff0000u);
+        r[8 * p + 4] = __uint_as_float(v.z << 16); r[8 * p + 5] = __uint_as_float(v.z & 0xffff0000u);
+        r[8 * p + 6] = __uint_as_float(v.w << 16); r[8 * p + 7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+}
+}  // namespace
+
+template <typename T>
+__global__ __launch_bounds__(256) void na2d_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ rpb,
+                                                       T* __restrict__ out, int B, int H, int W, int heads, int dil,
+                                                       float scale) {
+    constexpr int STRIDE = Row<T>::STRIDE;
+    extern __shared__ unsigned char na_lds[];
+    T* tile = reinterpret_cast<T*>(na_lds);                                 // [HALO*HALO][STRIDE]
+    float* bias = reinterpret_cast<float*>(na_lds + (size_t)HALO * HALO * STRIDE * sizeof(T));   // [13][13]
+
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z / (dil * dil), g = blockIdx.z % (dil * dil);
+    const int gi = g / dil, gj = g % dil;
+    const int hs = (H - gi + dil - 1) / dil, ws = (W - gj + dil - 1) / dil;   // sub-image of this dilation group
+    const int tiles_x = (((W + dil - 1) / dil) + TILE - 1) / TILE;
+    const int ti0 = (blockIdx.x / tiles_x) * TILE, tj0 = (blockIdx.x % tiles_x) * TILE;
+    if (ti0 >= hs || tj0 >= ws) return;                                     // uniform: whole block leaves
+
+    const int u = ti0 + ty, v = tj0 + tx;                                   // query in sub-image coordinates
+    const bool valid = u < hs && v < ws;
+    const int umax = min(ti0 + TILE - 1, hs - 1), vmax = min(tj0 + TILE - 1, ws - 1);
+    const int r0 = clampi(ti0 - NS, 0, hs - KS), c0 = clampi(tj0 - NS, 0, ws - KS);
+    const int nr = clampi(umax - NS, 0, hs - KS) + KS - r0, nc = clampi(vmax - NS, 0, ws - KS) + KS - c0;
+    const int wi = clampi(u - NS, 0, hs - KS), wj = clampi(v - NS, 0, ws - KS);   // window start of this query
+    const size_t tok = (size_t)3 * heads * HD;                              // elements per token in qkv
+
+    for (int t = tid; t < 13 * 13; t += 256) bias[t] = rpb[(size_t)h * 169 + t];
+
+    auto load_tile = [&](int which) {                                       // which: 1 = K, 2 = V
+        // one 16-byte piece per lane: HD*sizeof(T)/16 pieces per row
+        constexpr int PIECES = HD * (int)sizeof(T) / 16, EPP = 16 / (int)sizeof(T);
+        for (int p = tid; p < nr * nc * PIECES; p += 256) {
+            const int row = p / PIECES, piece = p - row * PIECES;
+            const int rr = row / nc, cc = row - rr * nc;
+            const int y = gi + (r0 + rr) * dil, x = gj + (c0 + cc) * dil;
+            const T* src = qkv + ((size_t)(b * H + y) * W + x) * tok + ((size_t)which * heads + h) * HD + piece * EPP;
+            *reinterpret_cast<uint4*>(tile + (size_t)(rr * HALO + cc) * STRIDE + piece * EPP) = *reinterpret_cast<const uint4*>(src);
+        }
+    };
+
+    float q[HD];
+    if (valid) {
+        const int y = gi + u * dil, x = gj + v * dil;
+        const T* src = qkv + ((size_t)(b * H + y) * W + x) * tok + (size_t)h * HD;
+        load_row(src, q);
+#pragma unroll
+        for (int c = 0; c < HD; ++c) q[c] = q[c] * scale;                   // q = q * scale before QK (NATTEN module)
+    }
+    load_tile(1);
+    __syncthreads();
+
+    float logit[KS * KS];
+    float mx = -3.0e38f;
+    if (valid) {
+        const int pbi = wi - u + (KS - 1), pbj = wj - v + (KS - 1);         // bias index of window member (0,0)
+#pragma unroll
+        for (int ki = 0; ki < KS; ++ki) {
+#pragma unroll
+            for (int kj = 0; kj < KS; ++kj) {
+                float kr[HD];
+                load_row(tile + (size_t)((wi - r0 + ki) * HALO + (wj - c0 + kj)) * STRIDE, kr);
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < HD; ++c) acc = fmaf(q[c], kr[c], acc);
+                acc += bias[(pbi + ki) * 13 + pbj + kj];
+                logit[ki * KS + kj] = acc;
+                mx = fmaxf(mx, acc);
+                asm volatile("" ::: "memory");                              // keep one neighbour's row in flight, not 49
+            }
+        }
+    }
+    __syncthreads();
+    load_tile(2);
+    __syncthreads();
+    if (valid) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t) { logit[t] = expf(logit[t] - mx); sum += logit[t]; }
+        float o[HD];
+#pragma unroll
+        for (int c = 0; c < HD; ++c) o[c] = 0.0f;
+#pragma unroll
+        for (int ki = 0; ki < KS; ++ki) {
+#pragma unroll
+            for (int kj = 0; kj < KS; ++kj) {
+                float vr[HD];
+                load_row(tile + (size_t)((wi - r0 + ki) * HALO + (wj - c0 + kj)) * STRIDE, vr);
+                const float p = logit[ki * KS + kj];
+#pragma unroll
+                for (int c = 0; c < HD; ++c) o[c] = fmaf(p, vr[c], o[c]);
+                asm volatile("" ::: "memory");
+            }
+        }
+        const float inv = 1.0f / sum;
+        const int y = gi + u * dil, x = gj + v * dil;
+        T* dst = out + ((size_t)(b * H + y) * W + x) * ((size_t)heads * HD) + (size_t)h * HD;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) store_out(dst + c, o[c] * inv);
+    }
+}
+
+template __global__ void na2d_fwd_kernel<float>(const float*, const float*, float*, int, int, int, int, int, float);
+template __global__ void na2d_fwd_kernel<__hip_bfloat16>(const __hip_bfloat16*, const float*, __hip_bfloat16*, int, int, int,
+                                                         int, int, float);
+
+int na2d_launch(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int dil, float scale,
+                int dtype, hipStream_t stream) {
+    const int hs = (H + dil - 1) / dil, ws = (W + dil - 1) / dil;
+    const dim3 grid(((hs + TILE - 1) / TILE) * ((ws + TILE - 1) / TILE), heads, B * dil * dil);
+    if (dtype == 0) {
+        const size_t lds = (size_t)HALO * HALO * Row<float>::STRIDE * sizeof(float) + 169 * sizeof(float);
+        hipError_t e = hipFuncSetAttribute((const void*)na2d_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(na2d_fwd_kernel<float>, grid, dim3(256), lds, stream, (const float*)qkv, rpb, (float*)out, B, H, W,
+                           heads, dil, scale);
+    } else {
+        const size_t lds = (size_t)HALO * HALO * Row<__hip_bfloat16>::STRIDE * sizeof(__hip_bfloat16) + 169 * sizeof(float);
+        hipLaunchKernelGGL(na2d_fwd_kernel<__hip_bfloat16>, grid, dim3(256), lds, stream, (const __hip_bfloat16*)qkv, rpb,
+                           (__hip_bfloat16*)out, B, H, W, heads, dil, scale);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace ppn

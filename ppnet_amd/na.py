@@ -1,0 +1,67 @@
+"""Neighbourhood attention on MI355X: `NeighborhoodAttention2D` with the constructor, forward signature and
+state-dict keys (`qkv.*`, `rpb`, `proj.*`) of natten.NeighborhoodAttention2D as the reference uses it
+(SegNet/nat.py:111-120,144), backed by the fused HIP kernel (ppn_na2d_fwd). Forward only; no CPU fallback."""
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+
+
+def na2d_forward(qkv, rpb, heads, dilation, scale):
+    """qkv: [B,H,W,3*C] contiguous CUDA tensor (float32 or bfloat16) straight from the qkv Linear;
+    rpb: [heads,13,13]. Returns [B,H,W,C] in the layout the output projection consumes."""
+    if not qkv.is_cuda:
+        raise RuntimeError("ppnet_amd.na: the neighbourhood-attention kernel runs on the GPU only (no CPU fallback)")
+    B, H, W, C3 = qkv.shape
+    ch = C3 // 3
+    if ch // heads != 32:
+        raise NotImplementedError("head_dim must be 32 (every NAT/DiNAT level)")
+    dtype = {torch.float32: 0, torch.bfloat16: 1}.get(qkv.dtype)
+    if dtype is None:
+        raise NotImplementedError(f"dtype {qkv.dtype}")
+    qkv = qkv.contiguous()
+    rpb = rpb.detach().to(torch.float32).contiguous()
+    out = torch.empty(B, H, W, ch, dtype=qkv.dtype, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        rc = L.lib.ppn_na2d_fwd(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(rpb.data_ptr()),
+                                ctypes.c_void_p(out.data_ptr()), B, H, W, heads, dilation, float(scale), dtype,
+                                ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream))
+    L.check(rc, "ppn_na2d_fwd")
+    return out
+
+
+class NeighborhoodAttention2D(nn.Module):
+    def __init__(self, dim, kernel_size, dilation=None, num_heads=1, qkv_bias=True, qk_scale=None, attn_drop=0.0,
+                 proj_drop=0.0):
+        super().__init__()
+        if kernel_size != 7:
+            raise NotImplementedError("kernel_size 7 only (every configuration in SegNet/configs)")
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = qk_scale or self.head_dim ** -0.5
+        self.kernel_size = kernel_size
+        self.dilation = dilation or 1
+        self.window_size = self.kernel_size * self.dilation
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.rpb = nn.Parameter(torch.zeros(num_heads, 2 * kernel_size - 1, 2 * kernel_size - 1))
+        nn.init.trunc_normal_(self.rpb, std=0.02, mean=0.0, a=-2.0, b=2.0)
+        self.proj = nn.Linear(dim, dim)
+        # attn_drop / proj_drop are identities at inference; kept for signature compatibility
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x):
+        B, Hp, Wp, C = x.shape
+        H, W = Hp, Wp
+        pad_r = pad_b = 0
+        if H < self.window_size or W < self.window_size:              # pad BEFORE qkv, bottom/right (NATTEN module)
+            pad_r = max(0, self.window_size - W)
+            pad_b = max(0, self.window_size - H)
+            x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))
+        o = na2d_forward(self.qkv(x), self.rpb, self.num_heads, self.dilation, self.scale)
+        if pad_r or pad_b:
+            o = o[:, :Hp, :Wp, :]
+        return self.proj_drop(self.proj(o))
