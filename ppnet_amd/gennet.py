@@ -1,0 +1,93 @@
+"""GenNet's AE-ViT (reference GenNet/networks/ae_vit.py:12-76 + vit.py:71-161) as an inference module with the
+reference's constructor `AEViT(img_channels, out_channels, img_resolution, dim)` and state-dict key names
+(`conv_first.{0,1}`, `enc_conv.i.{0,1}`, `vit_blocks.i.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}`,
+`dec_conv.i.{0,1}`, `conv_final`), so `model.load_state_dict(torch.load(w)['model'])` (predict.py:51-52) works.
+
+Structure: conv3x3+BN+LeakyReLU stem, int(log2(R//28)) stride-2 conv stages, 3 pre-LN ViT blocks (3 heads,
+MLP x4, GELU, LN eps 1e-6) on the (R/2^n)^2 tokens, mirrored transposed-conv stages, conv3x3 to out_channels.
+Dense work runs on the ROCm libraries through PyTorch (bf16 autocast optional); pinned against the reference's
+own module by tests/golden/g13_aevit.npz.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias=True):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        q, k, v = self.qkv(x).view(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(q, k, v, scale=self.scale)        # softmax(q k^T * scale) v, vit.py:103-109
+        return self.proj(o.transpose(1, 2).reshape(B, N, C))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim, num_heads)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x):                     # DropPath is the identity at inference (vit.py:158-161)
+        x = x + self.attn(self.norm1(x))
+        return x + self.mlp(self.norm2(x))
+
+
+def _stage(conv):
+    return nn.Sequential(conv, nn.BatchNorm2d(conv.out_channels), nn.LeakyReLU())
+
+
+class AEViT(nn.Module):
+    def __init__(self, img_channels, out_channels, img_resolution=256, dim=192):
+        super().__init__()
+        n_down = int(math.log2(img_resolution // 28))                       # ae_vit.py:23
+        self.conv_first = _stage(nn.Conv2d(img_channels, dim, 3, 1, 1))
+        self.enc_conv = nn.ModuleList(_stage(nn.Conv2d(dim, dim, 3, 2, 1)) for _ in range(n_down))
+        self.vit_blocks = nn.Sequential(*[_Block(dim, 3, 4) for _ in range(3)])
+        self.dec_conv = nn.ModuleList(_stage(nn.ConvTranspose2d(dim, dim, 3, 2, 1, output_padding=1)) for _ in range(n_down))
+        self.conv_final = nn.Conv2d(dim, out_channels, 3, 1, 1)
+
+    def forward(self, x):
+        x = self.conv_first(x)
+        for blk in self.enc_conv:
+            x = blk(x)
+        B, C, H, W = x.shape
+        t = self.vit_blocks(x.flatten(2).transpose(1, 2))                    # feature2token / token2feature, base.py:43-52
+        x = t.transpose(1, 2).reshape(B, C, H, W)
+        for blk in self.dec_conv:
+            x = blk(x)
+        return self.conv_final(x)
+
+
+AE = AEViT      # predict.py:12 `from networks import AEViT as AE`
+
+
+def normalize_heatmap_u8(y):
+    """predict.py:95-102 per sample: (y - min) / (max - min) -> 8-bit 'L' image. y [B,1,R,R] -> u8 [B,R,R]."""
+    B = y.shape[0]
+    f = y.float().reshape(B, -1)
+    lo = f.min(dim=1, keepdim=True).values
+    hi = f.max(dim=1, keepdim=True).values
+    n = (f - lo) / (hi - lo)
+    return (n * 255).to(torch.uint8).reshape(B, y.shape[-2], y.shape[-1])    # ToPILImage: mul(255).byte()

@@ -1,0 +1,204 @@
+"""SegNet = NAT / DiNAT backbone + SETR-UP head (reference SegNet/nat.py:17-332, dinat.py:15-22,
+mmseg/decode_heads/setr_up_head.py:28-81, mmseg/models/segmentors/encoder_decoder.py:63-80,200-265) as plain
+inference nn.Modules with the reference's constructor arguments and checkpoint key names
+(`backbone.patch_embed.proj.{0,1}`, `backbone.levels.i.blocks.j.{norm1,attn.{qkv,rpb,proj},norm2,mlp.{fc1,fc2},
+gamma1,gamma2}`, `backbone.levels.i.downsample.{reduction,norm}`, `backbone.norm{i}`,
+`decode_head.{norm,up_convs.i.0.{conv,bn},conv_seg}`), so mmcv `{'state_dict', 'meta'}` checkpoints load.
+
+The neighbourhood attention is the hand-written HIP kernel (ppnet_amd/na.py); tokenizer / downsampler / head
+convolutions and the linear projections run on the ROCm libraries through PyTorch.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .na import NeighborhoodAttention2D
+
+
+class ConvTokenizer(nn.Module):
+    def __init__(self, in_chans=3, embed_dim=96, norm_layer=None):
+        super().__init__()
+        self.proj = nn.Sequential(nn.Conv2d(in_chans, embed_dim // 2, 3, 2, 1), nn.Conv2d(embed_dim // 2, embed_dim, 3, 2, 1))
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+    def forward(self, x):
+        x = self.proj(x).permute(0, 2, 3, 1)
+        return self.norm(x) if self.norm is not None else x
+
+
+class ConvDownsampler(nn.Module):
+    def __init__(self, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.reduction = nn.Conv2d(dim, 2 * dim, 3, 2, 1, bias=False)
+        self.norm = norm_layer(2 * dim)
+
+    def forward(self, x):
+        return self.norm(self.reduction(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1))
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class NATLayer(nn.Module):
+    def __init__(self, dim, num_heads, kernel_size=7, dilation=None, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
+                 drop=0.0, attn_drop=0.0, drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm, layer_scale=None):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = NeighborhoodAttention2D(dim, kernel_size=kernel_size, dilation=dilation, num_heads=num_heads,
+                                            qkv_bias=qkv_bias, qk_scale=qk_scale)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), act_layer=act_layer)
+        self.layer_scale = layer_scale is not None and type(layer_scale) in (int, float)
+        if self.layer_scale:
+            self.gamma1 = nn.Parameter(layer_scale * torch.ones(dim))
+            self.gamma2 = nn.Parameter(layer_scale * torch.ones(dim))
+
+    def forward(self, x):                      # DropPath is the identity at inference (nat.py:140-153)
+        a = self.attn(self.norm1(x))
+        x = x + (self.gamma1 * a if self.layer_scale else a)
+        m = self.mlp(self.norm2(x))
+        return x + (self.gamma2 * m if self.layer_scale else m)
+
+
+class NATBlock(nn.Module):
+    def __init__(self, dim, depth, num_heads, kernel_size, dilations=None, downsample=True, mlp_ratio=4.0, qkv_bias=True,
+                 qk_scale=None, drop=0.0, attn_drop=0.0, drop_path=0.0, norm_layer=nn.LayerNorm, layer_scale=None):
+        super().__init__()
+        self.blocks = nn.ModuleList(
+            NATLayer(dim, num_heads, kernel_size, None if dilations is None else dilations[i], mlp_ratio, qkv_bias,
+                     qk_scale, norm_layer=norm_layer, layer_scale=layer_scale) for i in range(depth))
+        self.downsample = ConvDownsampler(dim, norm_layer) if downsample else None
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = blk(x)
+        return (x, x) if self.downsample is None else (self.downsample(x), x)
+
+
+class NAT(nn.Module):
+    def __init__(self, embed_dim, mlp_ratio, depths, num_heads, drop_path_rate=0.2, in_chans=3, kernel_size=7,
+                 dilations=None, out_indices=(0, 1, 2, 3), qkv_bias=True, qk_scale=None, drop_rate=0.0,
+                 attn_drop_rate=0.0, norm_layer=nn.LayerNorm, frozen_stages=-1, pretrained=None, layer_scale=None,
+                 **kwargs):
+        super().__init__()
+        self.num_levels = len(depths)
+        self.embed_dim = embed_dim
+        self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_levels)]
+        self.patch_embed = ConvTokenizer(in_chans, embed_dim, norm_layer)
+        self.levels = nn.ModuleList(
+            NATBlock(int(embed_dim * 2 ** i), depths[i], num_heads[i], kernel_size,
+                     None if dilations is None else dilations[i], downsample=(i < self.num_levels - 1),
+                     mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, norm_layer=norm_layer,
+                     layer_scale=layer_scale) for i in range(self.num_levels))
+        self.out_indices = out_indices
+        for i in out_indices:
+            self.add_module(f"norm{i}", norm_layer(self.num_features[i]))
+        if isinstance(pretrained, str):
+            self.init_weights(pretrained)
+
+    def init_weights(self, pretrained=None):
+        if isinstance(pretrained, str):
+            sd = torch.load(pretrained, map_location="cpu", weights_only=True)
+            sd = sd.get("state_dict", sd.get("model", sd))
+            self.load_state_dict(sd, strict=False)
+
+    def forward(self, x):
+        x = self.patch_embed(x)
+        outs = []
+        for idx, level in enumerate(self.levels):
+            x, xo = level(x)
+            if idx in self.out_indices:
+                outs.append(getattr(self, f"norm{idx}")(xo).permute(0, 3, 1, 2).contiguous())
+        return outs
+
+
+class DiNAT(NAT):
+    """DiNAT is NAT with per-layer dilations (dinat.py:15-22)."""
+
+
+class _ConvModule(nn.Sequential):
+    """mmcv ConvModule(conv -> bn -> ReLU) with its parameter names `conv.*`, `bn.*` (conv has no bias under a norm)."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.add_module("conv", nn.Conv2d(cin, cout, k, 1, (k - 1) // 2, bias=False))
+        self.add_module("bn", nn.BatchNorm2d(cout))          # SyncBN reverts to BN outside distributed runs (SegNet/train.py:179-185)
+        self.add_module("activate", nn.ReLU(inplace=True))
+
+
+class _Upsample(nn.Module):
+    def __init__(self, scale_factor, align_corners=False):
+        super().__init__()
+        self.scale_factor, self.align_corners = float(scale_factor), align_corners
+
+    def forward(self, x):
+        size = [int(t * self.scale_factor) for t in x.shape[-2:]]            # mmseg/ops/wrappers.py:43-51
+        return F.interpolate(x, size, None, "bilinear", self.align_corners)
+
+
+class SETRUPHead(nn.Module):
+    def __init__(self, in_channels=1024, channels=512, num_classes=2, num_convs=1, up_scale=4, kernel_size=3,
+                 in_index=-1, dropout_ratio=0.1, align_corners=False, norm_layer=None, norm_cfg=None, **kwargs):
+        super().__init__()
+        assert kernel_size in (1, 3)
+        self.in_index, self.align_corners = in_index, align_corners
+        self.norm = nn.LayerNorm(in_channels, eps=1e-6)
+        self.up_convs = nn.ModuleList()
+        cin = in_channels
+        for _ in range(num_convs):
+            self.up_convs.append(nn.Sequential(_ConvModule(cin, channels, kernel_size), _Upsample(up_scale, align_corners)))
+            cin = channels
+        self.conv_seg = nn.Conv2d(channels, num_classes, 1)                  # Dropout2d is the identity at inference
+
+    def forward(self, inputs):
+        x = inputs[self.in_index]
+        n, c, h, w = x.shape
+        x = self.norm(x.reshape(n, c, h * w).transpose(2, 1)).transpose(1, 2).reshape(n, c, h, w)
+        for up in self.up_convs:
+            x = up(x)
+        return self.conv_seg(x)
+
+
+DINAT_BASE = dict(   # SegNet/configs/dinat/dinat_base.py:5-24 over _base_/models/dinat.py:3-46
+    backbone=dict(embed_dim=128, mlp_ratio=2.0, depths=[3, 4, 18, 5], num_heads=[4, 8, 16, 32], kernel_size=7,
+                  layer_scale=1e-5,
+                  dilations=[[1, 16, 1], [1, 4, 1, 8], [1, 2, 1, 3, 1, 4, 1, 2, 1, 3, 1, 4, 1, 2, 1, 3, 1, 4], [1, 2, 1, 2, 1]]),
+    decode_head=dict(in_channels=1024, channels=512, num_convs=4, up_scale=2, num_classes=2, kernel_size=3))
+
+IMG_MEAN = (123.675, 116.28, 103.53)       # _base_/datasets/planning_seg.py:12-13
+IMG_STD = (58.395, 57.12, 57.375)
+
+
+class SegNet(nn.Module):
+    """EncoderDecoder(test_cfg=mode 'whole') for inference: encode_decode -> softmax -> argmax."""
+
+    def __init__(self, backbone=None, decode_head=None):
+        super().__init__()
+        self.backbone = DiNAT(**(backbone or DINAT_BASE["backbone"]))
+        self.decode_head = SETRUPHead(**(decode_head or DINAT_BASE["decode_head"]))
+        self.align_corners = self.decode_head.align_corners
+
+    def encode_decode(self, img):
+        out = self.decode_head(self.backbone(img))
+        return F.interpolate(out, img.shape[2:], mode="bilinear", align_corners=self.align_corners)
+
+    def forward(self, img, return_logits=False):
+        logits = self.encode_decode(img)
+        pred = F.softmax(logits.float(), dim=1).argmax(dim=1)               # encoder_decoder.py:242,257
+        return (pred, logits) if return_logits else pred
+
+
+def normalize_images(rgb_u8):
+    """u8 [B,R,R,3] or float [B,3,R,R] in [0,255] -> (x - mean) / std, [B,3,R,R] (planning_seg.py:12-41)."""
+    x = rgb_u8.permute(0, 3, 1, 2).float() if rgb_u8.dtype == torch.uint8 else rgb_u8.float()
+    mean = torch.tensor(IMG_MEAN, device=x.device).view(1, 3, 1, 1)
+    std = torch.tensor(IMG_STD, device=x.device).view(1, 3, 1, 1)
+    return (x - mean) / std

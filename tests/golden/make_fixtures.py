@@ -410,8 +410,41 @@ def fixture_plan_tail(PM):
                         init=np.array([3.4, 61.5]), end=np.array([30.5, 31.5]))
 
 
+# ----------------------------------------------------------------------------- G13 AE-ViT
+def fixture_aevit():
+    """GenNet AEViT(1,1,R,24) (GenNet/networks/ae_vit.py:12-76, the model predict.py:46 builds) with seeded
+    random weights in eval mode: weights (as plain arrays), {0,1} inputs and outputs at R = 64 and 224."""
+    gen = "/root/reference/GenNet"
+    sys.path.insert(0, gen)
+    from networks.ae_vit import AEViT
+    out = {}
+    for R, B in ((64, 3), (224, 2)):
+        torch.manual_seed(100 + R)
+        m = AEViT(1, 1, R, 24).eval()
+        # make BatchNorm statistics non-trivial so eval-mode folding is exercised
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.running_mean.uniform_(-0.2, 0.2)
+                    mod.running_var.uniform_(0.5, 1.5)
+                    mod.weight.uniform_(0.8, 1.2)
+                    mod.bias.uniform_(-0.1, 0.1)
+        x = (torch.rand(B, 1, R, R) > 0.5).float()            # my_dataset.py:15: values {0,1}
+        with torch.no_grad():
+            y = m(x)
+        for k, v in m.state_dict().items():
+            out[f"R{R}/w/{k}"] = v.numpy()
+        out[f"R{R}/x"] = x.numpy().astype(np.uint8)
+        out[f"R{R}/y"] = y.numpy()
+    np.savez_compressed(os.path.join(OUT, "g13_aevit.npz"), **out)
+    sys.path.remove(gen)
+
+
 def main():
     _install_stubs()
+    if len(sys.argv) > 1 and sys.argv[1] == "aevit":
+        fixture_aevit()
+        return
     sys.path.insert(0, REF)
     import PathSeg as PathSegMod
     import Path as PathMod
@@ -426,6 +459,10 @@ def main():
         print("config-1 fixture: reference did not terminate within 1500 s (seed 0)", flush=True)
     import process_map as PM
     fixture_plan_tail(PM)
+    sys.path.remove(REF)
+    for mod in ("utils",):
+        sys.modules.pop(mod, None)
+    fixture_aevit()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
