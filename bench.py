@@ -65,12 +65,70 @@ def cpu_baseline():
             "host_cores": os.cpu_count()}
 
 
+def ppnet_leg(torch, dev, mb, batch, steps, world):
+    """BASELINE config 3: PPNet inference (SegNet DiNAT-B + SETR-UP -> GenNet AE-ViT -> waypoint extraction ->
+    collision check), batch of 256 problems over the 256x256 maps stage B just produced, per GPU.  Weights are
+    seeded random initialisations of the reference architectures (no trained weights ship with the reference)."""
+    import torch.distributed as dist
+    from ppnet_amd.ppnet import PPNet
+    torch.manual_seed(0)
+    model = PPNet(resolution=R).to(dev).eval()
+    g = mb.grid[:batch]
+    init, end = mb.segpoint[:batch, 0].contiguous(), mb.segpoint[:batch, 10].contiguous()
+    obs, n_obs = mb.obstacles[:batch], mb.n_obstacles[:batch, 0].contiguous()
+    clearance = 1 / 50 * 224                                                  # process_map.py:491-495 call site
+
+    def one():
+        return model.plan(g, init, end, obs, n_obs, clearance)
+    for _ in range(2):
+        r = one()
+    torch.cuda.synchronize()
+    t_seg = t_gen = t_tail = 0.0
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ev[0].record(); mask = model.segment(g)
+        ev[1].record(); heat = model.heatmap(mask)
+        ev[2].record(); r = one() if False else None
+        from ppnet_amd import plan as _plan
+        ok, wp, cnt = _plan.extract_paths(heat, init, end, 2)
+        ev[3].record()
+        torch.cuda.synchronize()
+        t_seg += ev[0].elapsed_time(ev[1]); t_gen += ev[1].elapsed_time(ev[2]); t_tail += ev[2].elapsed_time(ev[3])
+    torch.cuda.synchronize()
+    # the timed figure is the full plan() call (segment + heatmap + extract + collision)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        r = one()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return {"metric": "ppnet_plans_per_sec", "value": round(world * batch * steps / el, 1), "unit": "plans/s",
+            "batch_per_gpu": batch, "steps": steps, "ms_per_batch": round(el / steps * 1e3, 2), "dtype": "bf16 (fp32 accumulate)",
+            "workload": "PPNet inference batch=256 over 256x256 maps: DiNAT-B + SETR-UP -> AE-ViT -> extract_path -> collision check",
+            "ms_segnet": round(t_seg / steps, 2), "ms_gennet": round(t_gen / steps, 2), "ms_extract": round(t_tail / steps, 2),
+            "weights": "seeded random init (no trained weights in the reference)",
+            "extract_ok_rate": round(float(r["ok"].float().mean().item()), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ppnet", action="store_true", help="skip the PPNet plans/s leg (BASELINE config 3)")
+    ap.add_argument("--ppnet-batch", type=int, default=256)
+    ap.add_argument("--ppnet-steps", type=int, default=5)
     args = ap.parse_args()
 
     import torch
@@ -152,6 +210,9 @@ def main():
     total_instances = world * n_local * args.steps
     value = total_instances / elapsed
 
+    ppnet = None
+    if not args.no_ppnet:
+        ppnet = ppnet_leg(torch, dev, mb, args.ppnet_batch, args.ppnet_steps, world)
     if rank == 0:
         bytes_per_launch = algorithmic_bytes_per_map(k_tot, k_pocket) * n_local
         achieved = bytes_per_launch / (maps_kernel_ms * 1e-3) / 1e9
@@ -179,6 +240,8 @@ def main():
             "placement_success": round(placed, 4),
             "mean_obstacles_per_map": round(k_tot, 2),
         }
+        if ppnet is not None:
+            out["ppnet"] = ppnet
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -259,7 +259,10 @@ int ppn_na2d_fwd(const void* qkv, const float* rpb, void* out, int32_t B, int32_
                  int32_t dilation, float scale, int32_t dtype, void* stream) {
     if (!qkv || !rpb || !out || B <= 0 || heads <= 0 || dilation < 1 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
     if (H < 7 * dilation || W < 7 * dilation) return PPN_E_INVALID;      // caller pads, like NATTEN's module
-    if ((long long)B * dilation * dilation > 65535) return PPN_E_INVALID;
+    {
+        const long long hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
+        if (((hs + 15) / 16) * ((ws + 15) / 16) * (long long)B * dilation * dilation > 0x7fffffffLL) return PPN_E_INVALID;
+    }
     const int e = ppn::na2d_launch(qkv, rpb, out, B, H, W, heads, dilation, scale, dtype, (hipStream_t)stream);
     if (e != 0) return hip_fail((hipError_t)e);
     return PPN_OK;

@@ -65,11 +65,13 @@ __global__ __launch_bounds__(256) void na2d_fwd_kernel(const T* __restrict__ qkv
 
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     const int h = blockIdx.y;
-    const int b = blockIdx.z / (dil * dil), g = blockIdx.z % (dil * dil);
+    const int tiles_x = (((W + dil - 1) / dil) + TILE - 1) / TILE, tiles_y = (((H + dil - 1) / dil) + TILE - 1) / TILE;
+    const int ntiles = tiles_x * tiles_y;
+    const int bz = blockIdx.x / ntiles, tile_id = blockIdx.x - bz * ntiles;     // grid.x = tiles * B * d*d (grid.z caps at 65535)
+    const int b = bz / (dil * dil), g = bz % (dil * dil);
     const int gi = g / dil, gj = g % dil;
     const int hs = (H - gi + dil - 1) / dil, ws = (W - gj + dil - 1) / dil;   // sub-image of this dilation group
-    const int tiles_x = (((W + dil - 1) / dil) + TILE - 1) / TILE;
-    const int ti0 = (blockIdx.x / tiles_x) * TILE, tj0 = (blockIdx.x % tiles_x) * TILE;
+    const int ti0 = (tile_id / tiles_x) * TILE, tj0 = (tile_id % tiles_x) * TILE;
     if (ti0 >= hs || tj0 >= ws) return;                                     // uniform: whole block leaves
 
     const int u = ti0 + ty, v = tj0 + tx;                                   // query in sub-image coordinates
@@ -162,7 +164,7 @@ template __global__ void na2d_fwd_kernel<__hip_bfloat16>(const __hip_bfloat16*, 
 int na2d_launch(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int dil, float scale,
                 int dtype, hipStream_t stream) {
     const int hs = (H + dil - 1) / dil, ws = (W + dil - 1) / dil;
-    const dim3 grid(((hs + TILE - 1) / TILE) * ((ws + TILE - 1) / TILE), heads, B * dil * dil);
+    const dim3 grid((unsigned)(((hs + TILE - 1) / TILE) * ((ws + TILE - 1) / TILE)) * (unsigned)(B * dil * dil), heads, 1);
     if (dtype == 0) {
         const size_t lds = (size_t)HALO * HALO * Row<float>::STRIDE * sizeof(float) + 169 * sizeof(float);
         hipError_t e = hipFuncSetAttribute((const void*)na2d_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

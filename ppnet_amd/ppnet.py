@@ -1,0 +1,58 @@
+"""PPNet inference path, batched over planning problems (reference: SegNet/test.py -> GenNet/predict.py ->
+EDaGe-PP/process_map.extract_path_image): occupancy grid -> SegNet free-space mask -> GenNet waypoint heat map ->
+greedy waypoint extraction -> circle-segment collision check.  Everything stays on the device."""
+import torch
+
+from . import _lib as L
+from . import edage, plan
+from .gennet import AEViT, normalize_heatmap_u8
+from .segnet import SegNet, normalize_images
+
+
+class PPNet(torch.nn.Module):
+    def __init__(self, resolution=256, segnet=None, gennet=None, amp_dtype=torch.bfloat16):
+        super().__init__()
+        self.resolution = resolution
+        self.segnet = segnet if segnet is not None else SegNet()
+        self.gennet = gennet if gennet is not None else AEViT(1, 1, resolution, 24)      # predict.py:36,46
+        self.amp_dtype = amp_dtype
+
+    @torch.no_grad()
+    def segment(self, grid_u8):
+        """u8 occupancy codes [B,R,R] -> free-space class mask [B,R,R] int64 (SegNet argmax)."""
+        rgb = edage.grid_to_rgb(grid_u8) * 255.0                             # the JPEG the reference would read back
+        x = normalize_images(rgb)
+        with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            return self.segnet(x)
+
+    @torch.no_grad()
+    def heatmap(self, mask):
+        """class mask [B,R,R] -> 8-bit waypoint heat map [B,R,R] (GenNet + per-sample min-max, predict.py:88-102)."""
+        x = mask.to(torch.float32).unsqueeze(1)                              # my_dataset.py:15: values {0,1}
+        with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            y = self.gennet(x)
+        return normalize_heatmap_u8(y)
+
+    @torch.no_grad()
+    def plan(self, grid_u8, init, end, obstacles, n_obstacles, clearance, down_sample_rate=2):
+        """Full pipeline for B problems. init/end [B,2] f64 (row, col); obstacles [B,S,3] f64 rows [col,row,r] with
+        n_obstacles [B] valid. Returns dict(ok, waypoints, counts, collision, success)."""
+        B = grid_u8.shape[0]
+        dev = grid_u8.device
+        heat = self.heatmap(self.segment(grid_u8))
+        ok, wp, cnt = plan.extract_paths(heat, init, end, down_sample_rate)
+        # consecutive-waypoint segments of every problem -> one collision launch (process_map.py:491-495)
+        M = wp.shape[1]
+        s = wp[:, :-1].reshape(-1, 2).to(torch.float32)
+        e = wp[:, 1:].reshape(-1, 2).to(torch.float32)
+        prob = torch.arange(B, device=dev, dtype=torch.int32).repeat_interleave(M - 1)
+        seg_valid = (torch.arange(M - 1, device=dev)[None, :] < (cnt[:, None] - 1)).reshape(-1)
+        S = obstacles.shape[1]
+        obs = obstacles.reshape(-1, 3).to(torch.float32)
+        off = (torch.arange(B + 1, device=dev, dtype=torch.int32) * S)
+        # only the first n_obstacles rows of each problem are real: give the rest zero size far away
+        pad = (torch.arange(S, device=dev)[None, :] >= n_obstacles[:, None].to(torch.int64)).reshape(-1)
+        obs = torch.where(pad[:, None], torch.tensor([-1e6, -1e6, 0.0], device=dev), obs)
+        hit = plan.collision_segments(s, e, prob, obs, off, clearance)
+        collision = (hit & seg_valid).reshape(B, M - 1).any(dim=1)
+        return dict(ok=ok, waypoints=wp, counts=cnt, collision=collision, success=ok & ~collision)

@@ -162,9 +162,13 @@ class SETRUPHead(nn.Module):
         x = inputs[self.in_index]
         n, c, h, w = x.shape
         x = self.norm(x.reshape(n, c, h * w).transpose(2, 1)).transpose(1, 2).reshape(n, c, h, w)
-        for up in self.up_convs:
+        for up in self.up_convs[:-1]:
             x = up(x)
-        return self.conv_seg(x)
+        # last stage: conv_seg is a 1x1 convolution and bilinear interpolation is linear with weights summing to 1,
+        # so conv_seg(upsample(y)) == upsample(conv_seg(y)): classify at the low resolution and upsample 2 channels
+        # instead of `channels` (the reference materialises a [B,512,R/2,R/2] tensor here, setr_up_head.py:78-80)
+        conv, up = self.up_convs[-1][0], self.up_convs[-1][1]
+        return up(self.conv_seg(conv(x)))
 
 
 DINAT_BASE = dict(   # SegNet/configs/dinat/dinat_base.py:5-24 over _base_/models/dinat.py:3-46
