@@ -21,7 +21,7 @@
 namespace ppn {
 
 namespace {
-constexpr int KS = 7, NS = 3, HD = 32, TILE = 16, HALO = TILE + KS - 1;   // 22
+constexpr int KS = 7, NS = 3, HD = 32;
 
 template <typename T> struct Row;
 template <> struct Row<float> { static constexpr int STRIDE = 36; };          // 144 B: 16 lanes x b128 hit 64 distinct banks
@@ -54,40 +54,49 @@ __device__ __forceinline__ void load_row(const __hip_bfloat16* row, float (&r)[H
 }
 }  // namespace
 
-template <typename T>
+// TILE x TILE queries per tile, NT threads per tile (= TILE*TILE), 256/NT tiles per workgroup.  TILE = 16: one tile
+// per workgroup (large sub-images); TILE = 8: four independent 8x8 tiles, one per wave — DiNAT's dilations leave
+// 7x7 or 8x8 sub-images on most layers, where a 16x16 tile would idle 75-80 % of its lanes.
+template <typename T, int TILE>
 __global__ __launch_bounds__(256) void na2d_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ rpb,
                                                        T* __restrict__ out, int B, int H, int W, int heads, int dil,
-                                                       float scale) {
+                                                       float scale, int total_tiles) {
     constexpr int STRIDE = Row<T>::STRIDE;
+    constexpr int HALO = TILE + KS - 1, NT = TILE * TILE, TPB = 256 / NT;    // tiles per workgroup
     extern __shared__ unsigned char na_lds[];
-    T* tile = reinterpret_cast<T*>(na_lds);                                 // [HALO*HALO][STRIDE]
-    float* bias = reinterpret_cast<float*>(na_lds + (size_t)HALO * HALO * STRIDE * sizeof(T));   // [13][13]
+    const int sub = threadIdx.x / NT;                                        // which tile of this workgroup
+    T* tile = reinterpret_cast<T*>(na_lds) + (size_t)sub * HALO * HALO * STRIDE;     // [HALO*HALO][STRIDE] per tile
+    float* bias = reinterpret_cast<float*>(na_lds + (size_t)TPB * HALO * HALO * STRIDE * sizeof(T));   // [13][13]
 
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int tid = threadIdx.x % NT, ty = tid / TILE, tx = tid % TILE;
     const int h = blockIdx.y;
     const int tiles_x = (((W + dil - 1) / dil) + TILE - 1) / TILE, tiles_y = (((H + dil - 1) / dil) + TILE - 1) / TILE;
     const int ntiles = tiles_x * tiles_y;
-    const int bz = blockIdx.x / ntiles, tile_id = blockIdx.x - bz * ntiles;     // grid.x = tiles * B * d*d (grid.z caps at 65535)
+    const int gtile = min((int)blockIdx.x * TPB + sub, total_tiles - 1);      // surplus sub-tiles redo the last tile's loads, store nothing
+    const bool live = (int)blockIdx.x * TPB + sub < total_tiles;
+    const int bz = gtile / ntiles, tile_id = gtile - bz * ntiles;             // tiles * B * d*d folded into grid.x
     const int b = bz / (dil * dil), g = bz % (dil * dil);
     const int gi = g / dil, gj = g % dil;
     const int hs = (H - gi + dil - 1) / dil, ws = (W - gj + dil - 1) / dil;   // sub-image of this dilation group
     const int ti0 = (tile_id / tiles_x) * TILE, tj0 = (tile_id % tiles_x) * TILE;
-    if (ti0 >= hs || tj0 >= ws) return;                                     // uniform: whole block leaves
+    // a tile outside this group's sub-image (groups differ by one row/column) idles through the barriers
+    const bool tile_in = live && ti0 < hs && tj0 < ws;
 
     const int u = ti0 + ty, v = tj0 + tx;                                   // query in sub-image coordinates
-    const bool valid = u < hs && v < ws;
+    const bool valid = tile_in && u < hs && v < ws;
     const int umax = min(ti0 + TILE - 1, hs - 1), vmax = min(tj0 + TILE - 1, ws - 1);
     const int r0 = clampi(ti0 - NS, 0, hs - KS), c0 = clampi(tj0 - NS, 0, ws - KS);
     const int nr = clampi(umax - NS, 0, hs - KS) + KS - r0, nc = clampi(vmax - NS, 0, ws - KS) + KS - c0;
     const int wi = clampi(u - NS, 0, hs - KS), wj = clampi(v - NS, 0, ws - KS);   // window start of this query
     const size_t tok = (size_t)3 * heads * HD;                              // elements per token in qkv
 
-    for (int t = tid; t < 13 * 13; t += 256) bias[t] = rpb[(size_t)h * 169 + t];
+    for (int t = threadIdx.x; t < 13 * 13; t += 256) bias[t] = rpb[(size_t)h * 169 + t];
 
     auto load_tile = [&](int which) {                                       // which: 1 = K, 2 = V
         // one 16-byte piece per lane: HD*sizeof(T)/16 pieces per row
         constexpr int PIECES = HD * (int)sizeof(T) / 16, EPP = 16 / (int)sizeof(T);
-        for (int p = tid; p < nr * nc * PIECES; p += 256) {
+        if (!tile_in) return;
+        for (int p = tid; p < nr * nc * PIECES; p += NT) {
             const int row = p / PIECES, piece = p - row * PIECES;
             const int rr = row / nc, cc = row - rr * nc;
             const int y = gi + (r0 + rr) * dil, x = gj + (c0 + cc) * dil;
@@ -157,26 +166,32 @@ __global__ __launch_bounds__(256) void na2d_fwd_kernel(const T* __restrict__ qkv
     }
 }
 
-template __global__ void na2d_fwd_kernel<float>(const float*, const float*, float*, int, int, int, int, int, float);
-template __global__ void na2d_fwd_kernel<__hip_bfloat16>(const __hip_bfloat16*, const float*, __hip_bfloat16*, int, int, int,
-                                                         int, int, float);
+template <typename T, int TILE>
+static int launch_variant(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int dil, float scale,
+                          hipStream_t stream) {
+    constexpr int HALO = TILE + KS - 1, TPB = 256 / (TILE * TILE);
+    const int hs = (H + dil - 1) / dil, ws = (W + dil - 1) / dil;
+    const long long total = (long long)((hs + TILE - 1) / TILE) * ((ws + TILE - 1) / TILE) * B * dil * dil;
+    const dim3 grid((unsigned)((total + TPB - 1) / TPB), heads, 1);
+    const size_t lds = (size_t)TPB * HALO * HALO * Row<T>::STRIDE * sizeof(T) + 169 * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void*)na2d_fwd_kernel<T, TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((na2d_fwd_kernel<T, TILE>), grid, dim3(256), lds, stream, (const T*)qkv, rpb, (T*)out, B, H, W, heads, dil,
+                       scale, (int)total);
+    return (int)hipGetLastError();
+}
 
 int na2d_launch(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int dil, float scale,
                 int dtype, hipStream_t stream) {
     const int hs = (H + dil - 1) / dil, ws = (W + dil - 1) / dil;
-    const dim3 grid((unsigned)(((hs + TILE - 1) / TILE) * ((ws + TILE - 1) / TILE)) * (unsigned)(B * dil * dil), heads, 1);
-    if (dtype == 0) {
-        const size_t lds = (size_t)HALO * HALO * Row<float>::STRIDE * sizeof(float) + 169 * sizeof(float);
-        hipError_t e = hipFuncSetAttribute((const void*)na2d_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(na2d_fwd_kernel<float>, grid, dim3(256), lds, stream, (const float*)qkv, rpb, (float*)out, B, H, W,
-                           heads, dil, scale);
-    } else {
-        const size_t lds = (size_t)HALO * HALO * Row<__hip_bfloat16>::STRIDE * sizeof(__hip_bfloat16) + 169 * sizeof(float);
-        hipLaunchKernelGGL(na2d_fwd_kernel<__hip_bfloat16>, grid, dim3(256), lds, stream, (const __hip_bfloat16*)qkv, rpb,
-                           (__hip_bfloat16*)out, B, H, W, heads, dil, scale);
-    }
-    return (int)hipGetLastError();
+    // lane utilisation of the two tilings on this sub-image size
+    auto util = [&](int t) { return (double)(hs * ws) / ((double)((hs + t - 1) / t * t) * ((ws + t - 1) / t * t)); };
+    const bool small = util(8) > util(16) + 0.05;
+    if (dtype == 0)
+        return small ? launch_variant<float, 8>(qkv, rpb, out, B, H, W, heads, dil, scale, stream)
+                     : launch_variant<float, 16>(qkv, rpb, out, B, H, W, heads, dil, scale, stream);
+    return small ? launch_variant<__hip_bfloat16, 8>(qkv, rpb, out, B, H, W, heads, dil, scale, stream)
+                 : launch_variant<__hip_bfloat16, 16>(qkv, rpb, out, B, H, W, heads, dil, scale, stream);
 }
 
 }  // namespace ppn

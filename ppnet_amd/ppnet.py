@@ -10,25 +10,34 @@ from .segnet import SegNet, normalize_images
 
 
 class PPNet(torch.nn.Module):
-    def __init__(self, resolution=256, segnet=None, gennet=None, amp_dtype=torch.bfloat16):
+    def __init__(self, resolution=256, segnet=None, gennet=None, amp_dtype=None, weights_dtype=torch.bfloat16):
+        """weights_dtype=bfloat16 (default): both networks hold bf16 weights and activations (fp32 accumulation inside
+        the GEMM / conv / attention kernels, fp32 statistics inside LayerNorm); amp_dtype=bfloat16 with
+        weights_dtype=None keeps fp32 weights under autocast; both None = fp32 everywhere."""
         super().__init__()
         self.resolution = resolution
         self.segnet = segnet if segnet is not None else SegNet()
         self.gennet = gennet if gennet is not None else AEViT(1, 1, resolution, 24)      # predict.py:36,46
         self.amp_dtype = amp_dtype
+        self.weights_dtype = weights_dtype
+        if weights_dtype is not None:
+            self.segnet.to(weights_dtype)
+            self.gennet.to(weights_dtype)
 
     @torch.no_grad()
     def segment(self, grid_u8):
         """u8 occupancy codes [B,R,R] -> free-space class mask [B,R,R] int64 (SegNet argmax)."""
         rgb = edage.grid_to_rgb(grid_u8) * 255.0                             # the JPEG the reference would read back
         x = normalize_images(rgb)
+        if self.weights_dtype is not None:
+            x = x.to(self.weights_dtype)
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             return self.segnet(x)
 
     @torch.no_grad()
     def heatmap(self, mask):
         """class mask [B,R,R] -> 8-bit waypoint heat map [B,R,R] (GenNet + per-sample min-max, predict.py:88-102)."""
-        x = mask.to(torch.float32).unsqueeze(1)                              # my_dataset.py:15: values {0,1}
+        x = mask.to(self.weights_dtype or torch.float32).unsqueeze(1)        # my_dataset.py:15: values {0,1}
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             y = self.gennet(x)
         return normalize_heatmap_u8(y)

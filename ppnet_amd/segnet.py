@@ -99,6 +99,7 @@ class NAT(nn.Module):
                      mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, norm_layer=norm_layer,
                      layer_scale=layer_scale) for i in range(self.num_levels))
         self.out_indices = out_indices
+        self.compute_indices = tuple(out_indices)      # inference may narrow this to the levels the head reads
         for i in out_indices:
             self.add_module(f"norm{i}", norm_layer(self.num_features[i]))
         if isinstance(pretrained, str):
@@ -115,7 +116,7 @@ class NAT(nn.Module):
         outs = []
         for idx, level in enumerate(self.levels):
             x, xo = level(x)
-            if idx in self.out_indices:
+            if idx in self.compute_indices:
                 outs.append(getattr(self, f"norm{idx}")(xo).permute(0, 3, 1, 2).contiguous())
         return outs
 
@@ -189,6 +190,9 @@ class SegNet(nn.Module):
         self.backbone = DiNAT(**(backbone or DINAT_BASE["backbone"]))
         self.decode_head = SETRUPHead(**(decode_head or DINAT_BASE["decode_head"]))
         self.align_corners = self.decode_head.align_corners
+        if self.decode_head.in_index in (-1, self.backbone.num_levels - 1):
+            # SETR-UP reads only the last level: skip the per-level norm + NHWC->NCHW copies nobody consumes
+            self.backbone.compute_indices = (self.backbone.num_levels - 1,)
 
     def encode_decode(self, img):
         out = self.decode_head(self.backbone(img))
