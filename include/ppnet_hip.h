@@ -201,6 +201,14 @@ int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const 
 int ppn_na2d_fwd(const void* qkv, const float* rpb, void* out, int32_t B, int32_t H, int32_t W, int32_t heads,
                  int32_t dilation, float scale, int32_t dtype, void* stream);
 
+/* Fused residual + LayerScale + LayerNorm around the NAT layer's dense ops (SegNet/nat.py:140-153):
+ *   a == NULL : y_out = LayerNorm(x)                                   (x_out ignored)
+ *   a != NULL : x_out = x + gamma * a  (gamma NULL = 1);  y_out = LayerNorm(x_out) unless y_out is NULL.
+ * rows x C row-major, C a multiple of 8 with C/8 a power of two <= 64, or C = 1024; w, b, gamma are [C] in the
+ * same dtype (0 = float32, 1 = bfloat16; statistics in float32). x_out may alias x. */
+int ppn_residual_layernorm(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out,
+                           void* y_out, int64_t rows, int32_t C, float eps, int32_t dtype, void* stream);
+
 /* PIL.Image.resize(size, BILINEAR) for 8-bit single-channel images, bit-exact: Pillow's ImagingResample
  * (support = max(scale,1), 22-bit fixed-point coefficients, horizontal pass then vertical pass, each rounded
  * to 8 bits).  Used by extract_path's down-sampling (process_map.py:301).  in [n][H][W], tmp [n][H][outW],

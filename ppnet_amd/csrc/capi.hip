@@ -268,6 +268,19 @@ int ppn_na2d_fwd(const void* qkv, const float* rpb, void* out, int32_t B, int32_
     return PPN_OK;
 }
 
+int ppn_residual_layernorm(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out,
+                           void* y_out, int64_t rows, int32_t C, float eps, int32_t dtype, void* stream) {
+    if (!x || rows < 0 || C <= 0 || (C % 8) != 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
+    if (a && !x_out) return PPN_E_INVALID;
+    if (!a && !y_out) return PPN_E_INVALID;
+    if (y_out && (!w || !b)) return PPN_E_INVALID;
+    if (rows == 0) return PPN_OK;
+    const int e = ppn::norm_launch(x, a, gamma, w, b, x_out, y_out, rows, C, eps, dtype, (hipStream_t)stream);
+    if (e == -1) return PPN_E_UNSUPPORTED;
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_resize_bilinear_u8(const uint8_t* in, int32_t n, int32_t H, int32_t W, int32_t outH, int32_t outW, uint8_t* tmp,
                            uint8_t* out, void* stream) {
     if (!in || n < 0 || H <= 0 || W <= 0 || outH <= 0 || outW <= 0 || !tmp || !out) return PPN_E_INVALID;

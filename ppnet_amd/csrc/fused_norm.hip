@@ -1,0 +1,150 @@
+// fused_norm.hip — HBM-bound fusions around the NAT layer's dense ops on gfx950 (reference SegNet/nat.py:140-153):
+//
+//   layernorm_kernel      y = LN(x)                                   (norm1 of the first layer of a level, output norms)
+//   residual_ln_kernel    x' = x + gamma * a ;  y = LN(x')            (residual + LayerScale + the NEXT sub-layer's norm)
+//
+// The reference runs these as separate torch ops (mul, add, layer_norm = 7 tensor passes per sub-layer); fused they are
+// 4 (read x, read a, write x', write y).  A row of C channels (128..1024, every NAT/DiNAT level) is owned by C/8 lanes
+// (at most one wave), 8 elements per lane per pass = one 16-byte access for bf16; statistics in float32.
+#include <hip/hip_bf16.h>
+#include "ppn_device.h"
+#include "ppn_kernels.h"
+
+namespace ppn {
+
+namespace {
+
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct Vec8<__hip_bfloat16> {
+    static __device__ __forceinline__ void load(const __hip_bfloat16* p, float (&v)[8]) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p);
+        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+        v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+        v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ uint32_t pack(float lo, float hi) {     // round-to-nearest-even, finite inputs
+        uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
+        a = (a + 0x7fffu + ((a >> 16) & 1u)) >> 16;
+        b = (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u;
+        return a | b;
+    }
+    static __device__ __forceinline__ void store(__hip_bfloat16* p, const float (&v)[8]) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(pack(v[0], v[1]), pack(v[2], v[3]), pack(v[4], v[5]), pack(v[6], v[7]));
+    }
+};
+
+// sum over the `lpr` lanes that share a row (lpr a power of two <= 64, groups aligned)
+__device__ __forceinline__ float group_sum(float v, int lpr) {
+    for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace
+
+// PASSES = C / (8 * lpr): 1 for C <= 512, 2 for C = 1024.  RESID: fuse x' = x + gamma * a (gamma may be null = 1).
+template <typename T, int PASSES, bool RESID>
+__global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ gamma,
+                                                   const T* __restrict__ w, const T* __restrict__ b, T* __restrict__ x_out,
+                                                   T* __restrict__ y_out, long long rows, int C, int lpr, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int rows_per_wave = 64 / lpr;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long row = wave * rows_per_wave + lane / lpr;
+    const int li = lane % lpr;
+    const bool live = row < rows;                                            // dead lanes still join the shuffles
+    float v[PASSES][8];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int c0 = (p * lpr + li) * 8;
+        if (live) {
+            Vec8<T>::load(x + row * C + c0, v[p]);
+            if (RESID) {
+                float av[8];
+                Vec8<T>::load(a + row * C + c0, av);
+                if (gamma) {
+                    float gv[8];
+                    Vec8<T>::load(gamma + c0, gv);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[p][k] = fmaf(gv[k], av[k], v[p][k]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[p][k] += av[k];
+                }
+                Vec8<T>::store(x_out + row * C + c0, v[p]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[p][k] = 0.0f;
+        }
+    }
+    if (!y_out) return;                                                      // residual only (last sub-layer of a level)
+    if (RESID && sizeof(T) == 2) {
+        // LN sees what the next op would read back: the rounded residual stream
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                const uint32_t u = Vec8<__hip_bfloat16>::pack(v[p][k], v[p][k + 1]);
+                v[p][k] = __uint_as_float(u << 16); v[p][k + 1] = __uint_as_float(u & 0xffff0000u);
+            }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[p][k];
+    const float mean = group_sum(s, lpr) / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = v[p][k] - mean; q = fmaf(d, d, q); }
+    const float rstd = rsqrtf(group_sum(q, lpr) / (float)C + eps);
+    if (!live) return;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int c0 = (p * lpr + li) * 8;
+        float wv[8], bv[8], o[8];
+        Vec8<T>::load(w + c0, wv);
+        Vec8<T>::load(b + c0, bv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = fmaf((v[p][k] - mean) * rstd, wv[k], bv[k]);
+        Vec8<T>::store(y_out + row * C + c0, o);
+    }
+}
+
+template <typename T>
+static int launch_norm(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,
+                       long long rows, int C, float eps, hipStream_t stream) {
+    int lpr = C / 8, passes = 1;
+    if (lpr > 64) { passes = lpr / 64; lpr = 64; }
+    if (passes > 2 || (lpr & (lpr - 1)) != 0 || lpr * 8 * passes != C) return -1;
+    const long long rows_per_block = 4LL * (64 / lpr);
+    const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
+    const bool resid = a != nullptr;
+#define PPN_NORM_LAUNCH(P, R) hipLaunchKernelGGL((norm_kernel<T, P, R>), grid, dim3(256), 0, stream, (const T*)x, (const T*)a, \
+    (const T*)gamma, (const T*)w, (const T*)b, (T*)x_out, (T*)y_out, rows, C, lpr, eps)
+    if (passes == 1) { if (resid) PPN_NORM_LAUNCH(1, true); else PPN_NORM_LAUNCH(1, false); }
+    else { if (resid) PPN_NORM_LAUNCH(2, true); else PPN_NORM_LAUNCH(2, false); }
+#undef PPN_NORM_LAUNCH
+    return (int)hipGetLastError();
+}
+
+int norm_launch(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,
+                long long rows, int C, float eps, int dtype, hipStream_t stream) {
+    return dtype == 0 ? launch_norm<float>(x, a, gamma, w, b, x_out, y_out, rows, C, eps, stream)
+                      : launch_norm<__hip_bfloat16>(x, a, gamma, w, b, x_out, y_out, rows, C, eps, stream);
+}
+
+}  // namespace ppn

@@ -58,4 +58,7 @@ __global__ void philox_doubles_kernel(uint64_t seed, uint32_t stream_id, uint64_
 int na2d_launch(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int dil, float scale,
                 int dtype, hipStream_t stream);
 
+int norm_launch(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,
+                long long rows, int C, float eps, int dtype, hipStream_t stream);
+
 }  // namespace ppn

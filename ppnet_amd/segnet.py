@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused
 from .na import NeighborhoodAttention2D
 
 
@@ -61,11 +62,14 @@ class NATLayer(nn.Module):
             self.gamma1 = nn.Parameter(layer_scale * torch.ones(dim))
             self.gamma2 = nn.Parameter(layer_scale * torch.ones(dim))
 
-    def forward(self, x):                      # DropPath is the identity at inference (nat.py:140-153)
-        a = self.attn(self.norm1(x))
-        x = x + (self.gamma1 * a if self.layer_scale else a)
-        m = self.mlp(self.norm2(x))
-        return x + (self.gamma2 * m if self.layer_scale else m)
+    def forward(self, x, y=None, next_norm=None):
+        """x: residual stream [B,H,W,C]; y = norm1(x) if the caller already has it. Returns (x', next_norm(x')).
+        Residual add, LayerScale and the following LayerNorm are one fused kernel each (DropPath is the identity
+        at inference, nat.py:140-153)."""
+        if y is None:
+            y = fused.layer_norm(x, self.norm1)
+        x, y2 = fused.residual_layer_norm(x, self.attn(y), self.gamma1 if self.layer_scale else None, self.norm2)
+        return fused.residual_layer_norm(x, self.mlp(y2), self.gamma2 if self.layer_scale else None, next_norm)
 
 
 class NATBlock(nn.Module):
@@ -77,10 +81,16 @@ class NATBlock(nn.Module):
                      qk_scale, norm_layer=norm_layer, layer_scale=layer_scale) for i in range(depth))
         self.downsample = ConvDownsampler(dim, norm_layer) if downsample else None
 
-    def forward(self, x):
-        for blk in self.blocks:
-            x = blk(x)
-        return (x, x) if self.downsample is None else (self.downsample(x), x)
+    def forward(self, x, out_norm=None):
+        """Returns (next level's input, out_norm(x) or x): the level's output norm rides on the last fused kernel."""
+        x = x.clone()                                  # the fused kernels update the residual stream in place
+        y = None
+        n = len(self.blocks)
+        for i, blk in enumerate(self.blocks):
+            nxt = self.blocks[i + 1].norm1 if i + 1 < n else out_norm
+            x, y = blk(x, y, nxt)
+        xo = y if out_norm is not None else x
+        return (x, xo) if self.downsample is None else (self.downsample(x), xo)
 
 
 class NAT(nn.Module):
@@ -115,9 +125,10 @@ class NAT(nn.Module):
         x = self.patch_embed(x)
         outs = []
         for idx, level in enumerate(self.levels):
-            x, xo = level(x)
-            if idx in self.compute_indices:
-                outs.append(getattr(self, f"norm{idx}")(xo).permute(0, 3, 1, 2).contiguous())
+            want = idx in self.compute_indices
+            x, xo = level(x, getattr(self, f"norm{idx}") if want else None)
+            if want:
+                outs.append(xo.permute(0, 3, 1, 2).contiguous())
         return outs
 
 

@@ -28,9 +28,37 @@ def test_dinat_base_checkpoint_layout():
     assert 85e6 < n < 95e6                                                # DiNAT-Base ~ 90 M parameters
 
 
+def _reference_nat_forward(m, x):
+    """float64 CPU evaluation of a ppnet_amd.segnet.NAT's weights, written out op by op from SegNet/nat.py:41-59,
+    140-153,204-209,316-324 with the definition oracle as the attention (test-side reference; the product module
+    itself is GPU-only)."""
+    import torch.nn.functional as F
+    from oracle import na_np as NA
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    ln = lambda t, p: F.layer_norm(t, (t.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+    x = F.conv2d(F.conv2d(x, sd["patch_embed.proj.0.weight"], sd["patch_embed.proj.0.bias"], 2, 1),
+                 sd["patch_embed.proj.1.weight"], sd["patch_embed.proj.1.bias"], 2, 1).permute(0, 2, 3, 1)
+    x = ln(x, "patch_embed.norm")
+    outs = []
+    for li, lvl in enumerate(m.levels):
+        for bi, blk in enumerate(lvl.blocks):
+            p = f"levels.{li}.blocks.{bi}"
+            a = NA.neighborhood_attention_2d(ln(x, p + ".norm1").numpy(), sd[p + ".attn.qkv.weight"].numpy(),
+                                             sd[p + ".attn.qkv.bias"].numpy(), sd[p + ".attn.rpb"].numpy(),
+                                             sd[p + ".attn.proj.weight"].numpy(), sd[p + ".attn.proj.bias"].numpy(),
+                                             blk.attn.num_heads, 7, blk.attn.dilation)
+            x = x + sd[p + ".gamma1"] * torch.tensor(a)
+            h = F.gelu(F.linear(ln(x, p + ".norm2"), sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"]))
+            x = x + sd[p + ".gamma2"] * F.linear(h, sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
+        outs.append(ln(x, f"norm{li}").permute(0, 3, 1, 2).numpy())
+        if lvl.downsample is not None:
+            x = ln(F.conv2d(x.permute(0, 3, 1, 2), sd[f"levels.{li}.downsample.reduction.weight"], None, 2, 1).permute(0, 2, 3, 1),
+                   f"levels.{li}.downsample.norm")
+    return outs
+
+
 @pytest.mark.gpu
 def test_small_nat_gpu_vs_oracle_composition():
-    from oracle import na_np as NA
     from ppnet_amd.segnet import NAT
     assert torch.cuda.is_available()
     torch.manual_seed(0)
@@ -38,25 +66,35 @@ def test_small_nat_gpu_vs_oracle_composition():
                dilations=[[1, 2], [1, 1]], layer_scale=0.5, out_indices=(0, 1))
     m = NAT(**cfg).eval()
     x = torch.randn(2, 3, 64, 64)
+    want = _reference_nat_forward(m, x.double())
     with torch.no_grad():
         got = [o.cpu().double().numpy() for o in m.cuda()(x.cuda())]
-    # float64 CPU evaluation of the same weights with the oracle attention
-    m = m.cpu().double()
-
-    def oracle_attn(mod):
-        def f(t):
-            sd = {k: v.detach().numpy() for k, v in mod.state_dict().items()}
-            return torch.tensor(NA.neighborhood_attention_2d(t.numpy(), sd["qkv.weight"], sd["qkv.bias"], sd["rpb"],
-                                                             sd["proj.weight"], sd["proj.bias"], mod.num_heads, 7, mod.dilation))
-        return f
-    for lvl in m.levels:
-        for blk in lvl.blocks:
-            blk.attn.forward = oracle_attn(blk.attn)
-    with torch.no_grad():
-        want = [o.numpy() for o in m(x.double())]
     assert [g.shape for g in got] == [(2, 64, 16, 16), (2, 128, 8, 8)]
     for g, w in zip(got, want):
         assert np.abs(g - w).max() < 2e-3                                  # float32 GPU vs float64 reference
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,dtype", [(128, "float32"), (256, "bfloat16"), (512, "bfloat16"), (1024, "bfloat16"), (64, "float32")])
+def test_fused_residual_layernorm_vs_torch(C, dtype):
+    from ppnet_amd import fused
+    dt = getattr(torch, dtype)
+    torch.manual_seed(1)
+    ln = torch.nn.LayerNorm(C, eps=1e-5).cuda().to(dt)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(3, 7, 5, C, device="cuda", dtype=dt)
+    a = torch.randn(3, 7, 5, C, device="cuda", dtype=dt)
+    g = (torch.rand(C, device="cuda") * 2).to(dt)
+    tol = 1e-5 if dt == torch.float32 else 4e-2
+    y = fused.layer_norm(x, ln)
+    assert (y.float() - torch.nn.functional.layer_norm(x.float(), (C,), ln.weight.float(), ln.bias.float(), 1e-5)).abs().max() < tol
+    want_x = x.float() + g.float() * a.float()
+    x2, y2 = fused.residual_layer_norm(x.clone(), a, g, ln)
+    assert (x2.float() - want_x).abs().max() < tol
+    assert (y2.float() - torch.nn.functional.layer_norm(x2.float(), (C,), ln.weight.float(), ln.bias.float(), 1e-5)).abs().max() < tol
+    x3, y3 = fused.residual_layer_norm(x.clone(), a, None, None)
+    assert y3 is None and (x3.float() - (x.float() + a.float())).abs().max() < tol
 
 
 @pytest.mark.gpu
@@ -65,10 +103,11 @@ def test_dinat_base_end_to_end_256():
     torch.manual_seed(0)
     m = SegNet().cuda().eval()
     img = torch.randint(0, 256, (2, 256, 256, 3), dtype=torch.uint8, device="cuda")
+    import copy
+    m16 = copy.deepcopy(m).to(torch.bfloat16)                   # what PPNet runs: bf16 weights and activations
     with torch.no_grad():
         pred, logits = m(normalize_images(img), return_logits=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            pred16, logits16 = m(normalize_images(img), return_logits=True)
+        pred16, logits16 = m16(normalize_images(img).to(torch.bfloat16), return_logits=True)
     assert pred.shape == (2, 256, 256) and pred.dtype == torch.int64 and logits.shape == (2, 2, 256, 256)
     assert set(torch.unique(pred).tolist()) <= {0, 1}
     assert torch.isfinite(logits).all()
