@@ -105,13 +105,23 @@ __global__ __launch_bounds__(256) void na2d_fwd_kernel(const T* __restrict__ qkv
         }
     };
 
-    float q[HD];
+    constexpr bool BF16 = sizeof(T) == 2;
+    float q[BF16 ? 1 : HD];
+    uint32_t qp[BF16 ? HD / 2 : 1];                                         // bf16: q stays packed, two channels per register
     if (valid) {
         const int y = gi + u * dil, x = gj + v * dil;
         const T* src = qkv + ((size_t)(b * H + y) * W + x) * tok + (size_t)h * HD;
-        load_row(src, q);
+        if constexpr (BF16) {
 #pragma unroll
-        for (int c = 0; c < HD; ++c) q[c] = q[c] * scale;                   // q = q * scale before QK (NATTEN module)
+            for (int p4 = 0; p4 < HD / 8; ++p4) {
+                const uint4 w4 = *reinterpret_cast<const uint4*>(src + 8 * p4);
+                qp[4 * p4] = w4.x; qp[4 * p4 + 1] = w4.y; qp[4 * p4 + 2] = w4.z; qp[4 * p4 + 3] = w4.w;
+            }
+        } else {
+            load_row(src, q);
+#pragma unroll
+            for (int c = 0; c < HD; ++c) q[c] = q[c] * scale;               // q = q * scale before QK (NATTEN module)
+        }
     }
     load_tile(1);
     __syncthreads();
@@ -124,11 +134,27 @@ __global__ __launch_bounds__(256) void na2d_fwd_kernel(const T* __restrict__ qkv
         for (int ki = 0; ki < KS; ++ki) {
 #pragma unroll
             for (int kj = 0; kj < KS; ++kj) {
-                float kr[HD];
-                load_row(tile + (size_t)((wi - r0 + ki) * HALO + (wj - c0 + kj)) * STRIDE, kr);
+                const T* krow = tile + (size_t)((wi - r0 + ki) * HALO + (wj - c0 + kj)) * STRIDE;
                 float acc = 0.0f;
+                if constexpr (BF16) {
+                    // v_dot2c_f32_bf16: two channels per instruction, float32 accumulate; the bf16 q cannot carry the
+                    // scale without another rounding, so the scale multiplies the finished dot product instead
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
 #pragma unroll
-                for (int c = 0; c < HD; ++c) acc = fmaf(q[c], kr[c], acc);
+                    for (int p4 = 0; p4 < HD / 8; ++p4) {
+                        const uint4 w4 = *reinterpret_cast<const uint4*>(krow + 8 * p4);
+                        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, qp[4 * p4]), __builtin_bit_cast(bf2, w4.x), acc, false);
+                        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, qp[4 * p4 + 1]), __builtin_bit_cast(bf2, w4.y), acc, false);
+                        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, qp[4 * p4 + 2]), __builtin_bit_cast(bf2, w4.z), acc, false);
+                        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, qp[4 * p4 + 3]), __builtin_bit_cast(bf2, w4.w), acc, false);
+                    }
+                    acc *= scale;
+                } else {
+                    float kr[HD];
+                    load_row(krow, kr);
+#pragma unroll
+                    for (int c = 0; c < HD; ++c) acc = fmaf(q[c], kr[c], acc);
+                }
                 acc += bias[(pbi + ki) * 13 + pbj + kj];
                 logit[ki * KS + kj] = acc;
                 mx = fmaxf(mx, acc);
