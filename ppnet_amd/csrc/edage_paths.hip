@@ -17,11 +17,29 @@
 #include "ppn_device.h"
 #include "ppn_kernels.h"
 
+#ifdef PPN_PHASE_TIMING
+__device__ unsigned long long g_paths_phase_cycles[16];
+#define PPN_PSTAMP(idx) do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        atomicAdd(&g_paths_phase_cycles[idx], t_ - tp_prev_); tp_prev_ = t_; } } while (0)
+#define PPN_PSTAMP_INIT unsigned long long tp_prev_ = __builtin_amdgcn_s_memtime()
+extern "C" int ppn_debug_paths_phase_cycles(unsigned long long* out_host, int reset) {
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_paths_phase_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_paths_phase_cycles), z, sizeof(z)) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#else
+#define PPN_PSTAMP(idx) do {} while (0)
+#define PPN_PSTAMP_INIT do {} while (0)
+#endif
+
 namespace ppn {
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = PPN_PATHS_THREADS;      // 1024: one path per workgroup, 4 waves per SIMD to hide the serial chains' latency
 constexpr int NW = NT / 64;
 
 struct SegLds {
@@ -69,11 +87,10 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
     __shared__ int lat[PPN_PATH_POINTS][2];       // integer lattice (hull input)
     __shared__ double hull[PPN_MAX_HULL][2];
     __shared__ int hull_i[PPN_MAX_HULL][2];
-    __shared__ double fit_part[PPN_SEGS][4][NW];
+    __shared__ double fit_part[PPN_SEGS][4];
     __shared__ double red_v[NW];
     __shared__ int red_i[NW];
     __shared__ double bc[16];                     // broadcast scalars
-    __shared__ int bci[8];
 
     const int p = blockIdx.x;
     const int tid = threadIdx.x;
@@ -87,6 +104,7 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
     const double step_c2i = prm.map_size / (double)R;            // Path.py:380
     const double Rd = (double)R;
     uint32_t flags = 0;
+    PPN_PSTAMP_INIT;
 
     // zero the canvas
     const int canvas_words = (2 * R) * (2 * R) / 32;
@@ -96,10 +114,12 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
     const double d0 = fed ? fed[0] : philox_double(prm.seed, STREAM_PATH, pid, 0);
     const int forced = prm.force_straight ? (int)prm.force_straight[p] : -1;
     const bool path_straight = forced >= 0 ? (forced != 0) : !(d0 > 0.01);    // PathGenerate.py:36 / Path.py:53
-    for (int s = 0; s < PPN_SEGS; ++s) {
+    static_assert(NW >= PPN_SEGS, "one wave per segment");
+    if (wv < PPN_SEGS) {                                         // wave s fits segment s: no cross-wave reduction
+        const int s = wv;
         const uint32_t base = 1u + (uint32_t)s * PPN_DRAWS_PER_SEG + 1u;   // first sample draw (even)
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        for (int q = tid; q < 500; q += NT) {
+        for (int q = lane; q < 500; q += 64) {
             double u0, u1;
             if (fed) { u0 = fed[base + 2 * q]; u1 = fed[base + 2 * q + 1]; }
             else philox_double2(prm.seed, STREAM_PATH, pid, (base >> 1) + (uint32_t)q, u0, u1);
@@ -111,10 +131,7 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
             a3 += prm.W[3 * 1000 + i0] * y0; a3 += prm.W[3 * 1000 + i1] * y1;
         }
         a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-        if (lane == 0) {
-            fit_part[s][0][wv] = a0; fit_part[s][1][wv] = a1;
-            fit_part[s][2][wv] = a2; fit_part[s][3][wv] = a3;
-        }
+        if (lane == 0) { fit_part[s][0] = a0; fit_part[s][1] = a1; fit_part[s][2] = a2; fit_part[s][3] = a3; }
     }
     __syncthreads();
     if (tid < PPN_SEGS) {
@@ -124,11 +141,7 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
         const double ue = fed ? fed[b + 1001] : philox_double(prm.seed, STREAM_PATH, pid, b + 1001);
         const bool st = path_straight || (uf < 0.2);             // PathSeg.py:19
         double poly[5];
-        for (int k = 0; k < 4; ++k) {
-            double v = 0.0;
-            for (int w = 0; w < NW; ++w) v += fit_part[s][k][w];
-            poly[k] = v;
-        }
+        for (int k = 0; k < 4; ++k) poly[k] = fit_part[s][k];
         poly[4] = 0.0;                                           // PathSeg.py:28
         if (st) { poly[0] = 0.0; poly[1] = 0.0; poly[2] = 0.0; } // PathSeg.py:29-31
         const double E = ue * 7.0 + 0.0;                         // PathSeg.py:32
@@ -154,6 +167,7 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
     }
     __syncthreads();
 
+    PPN_PSTAMP(0);
     // ------------------------------------------------------------------ A2: chaining (serial, tiny)
     if (tid == 0) {
         double a = 0.0;
@@ -195,6 +209,7 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
         O.segpoint_world[((size_t)p * 11 + tid) * 2 + 1] = S.segpoint[tid][1];
     }
 
+    PPN_PSTAMP(1);
     // path points (Path.plot, Path.py:256-260): 100 samples per segment
     for (int q = tid; q < PPN_PATH_POINTS; q += NT) {
         const int s = q / 100, j = q - s * 100;
@@ -207,8 +222,10 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
         pp[q][0] = rx; pp[q][1] = ry;
         O.pathpoint_world[((size_t)p * PPN_PATH_POINTS + q) * 2] = rx;
         O.pathpoint_world[((size_t)p * PPN_PATH_POINTS + q) * 2 + 1] = ry;
-        lat[q][0] = (int)rint(rx / step_c2i + Rd);               // convexhull input, Path.py:390
-        lat[q][1] = (int)rint(ry / step_c2i + Rd);
+        // convexhull input, Path.py:390; clamped to +-16383 so the hull walk's products are exact in 32 bits
+        // (a path that far outside the 2R canvas is not a valid instance: flagged below)
+        lat[q][0] = max(-16383, min(16383, (int)rint(rx / step_c2i + Rd)));
+        lat[q][1] = max(-16383, min(16383, (int)rint(ry / step_c2i + Rd)));
     }
     __syncthreads();
     {
@@ -230,6 +247,7 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
     }
     const double Ex = S.segpoint[PPN_SEGS][0], Ey = S.segpoint[PPN_SEGS][1];
 
+    PPN_PSTAMP(2);
     // ------------------------------------------------------------------ A3 + A4: boundary rays -> canvas
     {
         const int n_steps = (int)rint(0.8 * clearance / step_len);      // Path.py:119,398
@@ -295,85 +313,82 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
     if (O.canvas_bits)
         for (int w = tid; w < canvas_words; w += NT) O.canvas_bits[(size_t)p * canvas_words + w] = canvas[w];
 
+    PPN_PSTAMP(3);
     // ------------------------------------------------------------------ A5: exact integer hull (gift wrapping)
-    int hn = 0;
-    {
-        // start = lexicographically smallest lattice point
-        long long key = 0x7fffffffffffffffLL;
-        for (int q = tid; q < PPN_PATH_POINTS; q += NT) {
-            const long long k = ((long long)(lat[q][0] + 1048576) << 32) | (long long)(lat[q][1] + 1048576);
-            key = k < key ? k : key;
-        }
+    // One wave walks the hull (gift wrapping, exact integer tests): each lane keeps 16 lattice points in
+    // registers and proposes its own best successor; the wave then refines a candidate with ballots —
+    // "is anyone's proposal to the right of cur->cand (or collinear and farther)?" — and a readlane, a few
+    // rounds per vertex, with no barrier and no LDS traffic inside the walk.
+    __shared__ int hull_meta[2];                                 // hn, flags
+    if (wv == 0) {
+        constexpr int PPL = (PPN_PATH_POINTS + 63) / 64;         // points per lane
+        int px[PPL], py[PPL];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const long long t = __shfl_xor(key, o, 64); key = t < key ? t : key; }
-        __syncthreads();
-        if (lane == 0) { red_i[wv] = (int)(key >> 32); bci[4 + wv] = (int)(key & 0xffffffffLL); }
-        __syncthreads();
-        long long best = 0x7fffffffffffffffLL;
-        for (int w = 0; w < NW; ++w) {
-            const long long k = ((long long)red_i[w] << 32) | (long long)(uint32_t)bci[4 + w];
-            best = k < best ? k : best;
+        for (int k = 0; k < PPL; ++k) {
+            const int q = min(lane + 64 * k, PPN_PATH_POINTS - 1);   // tail lanes repeat the last point (harmless duplicate)
+            px[k] = lat[q][0]; py[k] = lat[q][1];
         }
-        const int sx0 = (int)(best >> 32) - 1048576, sy0 = (int)(best & 0xffffffffLL) - 1048576;
-        int cx = sx0, cy = sy0;
-        __syncthreads();
+        // start = lexicographically smallest lattice point
+        int sx0 = px[0], sy0 = py[0];
+#pragma unroll
+        for (int k = 1; k < PPL; ++k) if (px[k] < sx0 || (px[k] == sx0 && py[k] < sy0)) { sx0 = px[k]; sy0 = py[k]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ox = __shfl_xor(sx0, o, 64), oy = __shfl_xor(sy0, o, 64);
+            if (ox < sx0 || (ox == sx0 && oy < sy0)) { sx0 = ox; sy0 = oy; }
+        }
+        int cx = sx0, cy = sy0, n = 0;
+        uint32_t hflags = 0;
         while (true) {
-            if (tid == 0) { hull_i[hn][0] = cx; hull_i[hn][1] = cy; }
-            ++hn;
-            // candidate: the point with every other point on or to the left of cur -> cand
+            if (lane == 0) { hull_i[n][0] = cx; hull_i[n][1] = cy; }
+            ++n;
+            // this lane's proposal: the point with all its other points on or to the left of cur -> proposal
             int bx = 0, by = 0, have = 0;
-            for (int q = tid; q < PPN_PATH_POINTS; q += NT) {
-                const int rx = lat[q][0], ry = lat[q][1];
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+                const int rx = px[k], ry = py[k];
                 if (rx == cx && ry == cy) continue;
                 if (!have) { bx = rx; by = ry; have = 1; continue; }
-                const long long cr = (long long)(bx - cx) * (ry - cy) - (long long)(by - cy) * (rx - cx);
+                const int cr = __mul24(bx - cx, ry - cy) - __mul24(by - cy, rx - cx);
                 if (cr < 0) { bx = rx; by = ry; }
                 else if (cr == 0) {
-                    const long long db = (long long)(bx - cx) * (bx - cx) + (long long)(by - cy) * (by - cy);
-                    const long long dr = (long long)(rx - cx) * (rx - cx) + (long long)(ry - cy) * (ry - cy);
+                    const int db = __mul24(bx - cx, bx - cx) + __mul24(by - cy, by - cy);
+                    const int dr = __mul24(rx - cx, rx - cx) + __mul24(ry - cy, ry - cy);
                     if (dr > db) { bx = rx; by = ry; }
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const int ox = __shfl_xor(bx, o, 64), oy = __shfl_xor(by, o, 64), oh = __shfl_xor(have, o, 64);
-                if (oh) {
-                    if (!have) { bx = ox; by = oy; have = 1; }
-                    else {
-                        const long long cr = (long long)(bx - cx) * (oy - cy) - (long long)(by - cy) * (ox - cx);
-                        if (cr < 0) { bx = ox; by = oy; }
-                        else if (cr == 0) {
-                            const long long db = (long long)(bx - cx) * (bx - cx) + (long long)(by - cy) * (by - cy);
-                            const long long dr = (long long)(ox - cx) * (ox - cx) + (long long)(oy - cy) * (oy - cy);
-                            if (dr > db) { bx = ox; by = oy; }
-                        }
+            const unsigned long long hv = __ballot(have);
+            if (!hv) break;                                      // every point coincides with cur
+            int l0 = __ffsll((long long)hv) - 1;
+            int kx = __builtin_amdgcn_readlane(bx, l0), ky = __builtin_amdgcn_readlane(by, l0);
+            while (true) {
+                bool better = false;
+                if (have) {
+                    const int cr = __mul24(kx - cx, by - cy) - __mul24(ky - cy, bx - cx);
+                    if (cr < 0) better = true;
+                    else if (cr == 0) {
+                        const int dk = __mul24(kx - cx, kx - cx) + __mul24(ky - cy, ky - cy);
+                        const int dm = __mul24(bx - cx, bx - cx) + __mul24(by - cy, by - cy);
+                        better = dm > dk;
                     }
                 }
+                const unsigned long long m = __ballot(better);
+                if (!m) break;
+                l0 = __ffsll((long long)m) - 1;
+                kx = __builtin_amdgcn_readlane(bx, l0); ky = __builtin_amdgcn_readlane(by, l0);
             }
-            __syncthreads();
-            if (lane == 0) { red_i[wv] = have; bci[wv] = bx; bci[4 + wv] = by; }
-            __syncthreads();
-            int fx = 0, fy = 0, fh = 0;
-            for (int w = 0; w < NW; ++w) {
-                if (!red_i[w]) continue;
-                const int ox = bci[w], oy = bci[4 + w];
-                if (!fh) { fx = ox; fy = oy; fh = 1; continue; }
-                const long long cr = (long long)(fx - cx) * (oy - cy) - (long long)(fy - cy) * (ox - cx);
-                if (cr < 0) { fx = ox; fy = oy; }
-                else if (cr == 0) {
-                    const long long db = (long long)(fx - cx) * (fx - cx) + (long long)(fy - cy) * (fy - cy);
-                    const long long dr = (long long)(ox - cx) * (ox - cx) + (long long)(oy - cy) * (oy - cy);
-                    if (dr > db) { fx = ox; fy = oy; }
-                }
-            }
-            __syncthreads();
-            if (!fh || (fx == sx0 && fy == sy0)) break;
-            if (hn >= PPN_MAX_HULL) { flags |= PPN_FLAG_HULL_CAP; break; }
-            cx = fx; cy = fy;
+            if (kx == sx0 && ky == sy0) break;
+            if (n >= PPN_MAX_HULL) { hflags |= PPN_FLAG_HULL_CAP; break; }
+            cx = kx; cy = ky;
         }
+        if (lane == 0) { hull_meta[0] = n; hull_meta[1] = (int)hflags; }
     }
     __syncthreads();
+    const int hn = hull_meta[0];
+    flags |= (uint32_t)hull_meta[1];
+    __syncthreads();
 
+    PPN_PSTAMP(4);
     // ------------------------------------------------------------------ A6: normalisation
     if (tid == 0) {
         const double rotation = atan(Ey / Ex) / 3.141592653589793 * 180.0 + (-135.0);   // Path.py:159
@@ -423,6 +438,7 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
         O.pathpoint_image[((size_t)p * PPN_PATH_POINTS + q) * 2 + 1] = ry;
     }
 
+    PPN_PSTAMP(5);
     // corridor mask Path.Space: rotate (nearest, about the canvas centre) then translate + crop,
     // composed per output pixel; 32 pixels (one mask word) per thread iteration
     {
@@ -450,6 +466,7 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
     }
     __syncthreads();
 
+    PPN_PSTAMP(6);
     // ------------------------------------------------------------------ A7: search_isle
     __shared__ int isles[PPN_MAX_ISLES][2];
     int n_isles = 0;
@@ -498,6 +515,7 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
         O.isles[((size_t)p * PPN_MAX_ISLES + tid) * 2 + 1] = tid < n_isles ? isles[tid][1] : 0;
     }
 
+    PPN_PSTAMP(7);
     // ------------------------------------------------------------------ A8: set_obstacles
     int n_obs = 0, n_pocket_draws = 0;
     {
@@ -583,6 +601,7 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
         }
         n_pocket_draws = (int)fdraw;
     }
+    PPN_PSTAMP(8);
     if (tid == 0) {
         O.n_isles[p] = n_isles;
         O.n_obstacles[p] = n_obs;

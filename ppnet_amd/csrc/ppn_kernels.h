@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include "../../include/ppnet_hip.h"
 
+#define PPN_PATHS_THREADS 1024
+
 namespace ppn {
 
 struct PathsParams {
