@@ -60,13 +60,16 @@ __device__ __forceinline__ void load_row(const __hip_bfloat16* row, float (&r)[H
 template <typename T, int TILE>
 __global__ __launch_bounds__(256) void na2d_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ rpb,
                                                        T* __restrict__ out, int B, int H, int W, int heads, int dil,
-                                                       float scale, int total_tiles) {
+                                                       float scale, int total_tiles, int halo_r, int halo_c) {
     constexpr int STRIDE = Row<T>::STRIDE;
-    constexpr int HALO = TILE + KS - 1, NT = TILE * TILE, TPB = 256 / NT;    // tiles per workgroup
+    constexpr int NT = TILE * TILE, TPB = 256 / NT;                          // tiles per workgroup
+    // halo_r x halo_c = min(TILE + KS - 1, sub-image extent): the LDS footprint (and so the occupancy) follows the
+    // sub-image — DiNAT's padded dilated layers have 7x7 groups, 49 rows per tile instead of 196
+    const int HALO = halo_c;                                                  // row pitch of the staged tile
     extern __shared__ unsigned char na_lds[];
     const int sub = threadIdx.x / NT;                                        // which tile of this workgroup
-    T* tile = reinterpret_cast<T*>(na_lds) + (size_t)sub * HALO * HALO * STRIDE;     // [HALO*HALO][STRIDE] per tile
-    float* bias = reinterpret_cast<float*>(na_lds + (size_t)TPB * HALO * HALO * STRIDE * sizeof(T));   // [13][13]
+    T* tile = reinterpret_cast<T*>(na_lds) + (size_t)sub * halo_r * halo_c * STRIDE;
+    float* bias = reinterpret_cast<float*>(na_lds + ((((size_t)TPB * halo_r * halo_c * STRIDE * sizeof(T)) + 15) & ~(size_t)15));   // [13][13]
 
     const int tid = threadIdx.x % NT, ty = tid / TILE, tx = tid % TILE;
     const int h = blockIdx.y;
@@ -199,11 +202,12 @@ static int launch_variant(const void* qkv, const float* rpb, void* out, int B, i
     const int hs = (H + dil - 1) / dil, ws = (W + dil - 1) / dil;
     const long long total = (long long)((hs + TILE - 1) / TILE) * ((ws + TILE - 1) / TILE) * B * dil * dil;
     const dim3 grid((unsigned)((total + TPB - 1) / TPB), heads, 1);
-    const size_t lds = (size_t)TPB * HALO * HALO * Row<T>::STRIDE * sizeof(T) + 169 * sizeof(float);
+    const int halo_r = hs < HALO ? hs : HALO, halo_c = ws < HALO ? ws : HALO;
+    const size_t lds = (((size_t)TPB * halo_r * halo_c * Row<T>::STRIDE * sizeof(T) + 15) & ~(size_t)15) + 169 * sizeof(float);
     hipError_t e = hipFuncSetAttribute((const void*)na2d_fwd_kernel<T, TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((na2d_fwd_kernel<T, TILE>), grid, dim3(256), lds, stream, (const T*)qkv, rpb, (T*)out, B, H, W, heads, dil,
-                       scale, (int)total);
+                       scale, (int)total, halo_r, halo_c);
     return (int)hipGetLastError();
 }
 

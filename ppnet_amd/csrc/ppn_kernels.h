@@ -4,7 +4,9 @@
 #include <stdint.h>
 #include "../../include/ppnet_hip.h"
 
-#define PPN_PATHS_THREADS 1024
+#ifndef PPN_PATHS_THREADS
+#define PPN_PATHS_THREADS 512
+#endif
 
 namespace ppn {
 

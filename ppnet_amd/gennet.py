@@ -68,6 +68,21 @@ class AEViT(nn.Module):
         self.dec_conv = nn.ModuleList(_stage(nn.ConvTranspose2d(dim, dim, 3, 2, 1, output_padding=1)) for _ in range(n_down))
         self.conv_final = nn.Conv2d(dim, out_channels, 3, 1, 1)
 
+    def prepare_inference(self):
+        """After the checkpoint is loaded: fold every eval-mode BatchNorm into the (transposed) convolution in front of
+        it (exact algebra in float32) and switch the convolution weights to channels_last. Load the state dict first."""
+        for stage in [self.conv_first, *self.enc_conv, *self.dec_conv]:
+            conv, bn = stage[0], stage[1]
+            if not isinstance(bn, nn.BatchNorm2d):
+                continue
+            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
+            shape = (1, -1, 1, 1) if isinstance(conv, nn.ConvTranspose2d) else (-1, 1, 1, 1)     # out-channel axis
+            conv.weight = nn.Parameter(conv.weight.detach() * scale.view(shape))
+            conv.bias = nn.Parameter(((conv.bias.detach() if conv.bias is not None else 0) - bn.running_mean) * scale + bn.bias.detach())
+            stage[1] = nn.Identity()
+        self.to(memory_format=torch.channels_last)
+        return self
+
     def forward(self, x):
         x = self.conv_first(x)
         for blk in self.enc_conv:

@@ -20,6 +20,8 @@ class PPNet(torch.nn.Module):
         self.gennet = gennet if gennet is not None else AEViT(1, 1, resolution, 24)      # predict.py:36,46
         self.amp_dtype = amp_dtype
         self.weights_dtype = weights_dtype
+        self.segnet.prepare_inference()          # BN folded into convs (float32), channels_last weights
+        self.gennet.prepare_inference()
         if weights_dtype is not None:
             self.segnet.to(weights_dtype)
             self.gennet.to(weights_dtype)

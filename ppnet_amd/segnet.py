@@ -23,8 +23,9 @@ class ConvTokenizer(nn.Module):
         self.norm = norm_layer(embed_dim) if norm_layer is not None else None
 
     def forward(self, x):
-        x = self.proj(x).permute(0, 2, 3, 1)
-        return self.norm(x) if self.norm is not None else x
+        # channels_last in, channels_last out: the NHWC token tensor is a zero-copy view of the conv output
+        x = self.proj(x.contiguous(memory_format=torch.channels_last)).permute(0, 2, 3, 1)
+        return fused.layer_norm(x, self.norm) if self.norm is not None else x
 
 
 class ConvDownsampler(nn.Module):
@@ -33,8 +34,8 @@ class ConvDownsampler(nn.Module):
         self.reduction = nn.Conv2d(dim, 2 * dim, 3, 2, 1, bias=False)
         self.norm = norm_layer(2 * dim)
 
-    def forward(self, x):
-        return self.norm(self.reduction(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1))
+    def forward(self, x):                      # x [B,H,W,C] contiguous == a channels_last [B,C,H,W] view: no layout copies
+        return fused.layer_norm(self.reduction(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1), self.norm)
 
 
 class Mlp(nn.Module):
@@ -128,7 +129,7 @@ class NAT(nn.Module):
             want = idx in self.compute_indices
             x, xo = level(x, getattr(self, f"norm{idx}") if want else None)
             if want:
-                outs.append(xo.permute(0, 3, 1, 2).contiguous())
+                outs.append(xo.permute(0, 3, 1, 2))    # [B,C,H,W] in channels_last memory format (zero-copy view)
         return outs
 
 
@@ -172,8 +173,8 @@ class SETRUPHead(nn.Module):
 
     def forward(self, inputs):
         x = inputs[self.in_index]
-        n, c, h, w = x.shape
-        x = self.norm(x.reshape(n, c, h * w).transpose(2, 1)).transpose(1, 2).reshape(n, c, h, w)
+        # LayerNorm over channels (setr_up_head.py:73-76) on the NHWC view; stays channels_last for the convolutions
+        x = fused.layer_norm(x.permute(0, 2, 3, 1), self.norm).permute(0, 3, 1, 2)
         for up in self.up_convs[:-1]:
             x = up(x)
         # last stage: conv_seg is a 1x1 convolution and bilinear interpolation is linear with weights summing to 1,
@@ -204,6 +205,21 @@ class SegNet(nn.Module):
         if self.decode_head.in_index in (-1, self.backbone.num_levels - 1):
             # SETR-UP reads only the last level: skip the per-level norm + NHWC->NCHW copies nobody consumes
             self.backbone.compute_indices = (self.backbone.num_levels - 1,)
+
+    def prepare_inference(self):
+        """After the checkpoint is loaded: fold each head BatchNorm into its convolution (exact algebra in float32,
+        W' = W * g/sqrt(v+eps), b' = beta - mu * g/sqrt(v+eps)) and put every convolution weight in channels_last, so
+        the whole network runs on NHWC tensors with no layout copies.  Changes the state-dict layout: load first."""
+        for up in self.decode_head.up_convs:
+            cm = up[0]
+            if isinstance(cm.bn, nn.BatchNorm2d):
+                bn, conv = cm.bn, cm.conv
+                scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
+                conv.weight = nn.Parameter((conv.weight.detach() * scale.view(-1, 1, 1, 1)))
+                conv.bias = nn.Parameter((bn.bias - bn.running_mean * scale).detach())
+                cm.bn = nn.Identity()
+        self.to(memory_format=torch.channels_last)
+        return self
 
     def encode_decode(self, img):
         out = self.decode_head(self.backbone(img))

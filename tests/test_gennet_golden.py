@@ -41,6 +41,16 @@ def test_aevit_gpu_matches_reference(golden_dir, R):
     assert np.abs(got - y).max() < 1e-3 * max(1.0, np.abs(y).max())          # float32 on MIOpen / rocBLAS
 
 
+@pytest.mark.parametrize("R", [64])
+def test_bn_folding_is_exact(golden_dir, R):
+    import copy
+    m, x, y = _model_and_data(golden_dir, R)
+    f = copy.deepcopy(m).prepare_inference()
+    with torch.no_grad():
+        assert np.abs(f(x).numpy() - y).max() < 5e-5 * max(1.0, np.abs(y).max())
+    assert not any(isinstance(mod, torch.nn.BatchNorm2d) for mod in f.modules())
+
+
 def test_heatmap_normalisation():
     from ppnet_amd.gennet import normalize_heatmap_u8
     y = torch.tensor([[[[0.0, 1.0], [2.0, 4.0]]], [[[-1.0, -1.0], [0.0, 1.0]]]])
