@@ -200,6 +200,11 @@ int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const 
  * dtype: 0 = float32, 1 = bfloat16 (float32 accumulation). q is multiplied by `scale` before QK. */
 int ppn_na2d_fwd(const void* qkv, const float* rpb, void* out, int32_t B, int32_t H, int32_t W, int32_t heads,
                  int32_t dilation, float scale, int32_t dtype, void* stream);
+/* Same for a zero-padded token grid: qkv covers the padded H x W grid (the padded tokens' q/k/v are the qkv bias, as
+ * when NATTEN's module pads before its projection); only the Hr x Wr real tokens are queries and out is the cropped
+ * [B][Hr][Wr][heads*32] tensor.  Hr <= H, Wr <= W. */
+int ppn_na2d_fwd_padded(const void* qkv, const float* rpb, void* out, int32_t B, int32_t H, int32_t W, int32_t Hr,
+                        int32_t Wr, int32_t heads, int32_t dilation, float scale, int32_t dtype, void* stream);
 
 /* Fused residual + LayerScale + LayerNorm around the NAT layer's dense ops (SegNet/nat.py:140-153):
  *   a == NULL : y_out = LayerNorm(x)                                   (x_out ignored)
@@ -208,6 +213,11 @@ int ppn_na2d_fwd(const void* qkv, const float* rpb, void* out, int32_t B, int32_
  * same dtype (0 = float32, 1 = bfloat16; statistics in float32). x_out may alias x. */
 int ppn_residual_layernorm(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out,
                            void* y_out, int64_t rows, int32_t C, float eps, int32_t dtype, void* stream);
+/* Same, with y_out scattered into a zero-padded token grid: rows = B*Hr*Wr tokens in [B][Hr][Wr] order are written to
+ * y_out laid out [B][Hp][Wp][C] (the pad region is left untouched: the caller zero-fills it once). */
+int ppn_residual_layernorm_padded(const void* x, const void* a, const void* gamma, const void* w, const void* b,
+                                  void* x_out, void* y_out, int64_t rows, int32_t C, float eps, int32_t dtype,
+                                  int32_t Hr, int32_t Wr, int32_t Hp, int32_t Wp, void* stream);
 
 /* PIL.Image.resize(size, BILINEAR) for 8-bit single-channel images, bit-exact: Pillow's ImagingResample
  * (support = max(scale,1), 22-bit fixed-point coefficients, horizontal pass then vertical pass, each rounded

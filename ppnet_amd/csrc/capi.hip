@@ -257,25 +257,38 @@ int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const 
 
 int ppn_na2d_fwd(const void* qkv, const float* rpb, void* out, int32_t B, int32_t H, int32_t W, int32_t heads,
                  int32_t dilation, float scale, int32_t dtype, void* stream) {
+    return ppn_na2d_fwd_padded(qkv, rpb, out, B, H, W, H, W, heads, dilation, scale, dtype, stream);
+}
+
+int ppn_na2d_fwd_padded(const void* qkv, const float* rpb, void* out, int32_t B, int32_t H, int32_t W, int32_t Hr, int32_t Wr,
+                        int32_t heads, int32_t dilation, float scale, int32_t dtype, void* stream) {
     if (!qkv || !rpb || !out || B <= 0 || heads <= 0 || dilation < 1 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
+    if (Hr <= 0 || Wr <= 0 || Hr > H || Wr > W) return PPN_E_INVALID;
     if (H < 7 * dilation || W < 7 * dilation) return PPN_E_INVALID;      // caller pads, like NATTEN's module
     {
         const long long hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
         if (((hs + 15) / 16) * ((ws + 15) / 16) * (long long)B * dilation * dilation > 0x7fffffffLL) return PPN_E_INVALID;
     }
-    const int e = ppn::na2d_launch(qkv, rpb, out, B, H, W, heads, dilation, scale, dtype, (hipStream_t)stream);
+    const int e = ppn::na2d_launch(qkv, rpb, out, B, H, W, Hr, Wr, heads, dilation, scale, dtype, (hipStream_t)stream);
     if (e != 0) return hip_fail((hipError_t)e);
     return PPN_OK;
 }
 
 int ppn_residual_layernorm(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out,
                            void* y_out, int64_t rows, int32_t C, float eps, int32_t dtype, void* stream) {
+    return ppn_residual_layernorm_padded(x, a, gamma, w, b, x_out, y_out, rows, C, eps, dtype, 0, 0, 0, 0, stream);
+}
+
+int ppn_residual_layernorm_padded(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out,
+                                  void* y_out, int64_t rows, int32_t C, float eps, int32_t dtype, int32_t Hr, int32_t Wr,
+                                  int32_t Hp, int32_t Wp, void* stream) {
+    if (Hp != 0 && (Hr <= 0 || Wr <= 0 || Hp < Hr || Wp < Wr || rows % ((int64_t)Hr * Wr) != 0)) return PPN_E_INVALID;
     if (!x || rows < 0 || C <= 0 || (C % 8) != 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
     if (a && !x_out) return PPN_E_INVALID;
     if (!a && !y_out) return PPN_E_INVALID;
     if (y_out && (!w || !b)) return PPN_E_INVALID;
     if (rows == 0) return PPN_OK;
-    const int e = ppn::norm_launch(x, a, gamma, w, b, x_out, y_out, rows, C, eps, dtype, (hipStream_t)stream);
+    const int e = ppn::norm_launch(x, a, gamma, w, b, x_out, y_out, rows, C, eps, dtype, Hr, Wr, Hp, Wp, (hipStream_t)stream);
     if (e == -1) return PPN_E_UNSUPPORTED;
     if (e != 0) return hip_fail((hipError_t)e);
     return PPN_OK;

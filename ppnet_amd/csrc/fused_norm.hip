@@ -56,7 +56,8 @@ __device__ __forceinline__ float group_sum(float v, int lpr) {
 template <typename T, int PASSES, bool RESID>
 __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ gamma,
                                                    const T* __restrict__ w, const T* __restrict__ b, T* __restrict__ x_out,
-                                                   T* __restrict__ y_out, long long rows, int C, int lpr, float eps) {
+                                                   T* __restrict__ y_out, long long rows, int C, int lpr, float eps,
+                                                   int Hr, int Wr, int Hp, int Wp) {
     const int lane = threadIdx.x & 63;
     const int rows_per_wave = 64 / lpr;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -112,6 +113,11 @@ __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, cons
         for (int k = 0; k < 8; ++k) { const float d = v[p][k] - mean; q = fmaf(d, d, q); }
     const float rstd = rsqrtf(group_sum(q, lpr) / (float)C + eps);
     if (!live) return;
+    long long yrow = row;                                                    // optional scatter into a zero-padded token grid
+    if (Hp) {
+        const long long hw = (long long)Hr * Wr, bi = row / hw, rem = row - bi * hw;
+        yrow = (bi * Hp + rem / Wr) * Wp + rem % Wr;
+    }
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int c0 = (p * lpr + li) * 8;
@@ -120,13 +126,13 @@ __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, cons
         Vec8<T>::load(b + c0, bv);
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = fmaf((v[p][k] - mean) * rstd, wv[k], bv[k]);
-        Vec8<T>::store(y_out + row * C + c0, o);
+        Vec8<T>::store(y_out + yrow * C + c0, o);
     }
 }
 
 template <typename T>
 static int launch_norm(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,
-                       long long rows, int C, float eps, hipStream_t stream) {
+                       long long rows, int C, float eps, int Hr, int Wr, int Hp, int Wp, hipStream_t stream) {
     int lpr = C / 8, passes = 1;
     if (lpr > 64) { passes = lpr / 64; lpr = 64; }
     if (passes > 2 || (lpr & (lpr - 1)) != 0 || lpr * 8 * passes != C) return -1;
@@ -134,7 +140,7 @@ static int launch_norm(const void* x, const void* a, const void* gamma, const vo
     const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
     const bool resid = a != nullptr;
 #define PPN_NORM_LAUNCH(P, R) hipLaunchKernelGGL((norm_kernel<T, P, R>), grid, dim3(256), 0, stream, (const T*)x, (const T*)a, \
-    (const T*)gamma, (const T*)w, (const T*)b, (T*)x_out, (T*)y_out, rows, C, lpr, eps)
+    (const T*)gamma, (const T*)w, (const T*)b, (T*)x_out, (T*)y_out, rows, C, lpr, eps, Hr, Wr, Hp, Wp)
     if (passes == 1) { if (resid) PPN_NORM_LAUNCH(1, true); else PPN_NORM_LAUNCH(1, false); }
     else { if (resid) PPN_NORM_LAUNCH(2, true); else PPN_NORM_LAUNCH(2, false); }
 #undef PPN_NORM_LAUNCH
@@ -142,9 +148,9 @@ static int launch_norm(const void* x, const void* a, const void* gamma, const vo
 }
 
 int norm_launch(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,
-                long long rows, int C, float eps, int dtype, hipStream_t stream) {
-    return dtype == 0 ? launch_norm<float>(x, a, gamma, w, b, x_out, y_out, rows, C, eps, stream)
-                      : launch_norm<__hip_bfloat16>(x, a, gamma, w, b, x_out, y_out, rows, C, eps, stream);
+                long long rows, int C, float eps, int dtype, int Hr, int Wr, int Hp, int Wp, hipStream_t stream) {
+    return dtype == 0 ? launch_norm<float>(x, a, gamma, w, b, x_out, y_out, rows, C, eps, Hr, Wr, Hp, Wp, stream)
+                      : launch_norm<__hip_bfloat16>(x, a, gamma, w, b, x_out, y_out, rows, C, eps, Hr, Wr, Hp, Wp, stream);
 }
 
 }  // namespace ppn

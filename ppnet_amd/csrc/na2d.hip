@@ -54,15 +54,20 @@ __device__ __forceinline__ void load_row(const __hip_bfloat16* row, float (&r)[H
 }
 }  // namespace
 
-// TILE x TILE queries per tile, NT threads per tile (= TILE*TILE), 256/NT tiles per workgroup.  TILE = 16: one tile
-// per workgroup (large sub-images); TILE = 8: four independent 8x8 tiles, one per wave — DiNAT's dilations leave
-// 7x7 or 8x8 sub-images on most layers, where a 16x16 tile would idle 75-80 % of its lanes.
-template <typename T, int TILE>
-__global__ __launch_bounds__(256) void na2d_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ rpb,
-                                                       T* __restrict__ out, int B, int H, int W, int heads, int dil,
-                                                       float scale, int total_tiles, int halo_r, int halo_c) {
+// TILE x TILE queries per tile, NT threads per tile (= TILE*TILE), THREADS/NT tiles per workgroup.  TILE = 16: one
+// tile per 256-thread workgroup (large sub-images); TILE = 8: four independent 8x8 tiles, one per wave; TILE = 4:
+// eight 4x4 tiles per 128-thread workgroup.  DiNAT's dilations leave 7x7 or 8x8 sub-images on most layers (a 16x16
+// tile would idle 75-80 % of its lanes), and on the PADDED layers only the Hr x Wr real tokens are queries: their
+// 4x4 real corner of each 7x7 group fills a 4x4 tile exactly.
+//
+// qkv is laid out for the padded H x W token grid (the module pads before the qkv projection, like NATTEN);
+// out is the unpadded [B][Hr][Wr][heads*32] tensor — padded positions are keys/values only, never queries.
+template <typename T, int TILE, int THREADS>
+__global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ rpb,
+                                                           T* __restrict__ out, int B, int H, int W, int Hr, int Wr, int heads,
+                                                           int dil, float scale, int total_tiles, int halo_r, int halo_c) {
     constexpr int STRIDE = Row<T>::STRIDE;
-    constexpr int NT = TILE * TILE, TPB = 256 / NT;                          // tiles per workgroup
+    constexpr int NT = TILE * TILE, TPB = THREADS / NT;                      // tiles per workgroup
     // halo_r x halo_c = min(TILE + KS - 1, sub-image extent): the LDS footprint (and so the occupancy) follows the
     // sub-image — DiNAT's padded dilated layers have 7x7 groups, 49 rows per tile instead of 196
     const int HALO = halo_c;                                                  // row pitch of the staged tile
@@ -73,27 +78,28 @@ __global__ __launch_bounds__(256) void na2d_fwd_kernel(const T* __restrict__ qkv
 
     const int tid = threadIdx.x % NT, ty = tid / TILE, tx = tid % TILE;
     const int h = blockIdx.y;
-    const int tiles_x = (((W + dil - 1) / dil) + TILE - 1) / TILE, tiles_y = (((H + dil - 1) / dil) + TILE - 1) / TILE;
+    const int tiles_x = (((Wr + dil - 1) / dil) + TILE - 1) / TILE, tiles_y = (((Hr + dil - 1) / dil) + TILE - 1) / TILE;
     const int ntiles = tiles_x * tiles_y;
     const int gtile = min((int)blockIdx.x * TPB + sub, total_tiles - 1);      // surplus sub-tiles redo the last tile's loads, store nothing
     const bool live = (int)blockIdx.x * TPB + sub < total_tiles;
     const int bz = gtile / ntiles, tile_id = gtile - bz * ntiles;             // tiles * B * d*d folded into grid.x
     const int b = bz / (dil * dil), g = bz % (dil * dil);
     const int gi = g / dil, gj = g % dil;
-    const int hs = (H - gi + dil - 1) / dil, ws = (W - gj + dil - 1) / dil;   // sub-image of this dilation group
+    const int hs = (H - gi + dil - 1) / dil, ws = (W - gj + dil - 1) / dil;   // sub-image of this dilation group (keys)
+    const int hq = gi < Hr ? (Hr - gi + dil - 1) / dil : 0, wq = gj < Wr ? (Wr - gj + dil - 1) / dil : 0;   // ... its real part (queries)
     const int ti0 = (tile_id / tiles_x) * TILE, tj0 = (tile_id % tiles_x) * TILE;
-    // a tile outside this group's sub-image (groups differ by one row/column) idles through the barriers
-    const bool tile_in = live && ti0 < hs && tj0 < ws;
+    // a tile outside this group's queries (groups differ by one row/column) idles through the barriers
+    const bool tile_in = live && ti0 < hq && tj0 < wq;
 
     const int u = ti0 + ty, v = tj0 + tx;                                   // query in sub-image coordinates
-    const bool valid = tile_in && u < hs && v < ws;
-    const int umax = min(ti0 + TILE - 1, hs - 1), vmax = min(tj0 + TILE - 1, ws - 1);
+    const bool valid = tile_in && u < hq && v < wq;
+    const int umax = min(ti0 + TILE - 1, hq - 1), vmax = min(tj0 + TILE - 1, wq - 1);
     const int r0 = clampi(ti0 - NS, 0, hs - KS), c0 = clampi(tj0 - NS, 0, ws - KS);
     const int nr = clampi(umax - NS, 0, hs - KS) + KS - r0, nc = clampi(vmax - NS, 0, ws - KS) + KS - c0;
     const int wi = clampi(u - NS, 0, hs - KS), wj = clampi(v - NS, 0, ws - KS);   // window start of this query
     const size_t tok = (size_t)3 * heads * HD;                              // elements per token in qkv
 
-    for (int t = threadIdx.x; t < 13 * 13; t += 256) bias[t] = rpb[(size_t)h * 169 + t];
+    for (int t = threadIdx.x; t < 13 * 13; t += THREADS) bias[t] = rpb[(size_t)h * 169 + t];
 
     auto load_tile = [&](int which) {                                       // which: 1 = K, 2 = V
         // one 16-byte piece per lane: HD*sizeof(T)/16 pieces per row
@@ -189,39 +195,47 @@ __global__ __launch_bounds__(256) void na2d_fwd_kernel(const T* __restrict__ qkv
         }
         const float inv = 1.0f / sum;
         const int y = gi + u * dil, x = gj + v * dil;
-        T* dst = out + ((size_t)(b * H + y) * W + x) * ((size_t)heads * HD) + (size_t)h * HD;
+        T* dst = out + ((size_t)(b * Hr + y) * Wr + x) * ((size_t)heads * HD) + (size_t)h * HD;
 #pragma unroll
         for (int c = 0; c < HD; ++c) store_out(dst + c, o[c] * inv);
     }
 }
 
-template <typename T, int TILE>
-static int launch_variant(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int dil, float scale,
-                          hipStream_t stream) {
-    constexpr int HALO = TILE + KS - 1, TPB = 256 / (TILE * TILE);
-    const int hs = (H + dil - 1) / dil, ws = (W + dil - 1) / dil;
-    const long long total = (long long)((hs + TILE - 1) / TILE) * ((ws + TILE - 1) / TILE) * B * dil * dil;
+template <typename T, int TILE, int THREADS>
+static int launch_variant(const void* qkv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
+                          float scale, hipStream_t stream) {
+    constexpr int HALO = TILE + KS - 1, TPB = THREADS / (TILE * TILE);
+    const int hs = (H + dil - 1) / dil, ws = (W + dil - 1) / dil;            // largest key sub-image
+    const int hq = (Hr + dil - 1) / dil, wq = (Wr + dil - 1) / dil;          // largest query sub-image
+    const long long total = (long long)((hq + TILE - 1) / TILE) * ((wq + TILE - 1) / TILE) * B * dil * dil;
     const dim3 grid((unsigned)((total + TPB - 1) / TPB), heads, 1);
     const int halo_r = hs < HALO ? hs : HALO, halo_c = ws < HALO ? ws : HALO;
     const size_t lds = (((size_t)TPB * halo_r * halo_c * Row<T>::STRIDE * sizeof(T) + 15) & ~(size_t)15) + 169 * sizeof(float);
-    hipError_t e = hipFuncSetAttribute((const void*)na2d_fwd_kernel<T, TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)na2d_fwd_kernel<T, TILE, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((na2d_fwd_kernel<T, TILE>), grid, dim3(256), lds, stream, (const T*)qkv, rpb, (T*)out, B, H, W, heads, dil,
-                       scale, (int)total, halo_r, halo_c);
+    hipLaunchKernelGGL((na2d_fwd_kernel<T, TILE, THREADS>), grid, dim3(THREADS), lds, stream, (const T*)qkv, rpb, (T*)out, B, H, W, Hr,
+                       Wr, heads, dil, scale, (int)total, halo_r, halo_c);
     return (int)hipGetLastError();
 }
 
-int na2d_launch(const void* qkv, const float* rpb, void* out, int B, int H, int W, int heads, int dil, float scale,
+template <typename T>
+static int launch_typed(const void* qkv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
+                        float scale, hipStream_t stream) {
+    const int hq = (Hr + dil - 1) / dil, wq = (Wr + dil - 1) / dil;
+    // lane utilisation of each tiling on the query sub-image
+    auto util = [&](int t) { return (double)(hq * wq) / ((double)((hq + t - 1) / t * t) * ((wq + t - 1) / t * t)); };
+    int best = 16;
+    if (util(8) > util(best) + 0.05) best = 8;
+    if (util(4) > util(best) + 0.05) best = 4;
+    if (best == 4) return launch_variant<T, 4, 128>(qkv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
+    if (best == 8) return launch_variant<T, 8, 256>(qkv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
+    return launch_variant<T, 16, 256>(qkv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
+}
+
+int na2d_launch(const void* qkv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil, float scale,
                 int dtype, hipStream_t stream) {
-    const int hs = (H + dil - 1) / dil, ws = (W + dil - 1) / dil;
-    // lane utilisation of the two tilings on this sub-image size
-    auto util = [&](int t) { return (double)(hs * ws) / ((double)((hs + t - 1) / t * t) * ((ws + t - 1) / t * t)); };
-    const bool small = util(8) > util(16) + 0.05;
-    if (dtype == 0)
-        return small ? launch_variant<float, 8>(qkv, rpb, out, B, H, W, heads, dil, scale, stream)
-                     : launch_variant<float, 16>(qkv, rpb, out, B, H, W, heads, dil, scale, stream);
-    return small ? launch_variant<__hip_bfloat16, 8>(qkv, rpb, out, B, H, W, heads, dil, scale, stream)
-                 : launch_variant<__hip_bfloat16, 16>(qkv, rpb, out, B, H, W, heads, dil, scale, stream);
+    return dtype == 0 ? launch_typed<float>(qkv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream)
+                      : launch_typed<__hip_bfloat16>(qkv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
 }
 
 }  // namespace ppn

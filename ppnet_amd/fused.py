@@ -12,7 +12,20 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(None)
 
 
-def _call(x, a, gamma, ln, x_out, y_out):
+_PADDED = {}
+
+
+def _padded_buffer(B, Hp, Wp, C, dtype, device):
+    """Persistent zero-initialised [B,Hp,Wp,C] buffer: the kernels only ever write the real tokens, so the pad
+    region stays zero; consumers (the qkv projection) read it before the next same-shaped producer runs."""
+    key = (B, Hp, Wp, C, dtype, device)
+    buf = _PADDED.get(key)
+    if buf is None:
+        buf = _PADDED[key] = torch.zeros(B, Hp, Wp, C, dtype=dtype, device=device)
+    return buf
+
+
+def _call(x, a, gamma, ln, x_out, y_out, pad=None):
     if not x.is_cuda:
         raise RuntimeError("ppnet_amd.fused: GPU tensors only (no CPU fallback)")
     C = x.shape[-1]
@@ -24,25 +37,34 @@ def _call(x, a, gamma, ln, x_out, y_out):
     gamma = gamma.to(x.dtype) if gamma is not None else None
     for t in (a, gamma, w, b):
         assert t is None or (t.dtype == x.dtype and t.is_contiguous())
+    hr, wr, hp, wp = pad if pad is not None else (0, 0, 0, 0)
     with torch.cuda.device(x.device):
-        rc = L.lib.ppn_residual_layernorm(_p(x), _p(a), _p(gamma), _p(w), _p(b), _p(x_out), _p(y_out), rows, C,
-                                          float(ln.eps) if ln is not None else 0.0, dt,
-                                          ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        rc = L.lib.ppn_residual_layernorm_padded(_p(x), _p(a), _p(gamma), _p(w), _p(b), _p(x_out), _p(y_out), rows, C,
+                                                 float(ln.eps) if ln is not None else 0.0, dt, hr, wr, hp, wp,
+                                                 ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     L.check(rc, "ppn_residual_layernorm")
 
 
-def layer_norm(x, ln):
-    """y = ln(x) for a torch.nn.LayerNorm over the last dimension."""
+def _y_for(x, pad_to):
+    if pad_to is None:
+        return torch.empty_like(x), None
+    B, Hr, Wr, C = x.shape
+    return _padded_buffer(B, pad_to[0], pad_to[1], C, x.dtype, x.device), (Hr, Wr, pad_to[0], pad_to[1])
+
+
+def layer_norm(x, ln, pad_to=None):
+    """y = ln(x) for a torch.nn.LayerNorm over the last dimension. pad_to=(Hp,Wp): x is [B,H,W,C] and y is the
+    zero-padded (bottom/right) [B,Hp,Wp,C] grid the next neighbourhood attention wants."""
     x = x.contiguous()
-    y = torch.empty_like(x)
-    _call(x, None, None, ln, None, y)
+    y, pad = _y_for(x, pad_to)
+    _call(x, None, None, ln, None, y, pad)
     return y
 
 
-def residual_layer_norm(x, a, gamma, ln_next):
+def residual_layer_norm(x, a, gamma, ln_next, pad_to=None):
     """x' = x + gamma * a (gamma None = 1) in place of x; returns (x', ln_next(x')) — y is None when ln_next is None."""
     x = x.contiguous()
     a = a.to(x.dtype).contiguous()
-    y = torch.empty_like(x) if ln_next is not None else None
-    _call(x, a, gamma.detach() if gamma is not None else None, ln_next, x, y)
+    y, pad = _y_for(x, pad_to) if ln_next is not None else (None, None)
+    _call(x, a, gamma.detach() if gamma is not None else None, ln_next, x, y, pad)
     return x, y

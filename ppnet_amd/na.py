@@ -10,9 +10,10 @@ import torch.nn.functional as F
 from . import _lib as L
 
 
-def na2d_forward(qkv, rpb, heads, dilation, scale):
+def na2d_forward(qkv, rpb, heads, dilation, scale, real_hw=None):
     """qkv: [B,H,W,3*C] contiguous CUDA tensor (float32 or bfloat16) straight from the qkv Linear;
-    rpb: [heads,13,13]. Returns [B,H,W,C] in the layout the output projection consumes."""
+    rpb: [heads,13,13]. Returns [B,Hr,Wr,C] in the layout the output projection consumes; real_hw=(Hr,Wr) when the
+    H x W grid is the zero-padded one (padded tokens are keys/values only), default (H, W)."""
     if not qkv.is_cuda:
         raise RuntimeError("ppnet_amd.na: the neighbourhood-attention kernel runs on the GPU only (no CPU fallback)")
     B, H, W, C3 = qkv.shape
@@ -24,12 +25,13 @@ def na2d_forward(qkv, rpb, heads, dilation, scale):
         raise NotImplementedError(f"dtype {qkv.dtype}")
     qkv = qkv.contiguous()
     rpb = rpb.detach().to(torch.float32).contiguous()
-    out = torch.empty(B, H, W, ch, dtype=qkv.dtype, device=qkv.device)
+    Hr, Wr = real_hw if real_hw is not None else (H, W)
+    out = torch.empty(B, Hr, Wr, ch, dtype=qkv.dtype, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        rc = L.lib.ppn_na2d_fwd(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(rpb.data_ptr()),
-                                ctypes.c_void_p(out.data_ptr()), B, H, W, heads, dilation, float(scale), dtype,
-                                ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream))
-    L.check(rc, "ppn_na2d_fwd")
+        rc = L.lib.ppn_na2d_fwd_padded(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(rpb.data_ptr()),
+                                       ctypes.c_void_p(out.data_ptr()), B, H, W, Hr, Wr, heads, dilation, float(scale), dtype,
+                                       ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream))
+    L.check(rc, "ppn_na2d_fwd_padded")
     return out
 
 
@@ -53,15 +55,20 @@ class NeighborhoodAttention2D(nn.Module):
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj_drop = nn.Dropout(proj_drop)
 
-    def forward(self, x):
-        B, Hp, Wp, C = x.shape
-        H, W = Hp, Wp
-        pad_r = pad_b = 0
-        if H < self.window_size or W < self.window_size:              # pad BEFORE qkv, bottom/right (NATTEN module)
-            pad_r = max(0, self.window_size - W)
-            pad_b = max(0, self.window_size - H)
-            x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))
-        o = na2d_forward(self.qkv(x), self.rpb, self.num_heads, self.dilation, self.scale)
-        if pad_r or pad_b:
-            o = o[:, :Hp, :Wp, :]
+    def padded_hw(self, H, W):
+        """Token grid after NATTEN's pad-to-kernel*dilation rule, or None when (H, W) is large enough."""
+        if H >= self.window_size and W >= self.window_size:
+            return None
+        return max(H, self.window_size), max(W, self.window_size)
+
+    def forward(self, x, real_hw=None):
+        """x [B,H,W,C]. real_hw=(Hr,Wr): x is ALREADY zero-padded bottom/right from (Hr,Wr) to this layer's padded
+        grid (the fused LayerNorm kernel writes it that way); otherwise the padding happens here. Padding comes
+        BEFORE the qkv projection (NATTEN's module), and only the real tokens are queries, so no crop is needed."""
+        if real_hw is None:
+            real_hw = (x.shape[1], x.shape[2])
+            pad = self.padded_hw(*real_hw)
+            if pad is not None:
+                x = F.pad(x, (0, 0, 0, pad[1] - real_hw[1], 0, pad[0] - real_hw[0]))
+        o = na2d_forward(self.qkv(x), self.rpb, self.num_heads, self.dilation, self.scale, real_hw)
         return self.proj_drop(self.proj(o))

@@ -15,6 +15,9 @@ class PPNet(torch.nn.Module):
         the GEMM / conv / attention kernels, fp32 statistics inside LayerNorm); amp_dtype=bfloat16 with
         weights_dtype=None keeps fp32 weights under autocast; both None = fp32 everywhere."""
         super().__init__()
+        # exhaustive MIOpen search for the few convolution shapes of the two networks (a one-off at the first batch):
+        # measured 64 -> 57 ms per 256-problem batch against the default heuristic pick
+        torch.backends.cudnn.benchmark = True
         self.resolution = resolution
         self.segnet = segnet if segnet is not None else SegNet()
         self.gennet = gennet if gennet is not None else AEViT(1, 1, resolution, 24)      # predict.py:36,46

@@ -63,14 +63,16 @@ class NATLayer(nn.Module):
             self.gamma1 = nn.Parameter(layer_scale * torch.ones(dim))
             self.gamma2 = nn.Parameter(layer_scale * torch.ones(dim))
 
-    def forward(self, x, y=None, next_norm=None):
-        """x: residual stream [B,H,W,C]; y = norm1(x) if the caller already has it. Returns (x', next_norm(x')).
+    def forward(self, x, y=None, next_norm=None, next_pad=None):
+        """x: residual stream [B,H,W,C]; y = norm1(x) if the caller already has it (zero-padded to this layer's
+        attention grid when that is larger). Returns (x', next_norm(x')) with the second padded to next_pad.
         Residual add, LayerScale and the following LayerNorm are one fused kernel each (DropPath is the identity
         at inference, nat.py:140-153)."""
+        hw = (x.shape[1], x.shape[2])
         if y is None:
-            y = fused.layer_norm(x, self.norm1)
-        x, y2 = fused.residual_layer_norm(x, self.attn(y), self.gamma1 if self.layer_scale else None, self.norm2)
-        return fused.residual_layer_norm(x, self.mlp(y2), self.gamma2 if self.layer_scale else None, next_norm)
+            y = fused.layer_norm(x, self.norm1, self.attn.padded_hw(*hw))
+        x, y2 = fused.residual_layer_norm(x, self.attn(y, hw), self.gamma1 if self.layer_scale else None, self.norm2)
+        return fused.residual_layer_norm(x, self.mlp(y2), self.gamma2 if self.layer_scale else None, next_norm, next_pad)
 
 
 class NATBlock(nn.Module):
@@ -87,9 +89,12 @@ class NATBlock(nn.Module):
         x = x.clone()                                  # the fused kernels update the residual stream in place
         y = None
         n = len(self.blocks)
+        hw = (x.shape[1], x.shape[2])
         for i, blk in enumerate(self.blocks):
-            nxt = self.blocks[i + 1].norm1 if i + 1 < n else out_norm
-            x, y = blk(x, y, nxt)
+            if i + 1 < n:
+                x, y = blk(x, y, self.blocks[i + 1].norm1, self.blocks[i + 1].attn.padded_hw(*hw))
+            else:
+                x, y = blk(x, y, out_norm, None)
         xo = y if out_norm is not None else x
         return (x, xo) if self.downsample is None else (self.downsample(x), xo)
 

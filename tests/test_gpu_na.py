@@ -68,6 +68,21 @@ def test_module_with_padding_vs_oracle(dev, H, W, d):
     assert np.abs(got - want).max() < 5e-5
 
 
+@pytest.mark.parametrize("H,W,Hr,Wr,d,heads", [(28, 28, 16, 16, 4, 2), (112, 112, 64, 64, 16, 1), (14, 14, 8, 8, 2, 3), (21, 21, 16, 13, 3, 2)])
+def test_padded_grid_queries_only_real_tokens(dev, H, W, Hr, Wr, d, heads):
+    """ppn_na2d_fwd_padded: keys/values over the padded grid, queries and output over the real tokens only."""
+    import torch
+    from ppnet_amd import na
+    rng = np.random.RandomState(7)
+    C = heads * 32
+    qkv = rng.standard_normal((1, H, W, 3 * C)).astype(np.float32)
+    rpb = rng.standard_normal((heads, 13, 13)).astype(np.float32)
+    got = na.na2d_forward(torch.tensor(qkv, device=dev), torch.tensor(rpb, device=dev), heads, d, 32 ** -0.5, (Hr, Wr)).cpu().numpy()
+    want = NA.na2d_from_qkv(qkv, rpb, heads, 7, d, 32 ** -0.5)[:, :Hr, :Wr]
+    assert got.shape == (1, Hr, Wr, C)
+    assert np.abs(got - want).max() < 2e-5
+
+
 def test_no_cpu_fallback():
     import torch
     from ppnet_amd import na

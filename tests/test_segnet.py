@@ -63,7 +63,7 @@ def test_small_nat_gpu_vs_oracle_composition():
     assert torch.cuda.is_available()
     torch.manual_seed(0)
     cfg = dict(embed_dim=64, mlp_ratio=2.0, depths=[2, 2], num_heads=[2, 4], kernel_size=7,
-               dilations=[[1, 2], [1, 1]], layer_scale=0.5, out_indices=(0, 1))
+               dilations=[[1, 4], [2, 1]], layer_scale=0.5, out_indices=(0, 1))   # 16x16 d=4 and 8x8 d=2: padded grids
     m = NAT(**cfg).eval()
     x = torch.randn(2, 3, 64, 64)
     want = _reference_nat_forward(m, x.double())

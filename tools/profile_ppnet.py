@@ -9,6 +9,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 pb = edage.generate_paths(16, 256, 50, 3, seed=0, device=dev)
 mb = edage.generate_maps(pb, B // 16, 5, 20, seed=0)
 torch.manual_seed(0)
+import os
+if os.environ.get("PPN_CUDNN_BENCHMARK") == "1":
+    torch.backends.cudnn.benchmark = True
 m = PPNet(256).to(dev).eval()
 args = (mb.grid, mb.segpoint[:, 0].contiguous(), mb.segpoint[:, 10].contiguous(), mb.obstacles, mb.n_obstacles[:, 0].contiguous(), 1 / 50 * 224)
 for _ in range(2):
