@@ -219,6 +219,13 @@ int ppn_residual_layernorm_padded(const void* x, const void* a, const void* gamm
                                   void* x_out, void* y_out, int64_t rows, int32_t C, float eps, int32_t dtype,
                                   int32_t Hr, int32_t Wr, int32_t Hp, int32_t Wp, void* stream);
 
+/* Bilinear x2 up-sampling of an NHWC tensor x [B][H][W][C] -> y [B][2H][2W][C] with PyTorch's
+ * F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) arithmetic (the SETR-UP head's Upsample,
+ * SegNet/mmseg/ops/wrappers.py:30-51); relu != 0 applies max(x, 0) to the input first (the ConvModule's ReLU,
+ * setr_up_head.py:53-66). C a multiple of 8; dtype 0 = float32, 1 = bfloat16. */
+int ppn_upsample2x_nhwc(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t relu,
+                        int32_t dtype, void* stream);
+
 /* PIL.Image.resize(size, BILINEAR) for 8-bit single-channel images, bit-exact: Pillow's ImagingResample
  * (support = max(scale,1), 22-bit fixed-point coefficients, horizontal pass then vertical pass, each rounded
  * to 8 bits).  Used by extract_path's down-sampling (process_map.py:301).  in [n][H][W], tmp [n][H][outW],

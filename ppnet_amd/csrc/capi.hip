@@ -294,6 +294,14 @@ int ppn_residual_layernorm_padded(const void* x, const void* a, const void* gamm
     return PPN_OK;
 }
 
+int ppn_upsample2x_nhwc(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t relu, int32_t dtype,
+                        void* stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
+    const int e = ppn::upsample2x_launch(x, y, B, H, W, C, relu, dtype, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_resize_bilinear_u8(const uint8_t* in, int32_t n, int32_t H, int32_t W, int32_t outH, int32_t outW, uint8_t* tmp,
                            uint8_t* out, void* stream) {
     if (!in || n < 0 || H <= 0 || W <= 0 || outH <= 0 || outW <= 0 || !tmp || !out) return PPN_E_INVALID;

@@ -130,6 +130,50 @@ __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, cons
     }
 }
 
+// Bilinear x2 up-sampling of an NHWC tensor (F.interpolate(scale_factor=2, mode="bilinear", align_corners=False), the
+// SETR-UP head's Upsample, mmseg/ops/wrappers.py:30-51) with the preceding ReLU folded into the loads: one thread per
+// 8 channels of one output pixel, four 16-byte loads, one 16-byte store.
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+    const int cg = C / 8;
+    const long long total = (long long)B * (2 * H) * (2 * W) * cg;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c0 = (int)(idx % cg) * 8;
+    long long t = idx / cg;
+    const int ox = (int)(t % (2 * W)); t /= (2 * W);
+    const int oy = (int)(t % (2 * H));
+    const int b = (int)(t / (2 * H));
+    // source coordinate (dst + 0.5) / 2 - 0.5, clamped below at 0 (PyTorch's area_pixel_compute_source_index)
+    const float sy = fmaxf(((float)oy + 0.5f) * 0.5f - 0.5f, 0.0f), sx = fmaxf(((float)ox + 0.5f) * 0.5f - 0.5f, 0.0f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+    const T* base = x + (size_t)b * H * W * C + c0;
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    Vec8<T>::load(base + ((size_t)y0 * W + x0) * C, v00);
+    Vec8<T>::load(base + ((size_t)y0 * W + x1) * C, v01);
+    Vec8<T>::load(base + ((size_t)y1 * W + x0) * C, v10);
+    Vec8<T>::load(base + ((size_t)y1 * W + x1) * C, v11);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float a = v00[k], bq = v01[k], c = v10[k], d = v11[k];
+        if (RELU) { a = fmaxf(a, 0.0f); bq = fmaxf(bq, 0.0f); c = fmaxf(c, 0.0f); d = fmaxf(d, 0.0f); }
+        o[k] = hy * (hx * a + lx * bq) + ly * (hx * c + lx * d);
+    }
+    Vec8<T>::store(y + (((size_t)b * 2 * H + oy) * 2 * W + ox) * C + c0, o);
+}
+
+int upsample2x_launch(const void* x, void* y, int B, int H, int W, int C, int relu, int dtype, hipStream_t stream) {
+    const long long total = (long long)B * (2 * H) * (2 * W) * (C / 8);
+    const dim3 grid((unsigned)((total + 255) / 256));
+#define PPN_UP(T, R) hipLaunchKernelGGL((upsample2x_kernel<T, R>), grid, dim3(256), 0, stream, (const T*)x, (T*)y, B, H, W, C)
+    if (dtype == 0) { if (relu) PPN_UP(float, true); else PPN_UP(float, false); }
+    else { if (relu) PPN_UP(__hip_bfloat16, true); else PPN_UP(__hip_bfloat16, false); }
+#undef PPN_UP
+    return (int)hipGetLastError();
+}
+
 template <typename T>
 static int launch_norm(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,
                        long long rows, int C, float eps, int Hr, int Wr, int Hp, int Wp, hipStream_t stream) {

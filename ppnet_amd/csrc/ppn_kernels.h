@@ -65,4 +65,6 @@ int na2d_launch(const void* qkv, const float* rpb, void* out, int B, int H, int 
 int norm_launch(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,
                 long long rows, int C, float eps, int dtype, int Hr, int Wr, int Hp, int Wp, hipStream_t stream);
 
+int upsample2x_launch(const void* x, void* y, int B, int H, int W, int C, int relu, int dtype, hipStream_t stream);
+
 }  // namespace ppn

@@ -68,3 +68,20 @@ def residual_layer_norm(x, a, gamma, ln_next, pad_to=None):
     y, pad = _y_for(x, pad_to) if ln_next is not None else (None, None)
     _call(x, a, gamma.detach() if gamma is not None else None, ln_next, x, y, pad)
     return x, y
+
+
+def upsample2x_nhwc(x_nchw_cl, relu=False):
+    """Bilinear x2 (align_corners=False) of a channels_last [B,C,H,W] tensor, optionally with a ReLU folded into the
+    loads. Returns a channels_last [B,C,2H,2W] tensor (zero-copy views on both sides)."""
+    if not x_nchw_cl.is_cuda:
+        raise RuntimeError("ppnet_amd.fused: GPU tensors only (no CPU fallback)")
+    x = x_nchw_cl.permute(0, 2, 3, 1)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, H, W, C = x.shape
+    y = torch.empty(B, 2 * H, 2 * W, C, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = L.lib.ppn_upsample2x_nhwc(_p(x), _p(y), B, H, W, C, 1 if relu else 0, _DT[x.dtype],
+                                       ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    L.check(rc, "ppn_upsample2x_nhwc")
+    return y.permute(0, 3, 1, 2)

@@ -157,7 +157,11 @@ class _Upsample(nn.Module):
         super().__init__()
         self.scale_factor, self.align_corners = float(scale_factor), align_corners
 
-    def forward(self, x):
+    def forward(self, x, relu=False):
+        if self.scale_factor == 2.0 and not self.align_corners and x.shape[1] % 8 == 0 and x.is_cuda:
+            return fused.upsample2x_nhwc(x, relu)                            # HIP kernel, ReLU folded into the loads
+        if relu:
+            x = F.relu(x)
         size = [int(t * self.scale_factor) for t in x.shape[-2:]]            # mmseg/ops/wrappers.py:43-51
         return F.interpolate(x, size, None, "bilinear", self.align_corners)
 
@@ -181,12 +185,13 @@ class SETRUPHead(nn.Module):
         # LayerNorm over channels (setr_up_head.py:73-76) on the NHWC view; stays channels_last for the convolutions
         x = fused.layer_norm(x.permute(0, 2, 3, 1), self.norm).permute(0, 3, 1, 2)
         for up in self.up_convs[:-1]:
-            x = up(x)
+            cm = up[0]
+            x = up[1](cm.bn(cm.conv(x)), relu=True)                          # conv -> (folded) BN -> ReLU + x2 bilinear in one kernel
         # last stage: conv_seg is a 1x1 convolution and bilinear interpolation is linear with weights summing to 1,
         # so conv_seg(upsample(y)) == upsample(conv_seg(y)): classify at the low resolution and upsample 2 channels
         # instead of `channels` (the reference materialises a [B,512,R/2,R/2] tensor here, setr_up_head.py:78-80)
         conv, up = self.up_convs[-1][0], self.up_convs[-1][1]
-        return up(self.conv_seg(conv(x)))
+        return up(self.conv_seg(conv(x)).contiguous())                       # 2 channels: the library bilinear kernel
 
 
 DINAT_BASE = dict(   # SegNet/configs/dinat/dinat_base.py:5-24 over _base_/models/dinat.py:3-46

@@ -98,6 +98,21 @@ def test_fused_residual_layernorm_vs_torch(C, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_upsample2x_relu_vs_torch(dtype):
+    from ppnet_amd import fused
+    dt = getattr(torch, dtype)
+    torch.manual_seed(2)
+    x = torch.randn(3, 64, 9, 13, device="cuda", dtype=dt).contiguous(memory_format=torch.channels_last)
+    for relu in (False, True):
+        got = fused.upsample2x_nhwc(x, relu)
+        ref = torch.nn.functional.interpolate(torch.relu(x.float()) if relu else x.float(), scale_factor=2, mode="bilinear",
+                                              align_corners=False)
+        assert got.shape == ref.shape
+        assert (got.float() - ref).abs().max() < (1e-5 if dt == torch.float32 else 2e-2)
+
+
+@pytest.mark.gpu
 def test_dinat_base_end_to_end_256():
     from ppnet_amd.segnet import SegNet, normalize_images
     torch.manual_seed(0)
