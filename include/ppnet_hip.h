@@ -149,6 +149,14 @@ int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements
                    const double* place_draws, const double* obst_draws,
                    const ppn_maps_t* out, void* stream);
 
+/* The per-map label images written right after generation (process_map.py:148-191), for the n = n_paths*placements
+ * maps of a ppn_edage_maps call:
+ *   mask_path [n][R][R] u8 : generate_gen_path — every 5th label point with 0 < round(p) < bound set to 255;
+ *   mask_space[n][R][R] u8 : generate_seg_space — the target path's Space rotated by -angle and translated, {0,1}.
+ * `bound` is the reference's hard-coded 224 (pass R for other resolutions). Either output may be NULL. */
+int ppn_label_masks(const ppn_paths_t* paths, const ppn_maps_t* maps, int32_t n_paths, int32_t placements,
+                    int32_t R, int32_t bound, uint8_t* mask_path, uint8_t* mask_space, void* stream);
+
 /* Path.boundary_check (Path.py:100-111) for n (angle, translation) pairs against one hull.
  * angle_deg[n] is the angle passed by the caller (MapGenerate passes -angle), translation_rc
  * [n][2] is (row, col).  ok[n] u8. */

@@ -642,6 +642,22 @@ def compose_grid(prec, angle, t, obstacles_all, segpoint, R):
     return paint_markers(grid, segpoint[0], segpoint[PATHSEGNUM])
 
 
+def label_masks(prec, angle, t, pathpoint, R, bound=None):
+    """The two per-map label images process_map.py writes next:
+      mask_path  (generate_gen_path, :148-163): every 5th label point with 0 < round(p) < bound -> 255, else 0;
+      mask_space (generate_seg_space, :166-191): the target path's Space rotated by -angle, translated by t, thresholded
+                 to {0,1} — the same nearest-neighbour rule as the corridor in compose_grid (torchvision: parity unpinned).
+    `bound` is the reference's hard-coded 224 (default: R)."""
+    bound = R if bound is None else bound
+    mp = np.zeros([R, R], dtype=np.uint8)
+    for step in range(0, len(pathpoint), 5):
+        r0, c0 = int(np.round(pathpoint[step][0])), int(np.round(pathpoint[step][1]))
+        if 0 < r0 < bound and 0 < c0 < bound and r0 < R and c0 < R:
+            mp[r0, c0] = 255
+    ms = translate_nearest(rotate_nearest(prec["space"], float(-angle)), float(t[0]), float(t[1]), R, R).astype(np.uint8)
+    return mp, ms
+
+
 def make_map(prec, map_id, source, R, map_size, obstacles_size, K, clearance, want_grid=True):
     """One placement of one target path (MapGenerate.py:57-124), bounded retry."""
     flags = 0

@@ -189,6 +189,20 @@ int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements
     return PPN_OK;
 }
 
+int ppn_label_masks(const ppn_paths_t* paths, const ppn_maps_t* maps, int32_t n_paths, int32_t placements, int32_t R,
+                    int32_t bound, uint8_t* mask_path, uint8_t* mask_space, void* stream) {
+    if (!paths || !maps || n_paths < 0 || placements < 0 || bad_R(R) || bound <= 0) return PPN_E_INVALID;
+    if (mask_space && (!paths->space_bits || !maps->angle || !maps->translation)) return PPN_E_INVALID;
+    if (mask_path && !maps->pathpoint) return PPN_E_INVALID;
+    const long long n = (long long)n_paths * placements;
+    if (n == 0 || (!mask_path && !mask_space)) return PPN_OK;
+    if (n > 0x7fffffffLL) return PPN_E_INVALID;
+    hipLaunchKernelGGL(ppn::label_masks_kernel, dim3((unsigned)n), dim3(256), (size_t)R * R / 8, (hipStream_t)stream, *paths, *maps,
+                       placements, R, bound, mask_path, mask_space);
+    PPN_HIP(hipGetLastError());
+    return PPN_OK;
+}
+
 int ppn_boundary_check(const double* hull, int32_t hull_n, const double* angle_deg, const double* translation_rc,
                        int32_t n, int32_t R, uint8_t* ok, void* stream) {
     return ppn_boundary_check_ex(hull, hull_n, angle_deg, translation_rc, n, R, ok, nullptr, stream);

@@ -451,6 +451,63 @@ __global__ __launch_bounds__(NT) void boundary_check_kernel(const double* hull, 
     if (lane == 0) ok[i] = good ? 1 : 0;
 }
 
+// generate_gen_path / generate_seg_space (process_map.py:148-191): one workgroup per map. mask_space is the corridor of
+// the compose step (same inverse nearest-neighbour map of the target path's Space bits, staged in LDS), written as
+// {0,1} bytes with 16-byte stores; mask_path scatters the 200 every-5th label points as 255.
+__global__ __launch_bounds__(NT) void label_masks_kernel(ppn_paths_t P, ppn_maps_t M, int placements, int R, int bound,
+                                                         uint8_t* mask_path, uint8_t* mask_space) {
+    extern __shared__ uint32_t lm_space[];
+    const int m = blockIdx.x, tid = threadIdx.x, pj = m / placements;
+    const int words = R * R / 32;
+    const double half = (double)R / 2.0;
+    if (mask_space) {
+        for (int w = tid; w < words; w += NT) lm_space[w] = P.space_bits[(size_t)pj * words + w];
+        __syncthreads();
+        const double angle = M.angle[m];
+        const int t0 = M.translation[(size_t)m * 2], t1 = M.translation[(size_t)m * 2 + 1];
+        double c3, s3;
+        sincos_small((-angle) * PI / 180.0, s3, c3);
+        uint8_t* g = mask_space + (size_t)m * R * R;
+        const int cpr = R / 16;
+        for (int ch = tid; ch < R * cpr; ch += NT) {
+            const int i = ch / cpr, j0 = (ch - i * cpr) * 16;
+            const int i1 = i - t1;
+            uint32_t bits = 0u;
+            if (i1 >= 0 && i1 < R) {
+                const double yo = ((double)i1 + 0.5) - half;
+                for (int k = 0; k < 16; ++k) {
+                    const int j1 = j0 + k - t0;
+                    if (j1 < 0 || j1 >= R) continue;
+                    const double xo = ((double)j1 + 0.5) - half;
+                    const double xs = c3 * xo - s3 * yo, ys = s3 * xo + c3 * yo;
+                    const int jj = (int)rint(xs + (half - 0.5)), ii = (int)rint(ys + (half - 0.5));
+                    if (ii < 0 || ii >= R || jj < 0 || jj >= R) continue;
+                    const int bit = ii * R + jj;
+                    bits |= ((lm_space[bit >> 5] >> (bit & 31)) & 1u) << k;
+                }
+            }
+            uint32_t w4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t n4 = (bits >> (4 * q)) & 15u;
+                w4[q] = (n4 & 1u) | ((n4 & 2u) << 7) | ((n4 & 4u) << 14) | ((n4 & 8u) << 21);
+            }
+            *reinterpret_cast<uint4*>(g + (size_t)i * R + j0) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+    }
+    if (mask_path) {
+        uint8_t* g = mask_path + (size_t)m * R * R;
+        for (int w = tid; w < R * R / 16; w += NT) reinterpret_cast<uint4*>(g)[w] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        for (int q = tid; q < PPN_PATH_POINTS / 5; q += NT) {
+            const double* pt = M.pathpoint + ((size_t)m * PPN_PATH_POINTS + 5 * q) * 2;
+            const int r0 = (int)rint(pt[0]), c0 = (int)rint(pt[1]);
+            if (r0 > 0 && r0 < bound && c0 > 0 && c0 < bound && r0 < R && c0 < R) g[(size_t)r0 * R + c0] = 255;
+        }
+    }
+}
+
 // generate_map_randomly's accept loop on its own (MapGenerate.py:128-143): one workgroup per map,
 // one wave per candidate, shuffle min-reduce over the 500 odd path points
 __global__ __launch_bounds__(NT) void obstacle_filter_kernel(const double* pathpoint, const double* draws, int n, int K,

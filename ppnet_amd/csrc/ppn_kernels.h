@@ -67,4 +67,7 @@ int norm_launch(const void* x, const void* a, const void* gamma, const void* w, 
 
 int upsample2x_launch(const void* x, void* y, int B, int H, int W, int C, int relu, int dtype, hipStream_t stream);
 
+__global__ void label_masks_kernel(ppn_paths_t paths, ppn_maps_t maps, int placements, int R, int bound, uint8_t* mask_path,
+                                   uint8_t* mask_space);
+
 }  // namespace ppn

@@ -138,6 +138,19 @@ def generate_maps(paths, placements, obstacles_size=5, obstacles_num=50, seed=0,
     return mb
 
 
+def label_masks(paths, maps, placements, bound=None, want_path=True, want_space=True):
+    """generate_gen_path / generate_seg_space (process_map.py:148-191) for every map of a MapsBatch:
+    returns (mask_path u8 [n,R,R] with 255 on every 5th label point, mask_space u8 [n,R,R] in {0,1})."""
+    R, n, dev = paths.R, maps.n, paths.device
+    mp = torch.empty(n, R, R, dtype=torch.uint8, device=dev) if want_path else None
+    ms = torch.empty(n, R, R, dtype=torch.uint8, device=dev) if want_space else None
+    with torch.cuda.device(dev):
+        rc = L.lib.ppn_label_masks(C.byref(paths.struct), C.byref(maps.struct), paths.n, placements, R,
+                                   R if bound is None else int(bound), _ptr(mp), _ptr(ms), _stream_ptr(dev))
+    L.check(rc, "ppn_label_masks")
+    return mp, ms
+
+
 def boundary_check(hull, angle_deg, translation_rc, resolution, return_hull=False):
     """Path.boundary_check for n (angle, translation) pairs against one hull [h,2] (device tensors)."""
     n = angle_deg.shape[0]

@@ -410,6 +410,24 @@ def fixture_plan_tail(PM):
                         init=np.array([3.4, 61.5]), end=np.array([30.5, 31.5]))
 
 
+# ----------------------------------------------------------------------------- G14 mask_path labels
+def fixture_gen_path(PM):
+    """generate_gen_path (process_map.py:148-163): every 5th label point -> 255 on a 224x224 'L' PNG."""
+    from PIL import Image
+    import torchvision
+    class _ToPIL:                                            # ToPILImage on a float HxW array with values {0,255}
+        def __call__(self, a):
+            return Image.fromarray(np.asarray(a, dtype=np.float32), mode="F")
+    torchvision.transforms.ToPILImage = _ToPIL
+    g = np.load(os.path.join(OUT, "g10_config1_R64.npz"))
+    pts = g["pathpoint"][:6] * (224 / 64)                    # config-1 label points scaled to the hard-coded 224 canvas
+    tmp = tempfile.mkdtemp()
+    with quiet():
+        PM.generate_gen_path(list(pts), 0, root=tmp)
+    masks = np.stack([np.asarray(Image.open(os.path.join(tmp, f"{i}.png"))) for i in range(len(pts))])
+    np.savez_compressed(os.path.join(OUT, "g14_gen_path.npz"), pathpoint=pts, mask=masks.astype(np.uint8))
+
+
 # ----------------------------------------------------------------------------- G13 AE-ViT
 def fixture_aevit():
     """GenNet AEViT(1,1,R,24) (GenNet/networks/ae_vit.py:12-76, the model predict.py:46 builds) with seeded
@@ -445,6 +463,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "aevit":
         fixture_aevit()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "gen_path":
+        sys.path.insert(0, REF)
+        import process_map as PM
+        fixture_gen_path(PM)
+        return
     sys.path.insert(0, REF)
     import PathSeg as PathSegMod
     import Path as PathMod
@@ -459,6 +482,7 @@ def main():
         print("config-1 fixture: reference did not terminate within 1500 s (seed 0)", flush=True)
     import process_map as PM
     fixture_plan_tail(PM)
+    fixture_gen_path(PM)
     sys.path.remove(REF)
     for mod in ("utils",):
         sys.modules.pop(mod, None)

@@ -285,6 +285,31 @@ def test_corridor_compose_skip_is_exact(dev, R, clearance):
     assert torch.equal(a.pathpoint, b.pathpoint)
 
 
+def test_label_masks_vs_oracle_and_reference_golden(dev, golden_dir):
+    import torch
+    from ppnet_amd import edage
+    R, K, n, placements, seed = 128, 10, 5, 4, 17
+    pb = edage.generate_paths(n, R, 50, 3, seed=seed, device=dev)
+    mb = edage.generate_maps(pb, placements, 5, K, seed=seed)
+    mp, ms = edage.label_masks(pb, mb, placements)
+    torch.cuda.synchronize()
+    precs = oracle_paths(seed, n, R, 50, 3)
+    maps = oracle_maps(seed, precs, R, 50, 5, K, 3, placements)
+    for m, om in enumerate(maps):
+        omp, oms = E.label_masks(precs[m // placements], om["angle"], om["translation"], om["pathpoint"], R)
+        assert np.array_equal(_np(mp[m]), omp) and np.array_equal(_np(ms[m]), oms)            # bit-exact
+        # the corridor is free in the occupancy grid the same kernel family wrote
+        assert (_np(mb.grid[m])[oms.astype(bool)] != 0).all()
+    # the reference's own generate_gen_path output (224 canvas), label points fed in
+    g = np.load(os.path.join(golden_dir, "g14_gen_path.npz"))
+    k = len(g["pathpoint"])
+    pb2 = edage.PathsBatch(1, 224, 50, 3, dev)
+    mb2 = edage.MapsBatch(k, 224, 1, dev)
+    mb2.pathpoint.copy_(torch.tensor(g["pathpoint"], device=dev))
+    mp2, _ = edage.label_masks(pb2, mb2, k, bound=224, want_space=False)
+    assert np.array_equal(_np(mp2), g["mask"])
+
+
 def test_invalid_arguments_are_reported_not_fatal(dev):
     from ppnet_amd import edage, _lib
     with pytest.raises(ValueError):

@@ -248,3 +248,12 @@ def test_disc_raster_rule():
     assert occ[2, 4] and occ[1, 4] and occ[3, 4] and occ[2, 3] and occ[2, 5]
     assert occ.sum() == 5
     assert E.disc_raster(np.zeros([0, 3]), 8).sum() == 0
+
+
+# ------------------------------------------------------------------ G14 label masks (next row)
+def test_mask_path_matches_reference(golden_dir):
+    g = _load(golden_dir, "g14_gen_path.npz")
+    prec = dict(space=np.zeros([224, 224], bool))
+    for pts, want in zip(g["pathpoint"], g["mask"]):
+        mp, _ = E.label_masks(prec, 0.0, [0, 0], pts, 224, bound=224)
+        assert np.array_equal(mp, want)
