@@ -156,7 +156,7 @@ def test_config1_labels_vs_reference_golden(dev, golden_dir):
 
 
 # ------------------------------------------------------------------ (2) HIP vs oracle, Philox mode
-@pytest.mark.parametrize("R,clearance,seed,n", [(64, 3, 1, 12), (256, 3, 0, 12), (224, 1, 5, 6), (128, 3, 9, 8)])
+@pytest.mark.parametrize("R,clearance,seed,n", [(64, 3, 1, 12), (256, 3, 0, 12), (224, 1, 5, 6), (128, 3, 9, 8), (512, 3, 2, 3)])
 def test_paths_and_maps_philox_vs_oracle(dev, R, clearance, seed, n):
     import torch
     from ppnet_amd import edage

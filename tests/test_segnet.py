@@ -128,3 +128,25 @@ def test_dinat_base_end_to_end_256():
     assert torch.isfinite(logits).all()
     # bf16 projections / convolutions (fp32 accumulate): the 2-class mask agrees on almost every pixel
     assert float((pred == pred16).float().mean()) > 0.97
+
+
+@pytest.mark.gpu
+def test_ppnet_pipeline_runs_at_512_and_224():
+    """BASELINE config 5 resolution (512) and the reference default (224): the whole plan() path on generator output."""
+    from ppnet_amd import edage
+    from ppnet_amd.ppnet import PPNet
+    dev = torch.device("cuda:0")
+    for R, bound_ok in ((512, True), (224, True)):
+        pb = edage.generate_paths(2, R, 50, 3, seed=3, device=dev)
+        mb = edage.generate_maps(pb, 2, 5, 20, seed=3)
+        torch.manual_seed(0)
+        model = PPNet(R).to(dev).eval()
+        out = model.plan(mb.grid, mb.segpoint[:, 0].contiguous(), mb.segpoint[:, 10].contiguous(), mb.obstacles,
+                         mb.n_obstacles[:, 0].contiguous(), 1 / 50 * 224)
+        torch.cuda.synchronize()
+        assert out["ok"].shape == (4,) and out["waypoints"].shape[0] == 4 and out["collision"].dtype == torch.bool
+        mask = model.segment(mb.grid)
+        assert mask.shape == (4, R, R)
+        heat = model.heatmap(mask)
+        assert heat.shape == (4, R, R) and heat.dtype == torch.uint8
+        assert int(heat.reshape(4, -1).max(dim=1).values.min()) == 255          # per-sample min-max normalisation
