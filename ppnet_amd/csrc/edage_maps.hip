@@ -85,7 +85,8 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
     uint32_t* occw = reinterpret_cast<uint32_t*>(shareA);
     double (*cand)[3] = reinterpret_cast<double (*)[3]>(shareA + shareA_bytes);
     double (*obs)[3] = reinterpret_cast<double (*)[3]>(shareA + shareA_bytes + (size_t)K * 24);
-    float2* poddf = reinterpret_cast<float2*>(shareA + shareA_bytes + (size_t)K * 24 + (size_t)(K + PPN_MAX_POCKET) * 24);
+    // float copy of the odd points as pairs [x0, x1, y0, y1] so the pre-pass runs on packed (v_pk_*_f32) math
+    float* poddf = reinterpret_cast<float*>(shareA + shareA_bytes + (size_t)K * 24 + (size_t)(K + PPN_MAX_POCKET) * 24);
     uint64_t* lut = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(poddf) + (PPN_PATH_POINTS / 2) * 8);
     uint32_t flags = 0;
     PPN_STAMP_INIT;
@@ -195,7 +196,11 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
         rot2(c, s, pq.x - half, pq.y - half, rx, ry);
         rx = rx + half + tr0;
         ry = ry + half + tr1;
-        if (q & 1) { podd[q >> 1][0] = rx; podd[q >> 1][1] = ry; poddf[q >> 1] = make_float2((float)rx, (float)ry); }
+        if (q & 1) {
+            const int k = q >> 1;
+            podd[k][0] = rx; podd[k][1] = ry;
+            poddf[(k >> 1) * 4 + (k & 1)] = (float)rx; poddf[(k >> 1) * 4 + 2 + (k & 1)] = (float)ry;
+        }
         if (O.pathpoint) *reinterpret_cast<double2*>(O.pathpoint + ((size_t)m * PPN_PATH_POINTS + q) * 2) = make_double2(rx, ry);
     }
     if (tid < PPN_SEGS + 1) {                                             // MapGenerate.py:70-74
@@ -234,12 +239,14 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
                 const double thr = cand[k][2] + c_px;
                 // float pre-pass: |error| of the float minimum distance is < 1e-3 px for coordinates < 2^10,
                 // so it decides every case that is not within 0.01 px of a threshold; those fall back to double
-                const float oxf = (float)ox, oyf = (float)oy;
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const v2f oxf = {(float)ox, (float)ox}, oyf = {(float)oy, (float)oy};
                 float mf = 3.0e38f;
-                for (int q = lane; q < PPN_PATH_POINTS / 2; q += 64) {
-                    const float2 pt = poddf[q];
-                    const float dx = pt.x - oxf, dy = pt.y - oyf;
-                    mf = fminf(mf, __fmaf_rn(dx, dx, dy * dy));
+                for (int q = lane; q < PPN_PATH_POINTS / 4; q += 64) {    // 250 pairs of odd points
+                    const float4 pr = *reinterpret_cast<const float4*>(poddf + 4 * q);
+                    const v2f dx = (v2f){pr.x, pr.y} - oxf, dy = (v2f){pr.z, pr.w} - oyf;
+                    const v2f d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
+                    mf = fminf(mf, fminf(d2.x, d2.y));
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) mf = fminf(mf, __shfl_xor(mf, o, 64));
@@ -312,38 +319,63 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
     // estimate it with a float sqrt, then settle both ends with the exact double predicate.
     const int wpr = R / 32;
     const double c3 = bc[8], s3 = bc[9];
-    for (int n = wv; n < n_obs; n += NW) {
+    // (obstacle, row) pairs are flattened over the whole workgroup: obstacle n owns rows [row_lo[n], row_lo[n] + cnt),
+    // an exclusive scan of the counts (wave 0, shuffles) gives each pair an index, a binary search gives it back.
+    int* row_lo = reinterpret_cast<int*>(cand);                            // the candidates are dead: reuse their bytes
+    int* row_off = row_lo + (K + PPN_MAX_POCKET);                          // [n_obs + 1] exclusive offsets
+    for (int n = tid; n < n_obs; n += NT) {
+        const double cy = obs[n][1], r = obs[n][2];
+        const int lo = max((int)floor(cy - r - 0.5), 0), hi = min((int)ceil(cy + r - 0.5), R - 1);
+        row_lo[n] = lo;
+        row_off[n + 1] = max(hi - lo + 1, 0);
+    }
+    __syncthreads();
+    if (wv == 0) {
+        int carry = 0;
+        for (int b0 = 0; b0 < n_obs; b0 += 64) {
+            const int n = b0 + lane;
+            int v = n < n_obs ? row_off[n + 1] : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+            if (n < n_obs) row_off[n + 1] = carry + v;
+            carry += __shfl(v, 63, 64);
+        }
+        if (lane == 0) row_off[0] = 0;
+    }
+    __syncthreads();
+    const int n_pairs = row_off[n_obs];
+    for (int pr = tid; pr < n_pairs; pr += NT) {
+        int lo_n = 0, hi_n = n_obs - 1;                                    // largest n with row_off[n] <= pr
+        while (lo_n < hi_n) { const int mid = (lo_n + hi_n + 1) >> 1; if (row_off[mid] <= pr) lo_n = mid; else hi_n = mid - 1; }
+        const int n = lo_n, i = row_lo[n] + (pr - row_off[n]);
         const double cx = obs[n][0], cy = obs[n][1], r = obs[n][2];
         const double rr = r * r;
-        const int i_lo = max((int)floor(cy - r - 0.5), 0), i_hi = min((int)ceil(cy + r - 0.5), R - 1);
-        for (int i = i_lo + lane; i <= i_hi; i += 64) {
-            const double dy = ((double)i + 0.5) - cy;
-            const double dy2 = dy * dy;
-            if (dy2 > rr) continue;                                       // dx*dx + dy2 >= dy2 > rr for every column
-            // real-valued ends of the interval in column units: j + 0.5 in [cx - w, cx + w]
-            const float w = sqrtf((float)(rr - dy2));
-            const float xl = (float)cx - w - 0.5f, xr = (float)cx + w - 0.5f;
-            int jl = (int)ceilf(xl), jh = (int)floorf(xr);
-            // the float estimate is good to < 1e-3 column; an end closer than that to an integer is settled
-            // with the exact double predicate (monotone in |dx|, so one step either way suffices)
-            if (fabsf(xl - rintf(xl)) < 2e-3f) {
-                jl = (int)rintf(xl);
-                while (disc_pred(jl - 1, cx, dy2, rr)) --jl;
-                while (jl <= jh + 1 && !disc_pred(jl, cx, dy2, rr)) ++jl;
-            }
-            if (fabsf(xr - rintf(xr)) < 2e-3f) {
-                jh = (int)rintf(xr);
-                while (disc_pred(jh + 1, cx, dy2, rr)) ++jh;
-                while (jh >= jl - 1 && !disc_pred(jh, cx, dy2, rr)) --jh;
-            }
-            jl = max(jl, 0); jh = min(jh, R - 1);
-            if (jl > jh) continue;
-            uint32_t* row = occw + (size_t)i * wpr;
-            for (int ww = jl >> 5; ww <= (jh >> 5); ++ww) {
-                const int lo = max(jl - ww * 32, 0), hi = min(jh - ww * 32, 31);
-                const uint32_t msk = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-                atomicOr(&row[ww], msk);
-            }
+        const double dy = ((double)i + 0.5) - cy;
+        const double dy2 = dy * dy;
+        if (dy2 > rr) continue;                                           // dx*dx + dy2 >= dy2 > rr for every column
+        // real-valued ends of the interval in column units: j + 0.5 in [cx - w, cx + w]
+        const float w = sqrtf((float)(rr - dy2));
+        const float xl = (float)cx - w - 0.5f, xr = (float)cx + w - 0.5f;
+        int jl = (int)ceilf(xl), jh = (int)floorf(xr);
+        // the float estimate is good to < 1e-3 column; an end closer than that to an integer is settled
+        // with the exact double predicate (monotone in |dx|, so one step either way suffices)
+        if (fabsf(xl - rintf(xl)) < 2e-3f) {
+            jl = (int)rintf(xl);
+            while (disc_pred(jl - 1, cx, dy2, rr)) --jl;
+            while (jl <= jh + 1 && !disc_pred(jl, cx, dy2, rr)) ++jl;
+        }
+        if (fabsf(xr - rintf(xr)) < 2e-3f) {
+            jh = (int)rintf(xr);
+            while (disc_pred(jh + 1, cx, dy2, rr)) ++jh;
+            while (jh >= jl - 1 && !disc_pred(jh, cx, dy2, rr)) --jh;
+        }
+        jl = max(jl, 0); jh = min(jh, R - 1);
+        if (jl > jh) continue;
+        uint32_t* row = occw + (size_t)i * wpr;
+        for (int ww = jl >> 5; ww <= (jh >> 5); ++ww) {
+            const int lo = max(jl - ww * 32, 0), hi = min(jh - ww * 32, 31);
+            const uint32_t msk = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+            atomicOr(&row[ww], msk);
         }
     }
     __syncthreads();
@@ -380,38 +412,39 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
     }
     PPN_STAMP(6);
 
-    // ------------------------------------------------------------------ raster 3: bits -> bytes, 16-byte stores
-    // (8 bits -> 8 bytes through the LDS table; the two 7x7 marker squares touch at most 28 chunks)
+    // ------------------------------------------------------------------ raster 3: bits -> bytes, two 16-byte stores
+    // per lane per step (8 bits -> 8 bytes through the LDS table; the two 7x7 marker squares touch <= 28 words)
     {
         const int r_init = (int)rint(bc[2]), c_init = (int)rint(bc[3]);   // process_map.py:127-135
         const int r_end = (int)rint(bc[4]), c_end = (int)rint(bc[5]);
-        const int cpr = R / 16;
-        const int sh = (cpr & (cpr - 1)) == 0 ? 31 - __clz(cpr) : -1;     // log2(cpr) when R/16 is a power of two
+        const int sh = (wpr & (wpr - 1)) == 0 ? 31 - __clz(wpr) : -1;     // log2(words per row) when R/32 is a power of two
         uint8_t* g = O.grid + (size_t)m * R * R;
-        for (int ch = tid; ch < R * cpr; ch += NT) {
-            const int i = sh >= 0 ? (ch >> sh) : (ch / cpr);
-            const int jc16 = ch - i * cpr, j0 = jc16 * 16;
-            const uint32_t occ = (occw[(size_t)i * wpr + (jc16 >> 1)] >> ((jc16 & 1) * 16)) & 0xffffu;
-            uint64_t lo8 = lut[occ & 0xffu], hi8 = lut[occ >> 8];
+        for (int w = tid; w < words; w += NT) {
+            const int i = sh >= 0 ? (w >> sh) : (w / wpr);
+            const int j0 = (w - i * wpr) * 32;
+            const uint32_t occ = occw[w];
+            uint64_t q0 = lut[occ & 0xffu], q1 = lut[(occ >> 8) & 0xffu], q2 = lut[(occ >> 16) & 0xffu], q3 = lut[occ >> 24];
             const bool ri = (i >= r_init - 3) && (i <= r_init + 3), re = (i >= r_end - 3) && (i <= r_end + 3);
             if (ri || re) {
                 uint32_t mark = 0u;
                 if (ri) {
-                    const int lo = max(c_init - 3 - j0, 0), hi = min(c_init + 3 - j0, 15);
-                    if (lo <= hi) mark |= ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
+                    const int lo = max(c_init - 3 - j0, 0), hi = min(c_init + 3 - j0, 31);
+                    if (lo <= hi) mark |= (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
                 }
                 if (re) {
-                    const int lo = max(c_end - 3 - j0, 0), hi = min(c_end + 3 - j0, 15);
-                    if (lo <= hi) mark |= ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
+                    const int lo = max(c_end - 3 - j0, 0), hi = min(c_end + 3 - j0, 31);
+                    if (lo <= hi) mark |= (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
                 }
                 if (mark) {                                               // MARK = 0x80 over whatever is there
-                    const uint64_t ml = ~lut[mark & 0xffu], mh = ~lut[mark >> 8];    // 0xFF where marked
-                    lo8 = (lo8 & ~ml) | (ml & 0x8080808080808080ull);
-                    hi8 = (hi8 & ~mh) | (mh & 0x8080808080808080ull);
+                    const uint64_t m0 = ~lut[mark & 0xffu], m1 = ~lut[(mark >> 8) & 0xffu], m2 = ~lut[(mark >> 16) & 0xffu],
+                                   m3 = ~lut[mark >> 24];                 // 0xFF where marked
+                    q0 = (q0 & ~m0) | (m0 & 0x8080808080808080ull); q1 = (q1 & ~m1) | (m1 & 0x8080808080808080ull);
+                    q2 = (q2 & ~m2) | (m2 & 0x8080808080808080ull); q3 = (q3 & ~m3) | (m3 & 0x8080808080808080ull);
                 }
             }
-            *reinterpret_cast<uint4*>(g + (size_t)i * R + j0) =
-                make_uint4((uint32_t)lo8, (uint32_t)(lo8 >> 32), (uint32_t)hi8, (uint32_t)(hi8 >> 32));
+            uint4* dst = reinterpret_cast<uint4*>(g + (size_t)i * R + j0);
+            dst[0] = make_uint4((uint32_t)q0, (uint32_t)(q0 >> 32), (uint32_t)q1, (uint32_t)(q1 >> 32));
+            dst[1] = make_uint4((uint32_t)q2, (uint32_t)(q2 >> 32), (uint32_t)q3, (uint32_t)(q3 >> 32));
         }
     }
     PPN_STAMP(7);
