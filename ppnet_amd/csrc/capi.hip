@@ -179,10 +179,10 @@ int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements
         const char* f = getenv("PPN_FORCE_COMPOSE");
         prm.force_compose = (f && f[0] == '1') ? 1 : 0;
     }
-    // dynamic LDS: corridor mask + shared region (odd path points, then occupancy bits) + candidates + obstacles
-    const size_t shareA = (size_t)R * R / 8 > 8000 ? (size_t)R * R / 8 : 8000;
-    const size_t lds = (size_t)R * R / 8 + shareA + (size_t)K * 24 + (size_t)(K + PPN_MAX_POCKET) * 24 +
-                       (PPN_PATH_POINTS / 2) * 8 + 256 * 8;
+    // dynamic LDS: staged path points / occupancy bits + candidates + obstacles + float points + byte LUT + pocket rows
+    const size_t regionP = (size_t)R * R / 8 > (size_t)PPN_PATH_POINTS * 16 ? (size_t)R * R / 8 : (size_t)PPN_PATH_POINTS * 16;
+    const size_t lds = regionP + (size_t)K * 24 + (size_t)(K + PPN_MAX_POCKET) * 24 + (PPN_PATH_POINTS / 2) * 8 + 256 * 8 +
+                       (size_t)PPN_MAX_POCKET * 24;
     PPN_HIP(hipFuncSetAttribute((const void*)ppn::edage_maps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(ppn::edage_maps_kernel, dim3((unsigned)n_maps), dim3(256), lds, (hipStream_t)stream, prm);
     PPN_HIP(hipGetLastError());

@@ -49,13 +49,14 @@ __device__ __forceinline__ uint32_t expand4(uint32_t b) {
 
 __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
     // dynamic LDS carve (all 8-byte aligned):
-    //   space [R*R/32 u32]  the target path's corridor mask
-    //   shareA [max(R*R/8, 8000) B]  odd path points (500 x 2 f64) until the filter is done, then the
-    //                                 occupancy bit mask (R*R bits)
-    //   cand  [K][3] f64   candidates (row, col, r)
+    //   regionP [max(16000, R*R/8) B]  the target path's 1000 image-frame points (staged by waves 1-3 while wave 0
+    //                                   runs the placement loop); after the filter the same bytes hold the R*R-bit
+    //                                   occupancy mask
+    //   cand  [K][3] f64   candidates (row, col, r); later the raster's row tables
     //   obs   [K+64][3] f64  kept + pocket obstacles (col, row, r)
-    //   poddf [500][2] f32  float copy of the odd path points (filter pre-pass)
-    //   lut   [256] u64     8 occupancy bits -> 8 grid bytes
+    //   poddf [1000] f32   float copy of the transformed odd points as pairs [x0,x1,y0,y1] (filter pre-pass)
+    //   lut   [256] u64    8 occupancy bits -> 8 grid bytes
+    //   praw  [64][3] f64  the path's pocket obstacles as stored by stage A
     extern __shared__ uint64_t lds_raw[];
     __shared__ double hullc[PPN_MAX_HULL][2];     // hull - R/2
     __shared__ double bc[12];
@@ -78,36 +79,42 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
     const ppn_paths_t& P = prm.paths;
     const ppn_maps_t& O = prm.out;
     const int words = R * R / 32;
-    const int shareA_bytes = max(R * R / 8, (PPN_PATH_POINTS / 2) * 16);
-    uint32_t* space = reinterpret_cast<uint32_t*>(lds_raw);
-    unsigned char* shareA = reinterpret_cast<unsigned char*>(lds_raw) + (size_t)words * 4;
-    double (*podd)[2] = reinterpret_cast<double (*)[2]>(shareA);
-    uint32_t* occw = reinterpret_cast<uint32_t*>(shareA);
-    double (*cand)[3] = reinterpret_cast<double (*)[3]>(shareA + shareA_bytes);
-    double (*obs)[3] = reinterpret_cast<double (*)[3]>(shareA + shareA_bytes + (size_t)K * 24);
-    // float copy of the odd points as pairs [x0, x1, y0, y1] so the pre-pass runs on packed (v_pk_*_f32) math
-    float* poddf = reinterpret_cast<float*>(shareA + shareA_bytes + (size_t)K * 24 + (size_t)(K + PPN_MAX_POCKET) * 24);
+    const int regionP_bytes = max(R * R / 8, PPN_PATH_POINTS * 16);
+    unsigned char* lds = reinterpret_cast<unsigned char*>(lds_raw);
+    double2* pimg = reinterpret_cast<double2*>(lds);
+    uint32_t* occw = reinterpret_cast<uint32_t*>(lds);
+    double (*cand)[3] = reinterpret_cast<double (*)[3]>(lds + regionP_bytes);
+    double (*obs)[3] = reinterpret_cast<double (*)[3]>(lds + regionP_bytes + (size_t)K * 24);
+    float* poddf = reinterpret_cast<float*>(lds + regionP_bytes + (size_t)K * 24 + (size_t)(K + PPN_MAX_POCKET) * 24);
     uint64_t* lut = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(poddf) + (PPN_PATH_POINTS / 2) * 8);
+    double (*praw)[3] = reinterpret_cast<double (*)[3]>(reinterpret_cast<unsigned char*>(lut) + 256 * 8);
     uint32_t flags = 0;
     PPN_STAMP_INIT;
 
-    for (int w = tid; w < words; w += NT) space[w] = P.space_bits[(size_t)pj * words + w];
     const int hn = P.hull_n[pj];
-    if (tid < PPN_MAX_HULL) {
-        hullc[tid][0] = P.hull[((size_t)pj * PPN_MAX_HULL + tid) * 2] - half;
-        hullc[tid][1] = P.hull[((size_t)pj * PPN_MAX_HULL + tid) * 2 + 1] - half;
-    }
-    if (tid == 0) bci[12] = prm.force_compose;                            // "some obstacle may touch the corridor"
-    {   // byte-expansion table: bit k of the index set (= occupied) -> byte k 0x00, clear -> 0xFF
-        uint64_t v = 0ull;
+    const int n_pocket = P.n_obstacles[pj];
+    if (wv == 0) {
+        // wave 0: hull, then straight into the placement loop (same wave: LDS keeps program order)
+        hullc[lane][0] = P.hull[((size_t)pj * PPN_MAX_HULL + lane) * 2] - half;
+        hullc[lane][1] = P.hull[((size_t)pj * PPN_MAX_HULL + lane) * 2 + 1] - half;
+        if (lane == 0) bci[12] = prm.force_compose;                       // "some obstacle may touch the corridor"
+    } else {
+        // waves 1..3, concurrently with the placement: stage everything that does not depend on it
+        const int t3 = tid - 64;
+        for (int q = t3; q < PPN_PATH_POINTS; q += NT - 64)
+            pimg[q] = *reinterpret_cast<const double2*>(P.pathpoint_image + ((size_t)pj * PPN_PATH_POINTS + q) * 2);
+        for (int q = t3; q < n_pocket; q += NT - 64) {
+            const double* o = P.obstacles + ((size_t)pj * PPN_MAX_POCKET + q) * 3;
+            praw[q][0] = o[0]; praw[q][1] = o[1]; praw[q][2] = o[2];
+        }
+        for (int e = t3; e < 256; e += NT - 64) {   // byte-expansion table: bit k set (= occupied) -> byte k 0x00, clear -> 0xFF
+            uint64_t v = 0ull;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v |= ((tid >> k) & 1) ? 0ull : (0xFFull << (8 * k));
-        lut[tid] = v;
-    }
-    // K random obstacle candidates (MapGenerate.py:128-136) do not depend on the placement: waves 1..3
-    // draw them while wave 0 runs the placement loop
-    if (wv > 0 || K > 192) {
-        for (int k = (K > 192 ? tid : tid - 64); k < K; k += (K > 192 ? NT : NT - 64)) {
+            for (int k = 0; k < 8; ++k) v |= ((e >> k) & 1) ? 0ull : (0xFFull << (8 * k));
+            lut[e] = v;
+        }
+        // K random obstacle candidates (MapGenerate.py:128-136)
+        for (int k = t3; k < K; k += NT - 64) {
             double ux, uy, us;
             if (prm.obst_draws) {
                 const double* d = prm.obst_draws + (size_t)m * 3 * K;
@@ -122,7 +129,6 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
             cand[k][2] = us * prm.obstacles_size / prm.map_size * Rd;
         }
     }
-    __syncthreads();
     PPN_STAMP(0);
 
     // ------------------------------------------------------------------ placement: wave 0, one attempt per lane
@@ -191,14 +197,13 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
 
     // ------------------------------------------------------------------ labels
     for (int q = tid; q < PPN_PATH_POINTS; q += NT) {                     // MapGenerate.py:76-80
-        const double2 pq = *reinterpret_cast<const double2*>(P.pathpoint_image + ((size_t)pj * PPN_PATH_POINTS + q) * 2);
+        const double2 pq = pimg[q];
         double rx, ry;
         rot2(c, s, pq.x - half, pq.y - half, rx, ry);
         rx = rx + half + tr0;
         ry = ry + half + tr1;
         if (q & 1) {
             const int k = q >> 1;
-            podd[k][0] = rx; podd[k][1] = ry;
             poddf[(k >> 1) * 4 + (k & 1)] = (float)rx; poddf[(k >> 1) * 4 + 2 + (k & 1)] = (float)ry;
         }
         if (O.pathpoint) *reinterpret_cast<double2*>(O.pathpoint + ((size_t)m * PPN_PATH_POINTS + q) * 2) = make_double2(rx, ry);
@@ -252,9 +257,14 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
                 for (int o = 32; o > 0; o >>= 1) mf = fminf(mf, __shfl_xor(mf, o, 64));
                 double mn = (double)sqrtf(mf);
                 if (fabs(mn - thr) < 0.01 || fabs(mn - cand[k][2] - touch_margin) < 0.01) {
-                    double md = 1e300;
+                    double md = 1e300;                                     // rare: redo in double from the staged points
                     for (int q = lane; q < PPN_PATH_POINTS / 2; q += 64) {
-                        const double dx = podd[q][0] - ox, dy = podd[q][1] - oy;
+                        const double2 pq = pimg[2 * q + 1];
+                        double px, py;
+                        rot2(c, s, pq.x - half, pq.y - half, px, py);
+                        px = px + half + tr0;
+                        py = py + half + tr1;
+                        const double dx = px - ox, dy = py - oy;
                         md = fmin(md, dx * dx + dy * dy);
                     }
                     mn = sqrt(wave_min(md));
@@ -283,22 +293,20 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
         if (tid == 0) {
             bci[4] = n_rand;
             // pocket obstacles keep >= c_px from the odd path points by construction (Path.py:490-491)
-            if (P.n_obstacles[pj] > 0 && !(c_px > touch_margin)) bci[12] = 1;
+            if (n_pocket > 0 && !(c_px > touch_margin)) bci[12] = 1;
         }
     }
     __syncthreads();
     PPN_STAMP(3);
     const int n_rand = bci[4];
-    const int n_pocket = P.n_obstacles[pj];
     if (tid < n_pocket) {                                                 // MapGenerate.py:83-89
-        const double* o = P.obstacles + ((size_t)pj * PPN_MAX_POCKET + tid) * 3;
         double rx, ry;
-        rot2(c, s, o[1] - half, o[0] - half, rx, ry);
+        rot2(c, s, praw[tid][1] - half, praw[tid][0] - half, rx, ry);
         rx = rx + half + tr0;
         ry = ry + half + tr1;
-        obs[n_rand + tid][0] = ry; obs[n_rand + tid][1] = rx; obs[n_rand + tid][2] = o[2];
+        obs[n_rand + tid][0] = ry; obs[n_rand + tid][1] = rx; obs[n_rand + tid][2] = praw[tid][2];
     }
-    // podd is dead from here: its bytes become the occupancy bit mask
+    // the staged points are dead from here: their bytes become the occupancy bit mask
     for (int w = tid; w < words; w += NT) occw[w] = 0u;
     __syncthreads();
     const int n_obs = n_rand + n_pocket;
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
                     const int jj = (int)rint(xs + (half - 0.5)), ii = (int)rint(ys + (half - 0.5));
                     if (ii >= 0 && ii < R && jj >= 0 && jj < R) {
                         const int bit = ii * R + jj;
-                        clr = (space[bit >> 5] >> (bit & 31)) & 1u;
+                        clr = (P.space_bits[(size_t)pj * words + (bit >> 5)] >> (bit & 31)) & 1u;   // rare pass: straight from L2
                     }
                 }
             }
