@@ -29,6 +29,10 @@ __device__ unsigned long long g_phase_cycles[16];
 #define PPN_STAMP_INIT do {} while (0)
 #endif
 
+#ifndef PPN_FILTER_CH
+#define PPN_FILTER_CH 2      // obstacles per wave swept together in the clearance filter; 2 / 4 / 8 measured equal (VGPRs 7x / 86 / 106)
+#endif
+
 namespace {
 constexpr int NT = 256;
 constexpr int NW = NT / 64;
@@ -61,6 +65,7 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
     __shared__ double hullc[PPN_MAX_HULL][2];     // hull - R/2
     __shared__ double bc[12];
     __shared__ int bci[16];                       // [0..3] placement, [4..11] filter ballots, [12] corridor-touch flag
+    __shared__ float fmin_w[NW][PPN_FILTER_CH];               // per-wave float minima of the clearance filter
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // XCD-aware block -> map assignment: blocks b and b+8 share an XCD (round-robin dispatch), so
@@ -93,6 +98,7 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
 
     const int hn = P.hull_n[pj];
     const int n_pocket = P.n_obstacles[pj];
+    const uint32_t path_flags = P.flags[pj];
     if (wv == 0) {
         // wave 0: hull, then straight into the placement loop (same wave: LDS keeps program order)
         hullc[lane][0] = P.hull[((size_t)pj * PPN_MAX_HULL + lane) * 2] - half;
@@ -101,8 +107,15 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
     } else {
         // waves 1..3, concurrently with the placement: stage everything that does not depend on it
         const int t3 = tid - 64;
-        for (int q = t3; q < PPN_PATH_POINTS; q += NT - 64)
-            pimg[q] = *reinterpret_cast<const double2*>(P.pathpoint_image + ((size_t)pj * PPN_PATH_POINTS + q) * 2);
+        {   // 1000 points over 192 lanes: issue every load before the first LDS store (one L2 round trip, not six)
+            constexpr int PER = (PPN_PATH_POINTS + (NT - 64) - 1) / (NT - 64);
+            const double2* src = reinterpret_cast<const double2*>(P.pathpoint_image) + (size_t)pj * PPN_PATH_POINTS;
+            double2 r[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) { const int q = t3 + k * (NT - 64); r[k] = src[q < PPN_PATH_POINTS ? q : 0]; }
+#pragma unroll
+            for (int k = 0; k < PER; ++k) { const int q = t3 + k * (NT - 64); if (q < PPN_PATH_POINTS) pimg[q] = r[k]; }
+        }
         for (int q = t3; q < n_pocket; q += NT - 64) {
             const double* o = P.obstacles + ((size_t)pj * PPN_MAX_POCKET + q) * 3;
             praw[q][0] = o[0]; praw[q][1] = o[1]; praw[q][2] = o[2];
@@ -239,39 +252,66 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
         int n_rand = 0;
         for (int k0 = 0; k0 < K; k0 += 64) {                              // K <= 256: at most 4 groups of 64
             unsigned long long accm = 0ull;                              // accept bits of this wave's obstacles
-            for (int k = k0 + wv; k < min(K, k0 + 64); k += NW) {
-                const double ox = cand[k][0], oy = cand[k][1];
-                const double thr = cand[k][2] + c_px;
-                // float pre-pass: |error| of the float minimum distance is < 1e-3 px for coordinates < 2^10,
-                // so it decides every case that is not within 0.01 px of a threshold; those fall back to double
-                typedef float v2f __attribute__((ext_vector_type(2)));
-                const v2f oxf = {(float)ox, (float)ox}, oyf = {(float)oy, (float)oy};
-                float mf = 3.0e38f;
+            // this wave's obstacles of the group are k0 + wv, k0 + wv + 4, ...; eight at a time their float minima are
+            // accumulated in one sweep over the points and reduced as independent shuffle chains (latencies overlap)
+            constexpr int CH = PPN_FILTER_CH;
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            for (int j0 = 0; k0 + wv + j0 * NW < min(K, k0 + 64); j0 += CH) {
+                float mfv[CH], oxf[CH], oyf[CH];
+                int nk = 0;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int k = k0 + wv + (j0 + j) * NW;
+                    const bool in = k < min(K, k0 + 64);
+                    oxf[j] = in ? (float)cand[k][0] : 0.0f; oyf[j] = in ? (float)cand[k][1] : 0.0f;
+                    mfv[j] = 3.0e38f;
+                    nk += in ? 1 : 0;
+                }
                 for (int q = lane; q < PPN_PATH_POINTS / 4; q += 64) {    // 250 pairs of odd points
                     const float4 pr = *reinterpret_cast<const float4*>(poddf + 4 * q);
-                    const v2f dx = (v2f){pr.x, pr.y} - oxf, dy = (v2f){pr.z, pr.w} - oyf;
-                    const v2f d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
-                    mf = fminf(mf, fminf(d2.x, d2.y));
+                    const v2f px = {pr.x, pr.y}, py = {pr.z, pr.w};
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        if (j < nk) {
+                            const v2f dx = px - (v2f){oxf[j], oxf[j]}, dy = py - (v2f){oyf[j], oyf[j]};
+                            const v2f d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
+                            mfv[j] = fminf(mfv[j], fminf(d2.x, d2.y));
+                        }
+                    }
                 }
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mf = fminf(mf, __shfl_xor(mf, o, 64));
-                double mn = (double)sqrtf(mf);
-                if (fabs(mn - thr) < 0.01 || fabs(mn - cand[k][2] - touch_margin) < 0.01) {
-                    double md = 1e300;                                     // rare: redo in double from the staged points
-                    for (int q = lane; q < PPN_PATH_POINTS / 2; q += 64) {
-                        const double2 pq = pimg[2 * q + 1];
-                        double px, py;
-                        rot2(c, s, pq.x - half, pq.y - half, px, py);
-                        px = px + half + tr0;
-                        py = py + half + tr1;
-                        const double dx = px - ox, dy = py - oy;
-                        md = fmin(md, dx * dx + dy * dy);
-                    }
-                    mn = sqrt(wave_min(md));
+                for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) if (j < nk) mfv[j] = fminf(mfv[j], __shfl_xor(mfv[j], o, 64));
+                // decisions read the minima back from LDS so this loop stays rolled (a rare double fallback sits in it)
+                if (lane == 0) {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) fmin_w[wv][j] = mfv[j];
                 }
-                if (mn > thr) {
-                    accm |= 1ull << (k - k0);
-                    if (!(mn - cand[k][2] > touch_margin) && lane == 0) bci[12] = 1;
+                for (int j = 0; j < nk; ++j) {
+                    const int k = k0 + wv + (j0 + j) * NW;
+                    const double thr = cand[k][2] + c_px;
+                    // float pre-pass: |error| of the float minimum distance is < 1e-3 px for coordinates < 2^10,
+                    // so it decides every case that is not within 0.01 px of a threshold; those fall back to double
+                    double mn = (double)sqrtf(fmin_w[wv][j]);
+                    if (fabs(mn - thr) < 0.01 || fabs(mn - cand[k][2] - touch_margin) < 0.01) {
+                        const double ox = cand[k][0], oy = cand[k][1];
+                        double md = 1e300;                                 // rare: redo in double from the staged points
+                        for (int q = lane; q < PPN_PATH_POINTS / 2; q += 64) {
+                            const double2 pq = pimg[2 * q + 1];
+                            double ppx, ppy;
+                            rot2(c, s, pq.x - half, pq.y - half, ppx, ppy);
+                            ppx = ppx + half + tr0;
+                            ppy = ppy + half + tr1;
+                            const double dx = ppx - ox, dy = ppy - oy;
+                            md = fmin(md, dx * dx + dy * dy);
+                        }
+                        mn = sqrt(wave_min(md));
+                    }
+                    if (mn > thr) {
+                        accm |= 1ull << (k - k0);
+                        if (!(mn - cand[k][2] > touch_margin) && lane == 0) bci[12] = 1;
+                    }
                 }
             }
             if (lane == 0) { bci[4 + wv] = (int)(uint32_t)accm; bci[8 + wv] = (int)(uint32_t)(accm >> 32); }
@@ -317,7 +357,7 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
     if (tid == 0) {
         O.n_obstacles[(size_t)m * 2] = n_obs;
         O.n_obstacles[(size_t)m * 2 + 1] = n_rand;
-        O.flags[m] = flags | P.flags[pj];
+        O.flags[m] = flags | path_flags;
     }
     PPN_STAMP(4);
 
