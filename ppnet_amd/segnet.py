@@ -194,6 +194,46 @@ class SETRUPHead(nn.Module):
         return up(self.conv_seg(conv(x)).contiguous())                       # 2 channels: the library bilinear kernel
 
 
+class UPerHead(nn.Module):
+    """UPerNet head (SegNet/mmseg/decode_heads/uper_head.py:12-127 + psp_head.py:10-60): pyramid pooling on the last level,
+    lateral 1x1 convs, top-down bilinear fusion, 3x3 FPN convs, concatenation, 3x3 bottleneck, 1x1 classifier.  Checkpoint
+    keys follow mmseg: `psp_modules.i.1.{conv,bn}`, `bottleneck.{conv,bn}`, `lateral_convs.i.{conv,bn}`,
+    `fpn_convs.i.{conv,bn}`, `fpn_bottleneck.{conv,bn}`, `conv_seg`.  The head of the reference's default SegNet config
+    (SegNet/test.py:29-32 -> configs/nat/upernet_nat_base.py)."""
+
+    def __init__(self, in_channels=(128, 256, 512, 1024), channels=64, num_classes=2, pool_scales=(1, 2, 3, 6),
+                 in_index=(0, 1, 2, 3), dropout_ratio=0.1, align_corners=False, norm_cfg=None, **kwargs):
+        super().__init__()
+        self.in_index, self.align_corners = tuple(in_index), align_corners
+        self.psp_modules = nn.ModuleList(
+            nn.Sequential(nn.AdaptiveAvgPool2d(ps), _ConvModule(in_channels[-1], channels, 1)) for ps in pool_scales)
+        self.bottleneck = _ConvModule(in_channels[-1] + len(pool_scales) * channels, channels, 3)
+        self.lateral_convs = nn.ModuleList(_ConvModule(c, channels, 1) for c in in_channels[:-1])
+        self.fpn_convs = nn.ModuleList(_ConvModule(channels, channels, 3) for _ in in_channels[:-1])
+        self.fpn_bottleneck = _ConvModule(len(in_channels) * channels, channels, 3)
+        self.conv_seg = nn.Conv2d(channels, num_classes, 1)                  # Dropout2d is the identity at inference
+
+    def _resize(self, x, size):
+        return F.interpolate(x, size=size, mode="bilinear", align_corners=self.align_corners)
+
+    def forward(self, inputs):
+        inputs = [inputs[i] for i in self.in_index]
+        x = inputs[-1]
+        psp = torch.cat([x] + [self._resize(m(x), x.shape[2:]) for m in self.psp_modules], dim=1)
+        laterals = [conv(inputs[i]) for i, conv in enumerate(self.lateral_convs)] + [self.bottleneck(psp)]
+        for i in range(len(laterals) - 1, 0, -1):
+            laterals[i - 1] = laterals[i - 1] + self._resize(laterals[i], laterals[i - 1].shape[2:])
+        outs = [self.fpn_convs[i](laterals[i]) for i in range(len(laterals) - 1)] + [laterals[-1]]
+        outs = [outs[0]] + [self._resize(o, outs[0].shape[2:]) for o in outs[1:]]
+        return self.conv_seg(self.fpn_bottleneck(torch.cat(outs, dim=1)))
+
+
+NAT_BASE_UPER = dict(   # SegNet/configs/nat/upernet_nat_base.py:6-34 (the default config of SegNet/test.py:29-32)
+    backbone=dict(embed_dim=128, mlp_ratio=2.0, depths=[3, 4, 18, 5], num_heads=[4, 8, 16, 32], kernel_size=7,
+                  layer_scale=1e-5),
+    decode_head=dict(type="UPerHead", in_channels=[128, 256, 512, 1024], in_index=[0, 1, 2, 3], pool_scales=(1, 2, 3, 6),
+                     channels=64, num_classes=2))
+
 DINAT_BASE = dict(   # SegNet/configs/dinat/dinat_base.py:5-24 over _base_/models/dinat.py:3-46
     backbone=dict(embed_dim=128, mlp_ratio=2.0, depths=[3, 4, 18, 5], num_heads=[4, 8, 16, 32], kernel_size=7,
                   layer_scale=1e-5,
@@ -210,7 +250,9 @@ class SegNet(nn.Module):
     def __init__(self, backbone=None, decode_head=None):
         super().__init__()
         self.backbone = DiNAT(**(backbone or DINAT_BASE["backbone"]))
-        self.decode_head = SETRUPHead(**(decode_head or DINAT_BASE["decode_head"]))
+        head_cfg = dict(decode_head or DINAT_BASE["decode_head"])
+        head_type = head_cfg.pop("type", "SETRUPHead")
+        self.decode_head = {"SETRUPHead": SETRUPHead, "UPerHead": UPerHead}[head_type](**head_cfg)
         self.align_corners = self.decode_head.align_corners
         if self.decode_head.in_index in (-1, self.backbone.num_levels - 1):
             # SETR-UP reads only the last level: skip the per-level norm + NHWC->NCHW copies nobody consumes
@@ -220,8 +262,9 @@ class SegNet(nn.Module):
         """After the checkpoint is loaded: fold each head BatchNorm into its convolution (exact algebra in float32,
         W' = W * g/sqrt(v+eps), b' = beta - mu * g/sqrt(v+eps)) and put every convolution weight in channels_last, so
         the whole network runs on NHWC tensors with no layout copies.  Changes the state-dict layout: load first."""
-        for up in self.decode_head.up_convs:
-            cm = up[0]
+        cms = [up[0] for up in self.decode_head.up_convs] if isinstance(self.decode_head, SETRUPHead) else \
+              [m for m in self.decode_head.modules() if isinstance(m, _ConvModule)]
+        for cm in cms:
             if isinstance(cm.bn, nn.BatchNorm2d):
                 bn, conv = cm.bn, cm.conv
                 scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()

@@ -28,6 +28,21 @@ def test_dinat_base_checkpoint_layout():
     assert 85e6 < n < 95e6                                                # DiNAT-Base ~ 90 M parameters
 
 
+def test_nat_upernet_default_config_layout():
+    """The reference's default SegNet (SegNet/test.py:29-32): NAT-Base + UPerHead(channels=64)."""
+    from ppnet_amd.segnet import NAT_BASE_UPER, SegNet
+    m = SegNet(**NAT_BASE_UPER)
+    sd = m.state_dict()
+    for k in ["decode_head.psp_modules.0.1.conv.weight", "decode_head.psp_modules.3.1.bn.running_mean",
+              "decode_head.bottleneck.conv.weight", "decode_head.lateral_convs.2.bn.weight", "decode_head.fpn_convs.0.conv.weight",
+              "decode_head.fpn_bottleneck.conv.weight", "decode_head.conv_seg.weight"]:
+        assert k in sd, k
+    assert sd["decode_head.bottleneck.conv.weight"].shape == (64, 1024 + 4 * 64, 3, 3)
+    assert sd["decode_head.fpn_bottleneck.conv.weight"].shape == (64, 256, 3, 3)
+    assert all(b.attn.dilation == 1 for lvl in m.backbone.levels for b in lvl.blocks)       # NAT: no dilations
+    assert m.backbone.compute_indices == (0, 1, 2, 3)                                        # UPerNet reads every level
+
+
 def _reference_nat_forward(m, x):
     """float64 CPU evaluation of a ppnet_amd.segnet.NAT's weights, written out op by op from SegNet/nat.py:41-59,
     140-153,204-209,316-324 with the definition oracle as the attention (test-side reference; the product module
@@ -150,3 +165,21 @@ def test_ppnet_pipeline_runs_at_512_and_224():
         heat = model.heatmap(mask)
         assert heat.shape == (4, R, R) and heat.dtype == torch.uint8
         assert int(heat.reshape(4, -1).max(dim=1).values.min()) == 255          # per-sample min-max normalisation
+
+
+@pytest.mark.gpu
+def test_nat_upernet_end_to_end_and_bn_folding():
+    import copy
+    from ppnet_amd.segnet import NAT_BASE_UPER, SegNet, normalize_images
+    torch.manual_seed(1)
+    m = SegNet(**NAT_BASE_UPER).cuda().eval()
+    with torch.no_grad():
+        for mod in m.modules():                                   # non-trivial BN statistics so folding is exercised
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.5, 1.5)
+        img = normalize_images(torch.randint(0, 256, (2, 224, 224, 3), dtype=torch.uint8, device="cuda"))
+        pred, logits = m(img, return_logits=True)
+        f = copy.deepcopy(m).prepare_inference()
+        _, logits_f = f(img, return_logits=True)
+    assert pred.shape == (2, 224, 224) and logits.shape == (2, 2, 224, 224) and torch.isfinite(logits).all()
+    assert (logits - logits_f).abs().max() < 1e-3 * max(1.0, float(logits.abs().max()))
