@@ -117,6 +117,7 @@ int ppn_edage_paths_ex(int32_t n_paths, uint64_t first_path_id, int32_t R, doubl
                        const int8_t* force_straight, const ppn_paths_t* out, void* stream) {
     if (n_paths < 0 || bad_R(R) || !out || !(map_size > 0.0) || !(clearance > 0.0)) return PPN_E_INVALID;
     if (pocket_draws && pocket_stride <= 0) return PPN_E_INVALID;
+    if (n_paths == 0) return PPN_OK;                           // an empty batch has no buffers to validate
     const ppn_paths_t& o = *out;
     if (!o.seg_poly || !o.seg_endpoint || !o.seg_rotation || !o.seg_translation || !o.seg_straight ||
         !o.segpoint_world || !o.pathpoint_world || !o.hull || !o.hull_n || !o.rotation || !o.trans_rc ||
@@ -150,6 +151,7 @@ int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements
                    const double* place_draws, const double* obst_draws, const ppn_maps_t* out, void* stream) {
     if (!paths || !out || n_paths < 0 || placements < 0 || bad_R(R) || K < 0 || K > 256 || !(map_size > 0.0))
         return PPN_E_INVALID;
+    if ((long long)n_paths * placements == 0) return PPN_OK;   // an empty batch has no buffers to validate
     const ppn_paths_t& p = *paths;
     const ppn_maps_t& o = *out;
     if (!p.hull || !p.hull_n || !p.segpoint_image || !p.pathpoint_image || !p.space_bits || !p.obstacles ||

@@ -369,8 +369,8 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
     const double c3 = bc[8], s3 = bc[9];
     // (obstacle, row) pairs are flattened over the whole workgroup: obstacle n owns rows [row_lo[n], row_lo[n] + cnt),
     // an exclusive scan of the counts (wave 0, shuffles) gives each pair an index, a binary search gives it back.
-    int* row_lo = reinterpret_cast<int*>(cand);                            // the candidates are dead: reuse their bytes
-    int* row_off = row_lo + (K + PPN_MAX_POCKET);                          // [n_obs + 1] exclusive offsets
+    int* row_lo = reinterpret_cast<int*>(poddf);                           // the float points are dead after the filter: 4000 B
+    int* row_off = row_lo + (K + PPN_MAX_POCKET);                          // [n_obs + 1] exclusive offsets (2*(K+64)+1 ints <= 641)
     for (int n = tid; n < n_obs; n += NT) {
         const double cy = obs[n][1], r = obs[n][2];
         const int lo = max((int)floor(cy - r - 0.5), 0), hi = min((int)ceil(cy + r - 0.5), R - 1);

@@ -310,6 +310,76 @@ def test_label_masks_vs_oracle_and_reference_golden(dev, golden_dir):
     assert np.array_equal(_np(mp2), g["mask"])
 
 
+@pytest.mark.parametrize("K", [0, 1, 63, 64, 65, 256])
+def test_obstacle_count_edges_vs_oracle(dev, K):
+    """K = 0 (only pocket obstacles), the 64-wide ballot group boundaries, and the maximum K = 256."""
+    import torch
+    from ppnet_amd import edage
+    R, n, placements, seed = 64, 3, 2, 31
+    pb = edage.generate_paths(n, R, 50, 3, seed=seed, device=dev)
+    mb = edage.generate_maps(pb, placements, obstacles_size=2, obstacles_num=K, seed=seed)
+    torch.cuda.synchronize()
+    precs = oracle_paths(seed, n, R, 50, 3)
+    maps = oracle_maps(seed, precs, R, 50, 2, K, 3, placements)
+    for m, om in enumerate(maps):
+        nt, nr = _np(mb.n_obstacles[m]).tolist()
+        assert nt == len(om["obstacles"]) and nr == om["n_random"]
+        if K:
+            assert _np(mb.accept[m])[:K].astype(bool).tolist() == om["accept"].tolist()
+        assert np.array_equal(_np(mb.grid[m]), om["grid"])
+
+
+def test_many_pocket_obstacles_do_not_overflow_row_tables(dev):
+    """Stage B with the maximum number of pocket obstacles (64) and K = 20: n_obs = 84 rows in the raster tables."""
+    import torch
+    from ppnet_amd import edage
+    R, K = 128, 20
+    pb = edage.generate_paths(1, R, 50, 3, seed=4, device=dev)
+    rng = np.random.RandomState(0)
+    po = np.concatenate([rng.random_sample((64, 2)) * R, rng.random_sample((64, 1)) * 4 + 0.5], axis=1)
+    pb.obstacles[0] = torch.tensor(po, device=dev)
+    pb.n_obstacles[0] = 64
+    mb = edage.generate_maps(pb, 3, 5, K, seed=4)
+    torch.cuda.synchronize()
+    precs = oracle_paths(4, 1, R, 50, 3)
+    precs[0]["obstacles"] = po
+    maps = oracle_maps(4, precs, R, 50, 5, K, 3, 3)
+    for m, om in enumerate(maps):
+        assert int(mb.n_obstacles[m, 0]) == len(om["obstacles"]) >= 64
+        _close(_np(mb.obstacles[m])[:len(om["obstacles"])], om["obstacles"], POCKET_TOL)
+        assert np.array_equal(_np(mb.grid[m]), om["grid"])
+
+
+def test_empty_batches_and_forced_straight_paths(dev):
+    import torch
+    from ppnet_amd import edage
+    pb0 = edage.generate_paths(0, 64, 50, 3, device=dev)                      # zero paths: a no-op, not an error
+    mb0 = edage.generate_maps(pb0, 5, 5, 20)
+    assert pb0.n == 0 and mb0.n == 0
+    pb = edage.generate_paths(2, 64, 50, 3, seed=2, device=dev)
+    assert edage.generate_maps(pb, 0, 5, 20).n == 0                           # zero placements
+    force = torch.tensor([1, 0], dtype=torch.int8, device=dev)
+    pf = edage.generate_paths(2, 64, 50, 3, seed=2, device=dev, force_straight=force)
+    torch.cuda.synchronize()
+    assert _np(pf.straight).tolist() == [1, 0]
+    assert _np(pf.seg_straight[0]).all() and int(pf.n_obstacles[0]) == 0 and int(pf.n_isles[0]) == 0   # Path.py:148-149
+    assert np.abs(_np(pf.seg_poly[0])[:, [0, 1, 2, 4]]).max() == 0.0          # PathSeg.py:28-31: only the linear term survives
+    assert np.array_equal(_np(pf.pathpoint_image[1]), _np(pb.pathpoint_image[1]))   # the unforced path is unchanged
+
+
+def test_placement_cap_sets_flag(dev):
+    """A hull that can never fit (a path scaled past the image) exhausts PPN_PLACE_TRY_CAP attempts and is flagged,
+    where the reference would spin for 1e6 attempts and print an error (MapGenerate.py:60-62)."""
+    import torch
+    from ppnet_amd import edage, _lib
+    pb = edage.generate_paths(1, 64, 50, 3, seed=5, device=dev)
+    pb.hull[0, :4] = torch.tensor([[-50.0, -50.0], [200.0, -50.0], [200.0, 200.0], [-50.0, 200.0]], device=dev)
+    pb.hull_n[0] = 4
+    mb = edage.generate_maps(pb, 2, 5, 20, seed=5)
+    torch.cuda.synchronize()
+    assert (_np(mb.flags) & _lib.FLAG_PLACE_CAP).all() and (_np(mb.attempts) == _lib.PLACE_TRY_CAP).all()
+
+
 def test_invalid_arguments_are_reported_not_fatal(dev):
     from ppnet_amd import edage, _lib
     with pytest.raises(ValueError):
