@@ -264,7 +264,7 @@ def test_config2_full_size_properties(dev):
     assert torch.equal(torch.cat([pa.space_bits, pb2.space_bits]), pb.space_bits)
 
 
-@pytest.mark.parametrize("R,clearance", [(256, 3), (256, 1), (64, 3), (128, 2)])
+@pytest.mark.parametrize("R,clearance", [(256, 3), (256, 1), (64, 3), (128, 2), (256, 2), (512, 3), (224, 1.5), (96, 4), (256, 2.5), (64, 1)])
 def test_corridor_compose_skip_is_exact(dev, R, clearance):
     """Stage B skips the corridor-wins compose pass when it can prove no obstacle touches the corridor
     (margin argument in edage_maps.hip).  PPN_FORCE_COMPOSE=1 disables the skip: both must give
@@ -378,6 +378,35 @@ def test_placement_cap_sets_flag(dev):
     mb = edage.generate_maps(pb, 2, 5, 20, seed=5)
     torch.cuda.synchronize()
     assert (_np(mb.flags) & _lib.FLAG_PLACE_CAP).all() and (_np(mb.attempts) == _lib.PLACE_TRY_CAP).all()
+
+
+def test_config4_one_rank_share(dev):
+    """BASELINE config 4: 1 000 000 instances = 1000 paths x 1000 placements over 8 GPUs -> one rank's share is
+    125 paths x 1000 placements = 125 000 maps (8.2 GB of grids, > 2^32 bytes: 64-bit addressing), ids taken from
+    the middle of the global range exactly as ppnet_amd.shard assigns them to rank 3 of 8."""
+    import torch
+    from ppnet_amd import edage, shard
+    R, K, placements = 256, 20, 1000
+    first_path, n_local, first_map = shard.local_ids(1000, placements, 3, 8)
+    assert (first_path, n_local, first_map) == (375, 125, 375000)
+    pb = edage.generate_paths(n_local, R, 50, 3, seed=0, first_path_id=first_path, device=dev)
+    mb = edage.generate_maps(pb, placements, 5, K, seed=0, first_map_id=first_map)
+    torch.cuda.synchronize()
+    n = n_local * placements
+    assert mb.grid.numel() == n * R * R > 2 ** 32
+    # spot-check rows far past the 4 GiB mark against an independent small launch with the same global ids
+    for j in (0, 77, 124):
+        pj = edage.generate_paths(1, R, 50, 3, seed=0, first_path_id=first_path + j, device=dev)
+        mj = edage.generate_maps(pj, placements, 5, K, seed=0, first_map_id=first_map + j * placements)
+        torch.cuda.synchronize()
+        sl = slice(j * placements, (j + 1) * placements)
+        assert torch.equal(mj.grid, mb.grid[sl]) and torch.equal(mj.pathpoint, mb.pathpoint[sl])
+        assert torch.equal(mj.translation, mb.translation[sl])
+    hist = torch.zeros(256, dtype=torch.int64, device=dev)
+    for c in range(0, n, 12500):                                   # bincount in chunks: keep temporaries small
+        hist += torch.bincount(mb.grid[c:c + 12500].reshape(-1).to(torch.int64), minlength=256)
+    assert int(hist[0] + hist[128] + hist[255]) == n * R * R
+    assert float(((mb.flags & 2) == 0).float().mean()) > 0.9
 
 
 def test_invalid_arguments_are_reported_not_fatal(dev):
