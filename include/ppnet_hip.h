@@ -56,6 +56,7 @@ extern "C" {
 #define PPN_FLAG_HULL_CAP     8u        /* more than PPN_MAX_HULL hull vertices */
 #define PPN_FLAG_ISLE_CAP    16u
 #define PPN_FLAG_POCKET_FULL 32u        /* more than PPN_MAX_POCKET pocket obstacles */
+#define PPN_FLAG_CORRIDOR_PASS 64u       /* informational: an obstacle may touch the corridor, the raster ran its compose pass */
 
 int         ppn_version(void);
 const char* ppn_error_string(int code);
@@ -156,6 +157,18 @@ int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements
  * `bound` is the reference's hard-coded 224 (pass R for other resolutions). Either output may be NULL. */
 int ppn_label_masks(const ppn_paths_t* paths, const ppn_maps_t* maps, int32_t n_paths, int32_t placements,
                     int32_t R, int32_t bound, uint8_t* mask_path, uint8_t* mask_space, void* stream);
+
+/* The two halves of ppn_edage_maps as separate launches (same arguments): `_place` runs the rejection loop, the label
+ * transforms and the clearance filter and writes every output except `grid`; `_raster` turns the obstacle lists it
+ * left into `grid`.  ppn_edage_maps == _place then _raster on one stream.  Apart they let the compute-bound half of
+ * one batch overlap the store-bound half of another on different streams (double-buffer the ppn_maps_t). */
+int ppn_edage_maps_place(const ppn_paths_t* paths, int32_t n_paths, int32_t placements,
+                         uint64_t first_map_id, int32_t R, double map_size, double obstacles_size,
+                         int32_t K, double clearance, uint64_t seed,
+                         const double* place_draws, const double* obst_draws,
+                         const ppn_maps_t* out, void* stream);
+int ppn_edage_maps_raster(const ppn_paths_t* paths, int32_t n_paths, int32_t placements, int32_t R, int32_t K,
+                          const ppn_maps_t* out, void* stream);
 
 /* Path.boundary_check (Path.py:100-111) for n (angle, translation) pairs against one hull.
  * angle_deg[n] is the angle passed by the caller (MapGenerate passes -angle), translation_rc

@@ -146,21 +146,22 @@ int ppn_edage_paths_ex(int32_t n_paths, uint64_t first_path_id, int32_t R, doubl
     return PPN_OK;
 }
 
-int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements, uint64_t first_map_id, int32_t R,
-                   double map_size, double obstacles_size, int32_t K, double clearance, uint64_t seed,
-                   const double* place_draws, const double* obst_draws, const ppn_maps_t* out, void* stream) {
-    if (!paths || !out || n_paths < 0 || placements < 0 || bad_R(R) || K < 0 || K > 256 || !(map_size > 0.0))
-        return PPN_E_INVALID;
+// phase: 1 = placement half, 2 = raster half, 3 = both in one kernel
+static int maps_launch(int phase, const ppn_paths_t* paths, int32_t n_paths, int32_t placements, uint64_t first_map_id,
+                       int32_t R, double map_size, double obstacles_size, int32_t K, double clearance, uint64_t seed,
+                       const double* place_draws, const double* obst_draws, const ppn_maps_t* out, void* stream) {
+    if (!paths || !out || n_paths < 0 || placements < 0 || bad_R(R) || K < 0 || K > 256) return PPN_E_INVALID;
+    if ((phase & 1) && !(map_size > 0.0)) return PPN_E_INVALID;
     if ((long long)n_paths * placements == 0) return PPN_OK;   // an empty batch has no buffers to validate
     const ppn_paths_t& p = *paths;
     const ppn_maps_t& o = *out;
-    if (!p.hull || !p.hull_n || !p.segpoint_image || !p.pathpoint_image || !p.space_bits || !p.obstacles ||
-        !p.n_obstacles || !p.flags || !p.max_step_px)
+    if ((phase & 1) && (!p.hull || !p.hull_n || !p.segpoint_image || !p.pathpoint_image || !p.obstacles ||
+                        !p.n_obstacles || !p.flags || !p.max_step_px))
         return PPN_E_INVALID;
+    if (!p.space_bits) return PPN_E_INVALID;
     if (!o.grid || !o.angle || !o.translation || !o.attempts || !o.segpoint || !o.obstacles || !o.n_obstacles || !o.flags)
         return PPN_E_INVALID;
     const long long n_maps = (long long)n_paths * placements;
-    if (n_maps == 0) return PPN_OK;
     if (n_maps > 0x7fffffffLL) return PPN_E_INVALID;
     ppn::MapsParams prm;
     prm.paths = p;
@@ -181,14 +182,31 @@ int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements
         const char* f = getenv("PPN_FORCE_COMPOSE");
         prm.force_compose = (f && f[0] == '1') ? 1 : 0;
     }
-    // dynamic LDS: staged path points / occupancy bits + candidates + obstacles + float points + byte LUT + pocket rows
-    const size_t regionP = (size_t)R * R / 8 > (size_t)PPN_PATH_POINTS * 16 ? (size_t)R * R / 8 : (size_t)PPN_PATH_POINTS * 16;
-    const size_t lds = regionP + (size_t)K * 24 + (size_t)(K + PPN_MAX_POCKET) * 24 + (PPN_PATH_POINTS / 2) * 8 + 256 * 8 +
-                       (size_t)PPN_MAX_POCKET * 24;
-    PPN_HIP(hipFuncSetAttribute((const void*)ppn::edage_maps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ppn::edage_maps_kernel, dim3((unsigned)n_maps), dim3(256), lds, (hipStream_t)stream, prm);
-    PPN_HIP(hipGetLastError());
+    {
+        const int rc = ppn::edage_maps_launch(phase, prm, (hipStream_t)stream);
+        if (rc == PPN_E_HIP) g_last_hip = (int)hipGetLastError();
+        if (rc != PPN_OK) return rc;
+    }
     return PPN_OK;
+}
+
+int ppn_edage_maps(const ppn_paths_t* paths, int32_t n_paths, int32_t placements, uint64_t first_map_id, int32_t R,
+                   double map_size, double obstacles_size, int32_t K, double clearance, uint64_t seed,
+                   const double* place_draws, const double* obst_draws, const ppn_maps_t* out, void* stream) {
+    return maps_launch(3, paths, n_paths, placements, first_map_id, R, map_size, obstacles_size, K, clearance, seed,
+                       place_draws, obst_draws, out, stream);
+}
+
+int ppn_edage_maps_place(const ppn_paths_t* paths, int32_t n_paths, int32_t placements, uint64_t first_map_id, int32_t R,
+                         double map_size, double obstacles_size, int32_t K, double clearance, uint64_t seed,
+                         const double* place_draws, const double* obst_draws, const ppn_maps_t* out, void* stream) {
+    return maps_launch(1, paths, n_paths, placements, first_map_id, R, map_size, obstacles_size, K, clearance, seed,
+                       place_draws, obst_draws, out, stream);
+}
+
+int ppn_edage_maps_raster(const ppn_paths_t* paths, int32_t n_paths, int32_t placements, int32_t R, int32_t K,
+                          const ppn_maps_t* out, void* stream) {
+    return maps_launch(2, paths, n_paths, placements, 0, R, 0.0, 0.0, K, 0.0, 0, nullptr, nullptr, out, stream);
 }
 
 int ppn_label_masks(const ppn_paths_t* paths, const ppn_maps_t* maps, int32_t n_paths, int32_t placements, int32_t R,

@@ -29,15 +29,24 @@ __device__ unsigned long long g_phase_cycles[16];
 #define PPN_STAMP_INIT do {} while (0)
 #endif
 
-#ifndef PPN_FILTER_CH
-#define PPN_FILTER_CH 2      // obstacles per wave swept together in the clearance filter; 2 / 4 / 8 measured equal (VGPRs 7x / 86 / 106)
-#endif
-
 namespace {
 constexpr int NT = 256;
 constexpr int NW = NT / 64;
 constexpr int MAX_OBS = 256 + PPN_MAX_POCKET;     // K <= 256
 constexpr double PI = 3.141592653589793;
+constexpr int NCOARSE = PPN_PATH_POINTS / 8 + 1;   // coarse points of the clearance filter: odd points 0, 4, .., 496 and 499
+}
+
+// bytes of the first dynamic-LDS region: staged path points (phase 1) and / or the occupancy bit mask (phase 2)
+__host__ __device__ constexpr int maps_region_bytes(int phase, int R) {
+    const int pts = (phase & 1) ? PPN_PATH_POINTS * 16 : 0, occ = (phase & 2) ? R * R / 8 : 0;
+    return pts > occ ? pts : occ;
+}
+
+// bytes of the region that holds the filter's coarse float points, then the raster's row tables (2*(K+64)+1 ints)
+__host__ __device__ constexpr int maps_tab_bytes(int K) {
+    const int rows = ((2 * (K + PPN_MAX_POCKET) + 1) * 4 + 7) & ~7;
+    return rows > 1024 ? rows : 1024;
 }
 
 // exact predicate of the obstacle raster rule for pixel column j of a row at squared row offset dy2
@@ -51,21 +60,26 @@ __device__ __forceinline__ uint32_t expand4(uint32_t b) {
     return (((b & 1u) | ((b & 2u) << 7) | ((b & 4u) << 14) | ((b & 8u) << 21))) * 255u;
 }
 
-__global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
+// Stage B.  One workgroup per map.  PHASE 3 is the whole of MapGenerate.generate's loop body for a map; PHASE 1 (placement,
+// labels, clearance filter: every output but `grid`) and PHASE 2 (obstacle lists -> `grid`, reading what PHASE 1 left in
+// global memory) are the same code as two launches (ppn_edage_maps_place / _raster).
+template <int PHASE>
+__global__ __launch_bounds__(NT) void edage_maps_kernel_t(MapsParams prm) {
     // dynamic LDS carve (all 8-byte aligned):
-    //   regionP [max(16000, R*R/8) B]  the target path's 1000 image-frame points (staged by waves 1-3 while wave 0
-    //                                   runs the placement loop); after the filter the same bytes hold the R*R-bit
-    //                                   occupancy mask
-    //   cand  [K][3] f64   candidates (row, col, r); later the raster's row tables
-    //   obs   [K+64][3] f64  kept + pocket obstacles (col, row, r)
-    //   poddf [1000] f32   float copy of the transformed odd points as pairs [x0,x1,y0,y1] (filter pre-pass)
-    //   lut   [256] u64    8 occupancy bits -> 8 grid bytes
-    //   praw  [64][3] f64  the path's pocket obstacles as stored by stage A
+    //   regionP             PHASE&1: the target path's 1000 image-frame points (double2, staged by waves 1-3 while wave 0
+    //                       runs the placement loop); PHASE&2: the R*R-bit occupancy mask (after the filter when fused)
+    //   cand  [K][3] f64    candidates (row, col, r)                                   (PHASE&1)
+    //   obs   [K+64][3] f64 kept + pocket obstacles (col, row, r)
+    //   poddf [2][128] f32  float copy of the 126 coarse odd points as planes x | y (filter
+    //                       pre-pass); afterwards the raster's row tables
+    //   lut   [256] u64     8 occupancy bits -> 8 grid bytes                           (PHASE&2)
+    //   praw  [64][3] f64   the path's pocket obstacles as stored by stage A           (PHASE&1)
     extern __shared__ uint64_t lds_raw[];
     __shared__ double hullc[PPN_MAX_HULL][2];     // hull - R/2
     __shared__ double bc[12];
-    __shared__ int bci[16];                       // [0..3] placement, [4..11] filter ballots, [12] corridor-touch flag
-    __shared__ float fmin_w[NW][PPN_FILTER_CH];               // per-wave float minima of the clearance filter
+    __shared__ int bci[16];                       // [0..3] placement, [4] kept count, [12] corridor-touch flag
+    __shared__ float fmin_w[NW][64];              // per-wave partial minima (squared, float) of the clearance filter
+    __shared__ double dref[64];                   // exact minima of the obstacles the coarse filter left undecided
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // XCD-aware block -> map assignment: blocks b and b+8 share an XCD (round-robin dispatch), so
@@ -84,219 +98,240 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
     const ppn_paths_t& P = prm.paths;
     const ppn_maps_t& O = prm.out;
     const int words = R * R / 32;
-    const int regionP_bytes = max(R * R / 8, PPN_PATH_POINTS * 16);
+    const int regionP_bytes = maps_region_bytes(PHASE, R);
     unsigned char* lds = reinterpret_cast<unsigned char*>(lds_raw);
     double2* pimg = reinterpret_cast<double2*>(lds);
     uint32_t* occw = reinterpret_cast<uint32_t*>(lds);
+    const size_t cand_bytes = (PHASE & 1) ? (size_t)K * 24 : 0;
     double (*cand)[3] = reinterpret_cast<double (*)[3]>(lds + regionP_bytes);
-    double (*obs)[3] = reinterpret_cast<double (*)[3]>(lds + regionP_bytes + (size_t)K * 24);
-    float* poddf = reinterpret_cast<float*>(lds + regionP_bytes + (size_t)K * 24 + (size_t)(K + PPN_MAX_POCKET) * 24);
-    uint64_t* lut = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(poddf) + (PPN_PATH_POINTS / 2) * 8);
-    double (*praw)[3] = reinterpret_cast<double (*)[3]>(reinterpret_cast<unsigned char*>(lut) + 256 * 8);
-    uint32_t flags = 0;
+    double (*obs)[3] = reinterpret_cast<double (*)[3]>(lds + regionP_bytes + cand_bytes);
+    float* poddf = reinterpret_cast<float*>(lds + regionP_bytes + cand_bytes + (size_t)(K + PPN_MAX_POCKET) * 24);
+    uint64_t* lut = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(poddf) + maps_tab_bytes(K));
+    double (*praw)[3] = reinterpret_cast<double (*)[3]>(reinterpret_cast<unsigned char*>(lut) + ((PHASE & 2) ? 256 * 8 : 0));
+    (void)mid; (void)pimg; (void)occw; (void)cand; (void)praw; (void)hullc; (void)bci; (void)fmin_w; (void)dref; (void)lane; (void)wv; (void)words;
     PPN_STAMP_INIT;
 
-    const int hn = P.hull_n[pj];
-    const int n_pocket = P.n_obstacles[pj];
-    const uint32_t path_flags = P.flags[pj];
-    if (wv == 0) {
-        // wave 0: hull, then straight into the placement loop (same wave: LDS keeps program order)
-        hullc[lane][0] = P.hull[((size_t)pj * PPN_MAX_HULL + lane) * 2] - half;
-        hullc[lane][1] = P.hull[((size_t)pj * PPN_MAX_HULL + lane) * 2 + 1] - half;
-        if (lane == 0) bci[12] = prm.force_compose;                       // "some obstacle may touch the corridor"
-    } else {
-        // waves 1..3, concurrently with the placement: stage everything that does not depend on it
-        const int t3 = tid - 64;
-        {   // 1000 points over 192 lanes: issue every load before the first LDS store (one L2 round trip, not six)
-            constexpr int PER = (PPN_PATH_POINTS + (NT - 64) - 1) / (NT - 64);
-            const double2* src = reinterpret_cast<const double2*>(P.pathpoint_image) + (size_t)pj * PPN_PATH_POINTS;
-            double2 r[PER];
-#pragma unroll
-            for (int k = 0; k < PER; ++k) { const int q = t3 + k * (NT - 64); r[k] = src[q < PPN_PATH_POINTS ? q : 0]; }
-#pragma unroll
-            for (int k = 0; k < PER; ++k) { const int q = t3 + k * (NT - 64); if (q < PPN_PATH_POINTS) pimg[q] = r[k]; }
-        }
-        for (int q = t3; q < n_pocket; q += NT - 64) {
-            const double* o = P.obstacles + ((size_t)pj * PPN_MAX_POCKET + q) * 3;
-            praw[q][0] = o[0]; praw[q][1] = o[1]; praw[q][2] = o[2];
-        }
-        for (int e = t3; e < 256; e += NT - 64) {   // byte-expansion table: bit k set (= occupied) -> byte k 0x00, clear -> 0xFF
-            uint64_t v = 0ull;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v |= ((e >> k) & 1) ? 0ull : (0xFFull << (8 * k));
-            lut[e] = v;
-        }
-        // K random obstacle candidates (MapGenerate.py:128-136)
-        for (int k = t3; k < K; k += NT - 64) {
-            double ux, uy, us;
+    // the hand-over from the placement half to the raster half
+    int n_obs = 0, t0 = 0, t1 = 0;
+    bool compose = false;
+
+    if constexpr (PHASE & 1) {
+        uint32_t flags = 0;
+
+        const int hn = P.hull_n[pj];
+        const int n_pocket = P.n_obstacles[pj];
+        const uint32_t path_flags = P.flags[pj];
+        if (wv == 0) {
+            // wave 0: hull, then straight into the placement loop (same wave: LDS keeps program order)
+            hullc[lane][0] = P.hull[((size_t)pj * PPN_MAX_HULL + lane) * 2] - half;
+            hullc[lane][1] = P.hull[((size_t)pj * PPN_MAX_HULL + lane) * 2 + 1] - half;
+            if (lane == 0) bci[12] = prm.force_compose;                       // "some obstacle may touch the corridor"
+        } else {
+            // waves 1..3, concurrently with the placement: stage everything that does not depend on it
+            const int t3 = tid - 64;
+            {   // 1000 points over 192 lanes: issue every load before the first LDS store (one L2 round trip, not six)
+                constexpr int PER = (PPN_PATH_POINTS + (NT - 64) - 1) / (NT - 64);
+                const double2* src = reinterpret_cast<const double2*>(P.pathpoint_image) + (size_t)pj * PPN_PATH_POINTS;
+                double2 r[PER];
+    #pragma unroll
+                for (int k = 0; k < PER; ++k) { const int q = t3 + k * (NT - 64); r[k] = src[q < PPN_PATH_POINTS ? q : 0]; }
+    #pragma unroll
+                for (int k = 0; k < PER; ++k) { const int q = t3 + k * (NT - 64); if (q < PPN_PATH_POINTS) pimg[q] = r[k]; }
+            }
+            for (int q = t3; q < n_pocket; q += NT - 64) {
+                const double* o = P.obstacles + ((size_t)pj * PPN_MAX_POCKET + q) * 3;
+                praw[q][0] = o[0]; praw[q][1] = o[1]; praw[q][2] = o[2];
+            }
+            // K random obstacle candidates (MapGenerate.py:128-136): draws [0,K) rows, [K,2K) columns, [2K,3K) sizes
             if (prm.obst_draws) {
                 const double* d = prm.obst_draws + (size_t)m * 3 * K;
-                ux = d[k]; uy = d[K + k]; us = d[2 * K + k];
-            } else {
-                ux = philox_double(prm.seed, STREAM_OBST, mid, (uint32_t)k);
-                uy = philox_double(prm.seed, STREAM_OBST, mid, (uint32_t)(K + k));
-                us = philox_double(prm.seed, STREAM_OBST, mid, (uint32_t)(2 * K + k));
-            }
-            cand[k][0] = ux * prm.map_size / prm.map_size * Rd;
-            cand[k][1] = uy * prm.map_size / prm.map_size * Rd;
-            cand[k][2] = us * prm.obstacles_size / prm.map_size * Rd;
-        }
-    }
-    PPN_STAMP(0);
-
-    // ------------------------------------------------------------------ placement: wave 0, one attempt per lane
-    if (wv == 0) {
-        const double* fed = prm.place_draws ? prm.place_draws + (size_t)m * 3 : nullptr;
-        int attempts = 0, t0 = 0, t1 = 0;
-        double angle = 0.0, ca = 1.0, sa = 0.0;
-        for (int round = 0;; ++round) {
-            const int a = round * 64 + lane;                              // this lane's attempt index
-            double u0, u1, u2;
-            if (fed) { u0 = fed[0]; u1 = fed[1]; u2 = fed[2]; }
-            else {
-                // draws 3a, 3a+1, 3a+2 live in Philox blocks (3a)>>1 and (3a)>>1 + 1
-                const uint32_t d = 3u * (uint32_t)a;
-                double p0, p1, p2, p3;
-                philox_double2(prm.seed, STREAM_PLACE, mid, d >> 1, p0, p1);
-                philox_double2(prm.seed, STREAM_PLACE, mid, (d >> 1) + 1u, p2, p3);
-                if (d & 1u) { u0 = p1; u1 = p2; u2 = p3; } else { u0 = p0; u1 = p1; u2 = p2; }
-            }
-            const double ang = u0 * 360.0 - 180.0;                        // MapGenerate.py:63
-            const int a0 = (int)(u1 * Rd - half);                         // MapGenerate.py:64 (trunc)
-            const int a1 = (int)(u2 * Rd - half);
-            // boundary_check(-angle, [t1, t0]), Path.py:100-111, MapOffset = R/2
-            const double rad = (-ang) / 180.0 * PI;
-            double c, s;
-            sincos_small(rad, s, c);
-            const double o1 = (double)a1, o0 = (double)a0;
-            bool out = false;
-            for (int v = 0; v < hn; ++v) {
-                double hx, hy;
-                rot2(c, s, hullc[v][0], hullc[v][1], hx, hy);
-                hx = hx + o1 + half;
-                hy = hy + o0 + half;
-                out = out || (hx < 0.0) || (hx >= Rd) || (hy < 0.0) || (hy >= Rd);
-            }
-            unsigned long long okm = __ballot(!out);
-            if (fed) okm &= 1ull;
-            int src;
-            if (okm) { src = __ffsll((long long)okm) - 1; attempts = round * 64 + src + 1; }
-            else if (fed) { src = 0; attempts = 1; flags |= PPN_FLAG_PLACE_CAP; }
-            else if ((round + 1) * 64 >= PPN_PLACE_TRY_CAP) { src = 63; attempts = PPN_PLACE_TRY_CAP; flags |= PPN_FLAG_PLACE_CAP; }
-            else continue;
-            angle = __shfl(ang, src, 64);
-            ca = __shfl(c, src, 64);
-            sa = __shfl(s, src, 64);
-            t0 = __shfl(a0, src, 64);
-            t1 = __shfl(a1, src, 64);
-            break;
-        }
-        double c3, s3;
-        sincos_small((-angle) * PI / 180.0, s3, c3);                      // rotate_nearest(space, -angle)
-        if (lane == 0) {
-            bc[0] = angle; bc[6] = ca; bc[7] = sa; bc[8] = c3; bc[9] = s3;
-            bci[0] = t0; bci[1] = t1; bci[2] = attempts; bci[3] = (int)flags;
-            O.angle[m] = angle;
-            O.translation[(size_t)m * 2] = t0; O.translation[(size_t)m * 2 + 1] = t1;
-            O.attempts[m] = attempts;
-        }
-    }
-    __syncthreads();
-    PPN_STAMP(1);
-    const int t0 = bci[0], t1 = bci[1];
-    flags = (uint32_t)bci[3];
-    const double c = bc[6], s = bc[7];                                    // cos/sin(-angle/180*pi), MapGenerate.py:72
-    const double tr0 = (double)t1, tr1 = (double)t0;                      // [translation[1], translation[0]]
-
-    // ------------------------------------------------------------------ labels
-    for (int q = tid; q < PPN_PATH_POINTS; q += NT) {                     // MapGenerate.py:76-80
-        const double2 pq = pimg[q];
-        double rx, ry;
-        rot2(c, s, pq.x - half, pq.y - half, rx, ry);
-        rx = rx + half + tr0;
-        ry = ry + half + tr1;
-        if (q & 1) {
-            const int k = q >> 1;
-            poddf[(k >> 1) * 4 + (k & 1)] = (float)rx; poddf[(k >> 1) * 4 + 2 + (k & 1)] = (float)ry;
-        }
-        if (O.pathpoint) *reinterpret_cast<double2*>(O.pathpoint + ((size_t)m * PPN_PATH_POINTS + q) * 2) = make_double2(rx, ry);
-    }
-    if (tid < PPN_SEGS + 1) {                                             // MapGenerate.py:70-74
-        const double x = P.segpoint_image[((size_t)pj * 11 + tid) * 2] - half;
-        const double y = P.segpoint_image[((size_t)pj * 11 + tid) * 2 + 1] - half;
-        double rx, ry;
-        rot2(c, s, x, y, rx, ry);
-        rx = rx + half + tr0;
-        ry = ry + half + tr1;
-        O.segpoint[((size_t)m * 11 + tid) * 2] = rx;
-        O.segpoint[((size_t)m * 11 + tid) * 2 + 1] = ry;
-        if (tid == 0) { bc[2] = rx; bc[3] = ry; }
-        if (tid == PPN_SEGS) { bc[4] = rx; bc[5] = ry; }                  // end = segpoint[10]
-    }
-    __syncthreads();
-    PPN_STAMP(2);
-
-    // ------------------------------------------------------------------ clearance filter: one wave per obstacle,
-    // shuffle min-reduce over the 500 odd path points (squared distances, one sqrt: sqrt is monotone and
-    // correctly rounded, so sqrt(min d2) == min sqrt(d2) bit for bit), ballot compaction in draw order
-    {
-        const double c_px = prm.clearance / prm.map_size * Rd;            // MapGenerate.py:142
-        // Corridor-touch margin.  Every corridor pixel of the map lies within
-        //   0.5*c_px (ray reach from the centre line, Path.py:119-134) + max_step (next odd path point)
-        //   + 4.3 px (five nearest-neighbour roundings of <= 0.71 px: canvas, point lattice, two rotations,
-        //     one fractional translation; + the half-pixel offset between the label and the disc frames)
-        // of an odd path point, and a pixel of obstacle k lies >= md_k - r_k - 0.71 from every odd path point.
-        // So an obstacle with md_k - r_k > touch_margin cannot meet the corridor; if none can, the compose
-        // pass below is a no-op and is skipped (tests/test_gpu_edage.py checks this against a forced run).
-        const double touch_margin = 0.5 * c_px + P.max_step_px[pj] + 5.0;
-        int n_rand = 0;
-        for (int k0 = 0; k0 < K; k0 += 64) {                              // K <= 256: at most 4 groups of 64
-            unsigned long long accm = 0ull;                              // accept bits of this wave's obstacles
-            // this wave's obstacles of the group are k0 + wv, k0 + wv + 4, ...; eight at a time their float minima are
-            // accumulated in one sweep over the points and reduced as independent shuffle chains (latencies overlap)
-            constexpr int CH = PPN_FILTER_CH;
-            typedef float v2f __attribute__((ext_vector_type(2)));
-            for (int j0 = 0; k0 + wv + j0 * NW < min(K, k0 + 64); j0 += CH) {
-                float mfv[CH], oxf[CH], oyf[CH];
-                int nk = 0;
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    const int k = k0 + wv + (j0 + j) * NW;
-                    const bool in = k < min(K, k0 + 64);
-                    oxf[j] = in ? (float)cand[k][0] : 0.0f; oyf[j] = in ? (float)cand[k][1] : 0.0f;
-                    mfv[j] = 3.0e38f;
-                    nk += in ? 1 : 0;
+                for (int k = t3; k < K; k += NT - 64) {
+                    cand[k][0] = d[k] * prm.map_size / prm.map_size * Rd;
+                    cand[k][1] = d[K + k] * prm.map_size / prm.map_size * Rd;
+                    cand[k][2] = d[2 * K + k] * prm.obstacles_size / prm.map_size * Rd;
                 }
-                for (int q = lane; q < PPN_PATH_POINTS / 4; q += 64) {    // 250 pairs of odd points
-                    const float4 pr = *reinterpret_cast<const float4*>(poddf + 4 * q);
-                    const v2f px = {pr.x, pr.y}, py = {pr.z, pr.w};
+            } else {
+                // one Philox block yields draws 2b and 2b+1: a lane per block, not per candidate (a third of the rounds)
+                for (int bk = t3; 2 * bk < 3 * K; bk += NT - 64) {
+                    double u[2];
+                    philox_double2(prm.seed, STREAM_OBST, mid, (uint32_t)bk, u[0], u[1]);
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        if (j < nk) {
-                            const v2f dx = px - (v2f){oxf[j], oxf[j]}, dy = py - (v2f){oyf[j], oyf[j]};
-                            const v2f d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
-                            mfv[j] = fminf(mfv[j], fminf(d2.x, d2.y));
+                    for (int h = 0; h < 2; ++h) {
+                        const int d = 2 * bk + h;
+                        if (d < 3 * K) {
+                            const int comp = (d >= K ? 1 : 0) + (d >= 2 * K ? 1 : 0);
+                            cand[d - comp * K][comp] = u[h] * (comp == 2 ? prm.obstacles_size : prm.map_size) / prm.map_size * Rd;
                         }
                     }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                    for (int j = 0; j < CH; ++j) if (j < nk) mfv[j] = fminf(mfv[j], __shfl_xor(mfv[j], o, 64));
-                // decisions read the minima back from LDS so this loop stays rolled (a rare double fallback sits in it)
-                if (lane == 0) {
-#pragma unroll
-                    for (int j = 0; j < CH; ++j) fmin_w[wv][j] = mfv[j];
+            }
+        }
+        PPN_STAMP(0);
+
+        // ------------------------------------------------------------------ placement: wave 0, one attempt per lane
+        if (wv == 0) {
+            const double* fed = prm.place_draws ? prm.place_draws + (size_t)m * 3 : nullptr;
+            int attempts = 0, t0 = 0, t1 = 0;
+            double angle = 0.0, ca = 1.0, sa = 0.0;
+            for (int round = 0;; ++round) {
+                const int a = round * 64 + lane;                              // this lane's attempt index
+                double u0, u1, u2;
+                if (fed) { u0 = fed[0]; u1 = fed[1]; u2 = fed[2]; }
+                else {
+                    // draws 3a, 3a+1, 3a+2 live in Philox blocks (3a)>>1 and (3a)>>1 + 1
+                    const uint32_t d = 3u * (uint32_t)a;
+                    double p0, p1, p2, p3;
+                    philox_double2(prm.seed, STREAM_PLACE, mid, d >> 1, p0, p1);
+                    philox_double2(prm.seed, STREAM_PLACE, mid, (d >> 1) + 1u, p2, p3);
+                    if (d & 1u) { u0 = p1; u1 = p2; u2 = p3; } else { u0 = p0; u1 = p1; u2 = p2; }
                 }
-                for (int j = 0; j < nk; ++j) {
-                    const int k = k0 + wv + (j0 + j) * NW;
-                    const double thr = cand[k][2] + c_px;
-                    // float pre-pass: |error| of the float minimum distance is < 1e-3 px for coordinates < 2^10,
-                    // so it decides every case that is not within 0.01 px of a threshold; those fall back to double
-                    double mn = (double)sqrtf(fmin_w[wv][j]);
-                    if (fabs(mn - thr) < 0.01 || fabs(mn - cand[k][2] - touch_margin) < 0.01) {
-                        const double ox = cand[k][0], oy = cand[k][1];
-                        double md = 1e300;                                 // rare: redo in double from the staged points
+                const double ang = u0 * 360.0 - 180.0;                        // MapGenerate.py:63
+                const int a0 = (int)(u1 * Rd - half);                         // MapGenerate.py:64 (trunc)
+                const int a1 = (int)(u2 * Rd - half);
+                // boundary_check(-angle, [t1, t0]), Path.py:100-111, MapOffset = R/2
+                const double rad = (-ang) / 180.0 * PI;
+                double c, s;
+                sincos_small(rad, s, c);
+                const double o1 = (double)a1, o0 = (double)a0;
+                bool out = false;
+                for (int v = 0; v < hn; ++v) {
+                    double hx, hy;
+                    rot2(c, s, hullc[v][0], hullc[v][1], hx, hy);
+                    hx = hx + o1 + half;
+                    hy = hy + o0 + half;
+                    out = out || (hx < 0.0) || (hx >= Rd) || (hy < 0.0) || (hy >= Rd);
+                }
+                unsigned long long okm = __ballot(!out);
+                if (fed) okm &= 1ull;
+                int src;
+                if (okm) { src = __ffsll((long long)okm) - 1; attempts = round * 64 + src + 1; }
+                else if (fed) { src = 0; attempts = 1; flags |= PPN_FLAG_PLACE_CAP; }
+                else if ((round + 1) * 64 >= PPN_PLACE_TRY_CAP) { src = 63; attempts = PPN_PLACE_TRY_CAP; flags |= PPN_FLAG_PLACE_CAP; }
+                else continue;
+                angle = __shfl(ang, src, 64);
+                ca = __shfl(c, src, 64);
+                sa = __shfl(s, src, 64);
+                t0 = __shfl(a0, src, 64);
+                t1 = __shfl(a1, src, 64);
+                break;
+            }
+            if (lane == 0) {
+                bc[0] = angle; bc[6] = ca; bc[7] = sa;
+                if constexpr (PHASE & 2) {
+                    double s3, c3;
+                    sincos_small((-angle) * PI / 180.0, s3, c3);              // rotate_nearest(space, -angle)
+                    bc[8] = c3; bc[9] = s3;
+                }
+                bci[0] = t0; bci[1] = t1; bci[2] = attempts; bci[3] = (int)flags;
+                O.angle[m] = angle;
+                O.translation[(size_t)m * 2] = t0; O.translation[(size_t)m * 2 + 1] = t1;
+                O.attempts[m] = attempts;
+            }
+        }
+        __syncthreads();
+        PPN_STAMP(1);
+        t0 = bci[0]; t1 = bci[1];
+        flags = (uint32_t)bci[3];
+        const double c = bc[6], s = bc[7];                                    // cos/sin(-angle/180*pi), MapGenerate.py:72
+        const double tr0 = (double)t1, tr1 = (double)t0;                      // [translation[1], translation[0]]
+
+        // ------------------------------------------------------------------ labels
+        for (int q = tid; q < PPN_PATH_POINTS; q += NT) {                     // MapGenerate.py:76-80
+            const double2 pq = pimg[q];
+            double rx, ry;
+            rot2(c, s, pq.x - half, pq.y - half, rx, ry);
+            rx = rx + half + tr0;
+            ry = ry + half + tr1;
+            if (q & 1) {
+                const int k = q >> 1;
+                if ((k & 3) == 0 || k == PPN_PATH_POINTS / 2 - 1) {                 // the filter's coarse points
+                    const int ci = (k & 3) == 0 ? (k >> 2) : NCOARSE - 1;
+                    poddf[ci] = (float)rx; poddf[128 + ci] = (float)ry;
+                }
+            }
+            if (O.pathpoint) *reinterpret_cast<double2*>(O.pathpoint + ((size_t)m * PPN_PATH_POINTS + q) * 2) = make_double2(rx, ry);
+        }
+        if (tid < PPN_SEGS + 1) {                                             // MapGenerate.py:70-74
+            const double x = P.segpoint_image[((size_t)pj * 11 + tid) * 2] - half;
+            const double y = P.segpoint_image[((size_t)pj * 11 + tid) * 2 + 1] - half;
+            double rx, ry;
+            rot2(c, s, x, y, rx, ry);
+            rx = rx + half + tr0;
+            ry = ry + half + tr1;
+            O.segpoint[((size_t)m * 11 + tid) * 2] = rx;
+            O.segpoint[((size_t)m * 11 + tid) * 2 + 1] = ry;
+            if (tid == 0) { bc[2] = rx; bc[3] = ry; }                         // init = segpoint[0]
+            if (tid == PPN_SEGS) { bc[4] = rx; bc[5] = ry; }                  // end = segpoint[10]
+        }
+        __syncthreads();
+        PPN_STAMP(2);
+
+        // ------------------------------------------------------------------ clearance filter: one lane per obstacle,
+        // minimum over the 500 odd path points (squared distances, one sqrt: sqrt is monotone and correctly
+        // rounded, so sqrt(min d2) == min sqrt(d2) bit for bit), ballot compaction in draw order
+        {
+            const double c_px = prm.clearance / prm.map_size * Rd;            // MapGenerate.py:142
+            // Corridor-touch margin.  Every corridor pixel of the map lies within
+            //   0.5*c_px (ray reach from the centre line, Path.py:119-134) + max_step (next odd path point)
+            //   + 4.3 px (five nearest-neighbour roundings of <= 0.71 px: canvas, point lattice, two rotations,
+            //     one fractional translation; + the half-pixel offset between the label and the disc frames)
+            // of an odd path point, and a pixel of obstacle k lies >= md_k - r_k - 0.71 from every odd path point.
+            // So an obstacle with md_k - r_k > touch_margin cannot meet the corridor; if none can, the compose
+            // pass below is a no-op and is skipped (tests/test_gpu_edage.py checks this against a forced run).
+            const double touch_margin = 0.5 * c_px + P.max_step_px[pj] + 5.0;
+            // Two levels.  Coarse: every 4th odd point (plus the last: NCOARSE = 126 points), in float, one lane per
+            // obstacle, each wave a quarter of the 63 point pairs (8-byte same-address LDS reads broadcast; a 16-byte one
+            // measured ~64 LDS cycles).  An odd point is at most 4 path steps from a coarse one, and the image-frame
+            // points sit on the pixel lattice (each rounded by <= 0.5 per axis, Path.py:378-386), so the true minimum
+            // distance lies in [dc - 4*max_step - sqrt(2), dc]: that settles every obstacle but the ~3 % whose coarse
+            // distance falls inside that band around the threshold.  Those get the exact double minimum over all 500 odd points,
+            // a wave per obstacle, and the decision `mn > thr` is then the reference's (MapGenerate.py:139-143).
+            const double slack = 4.0 * P.max_step_px[pj] + 1.4143 + 0.01;      // + float error of dc (< 1e-3 px)
+            int n_rand = 0;
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const float* cpx = poddf;
+            const float* cpy = poddf + 128;
+            const int q_lo = wv * ((NCOARSE / 2 + NW - 1) / NW);
+            const int q_hi = min(q_lo + (NCOARSE / 2 + NW - 1) / NW, NCOARSE / 2);
+            for (int k0 = 0; k0 < K; k0 += 64) {                              // K <= 256: at most 4 groups of 64
+                const int k = k0 + lane;
+                const bool valid = k < K;
+                {
+                    const float oxf = valid ? (float)cand[k][0] : 0.0f, oyf = valid ? (float)cand[k][1] : 0.0f;
+                    const v2f ox2 = {oxf, oxf}, oy2 = {oyf, oyf};
+                    v2f m2 = {3.0e38f, 3.0e38f};
+#pragma unroll 4
+                    for (int q = q_lo; q < q_hi; ++q) {
+                        const v2f dx = *reinterpret_cast<const v2f*>(cpx + 2 * q) - ox2;
+                        const v2f dy = *reinterpret_cast<const v2f*>(cpy + 2 * q) - oy2;
+                        const v2f d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
+                        m2 = __builtin_elementwise_min(m2, d2);
+                    }
+                    fmin_w[wv][lane] = fminf(m2.x, m2.y);
+                }
+                __syncthreads();
+                double rk = 0.0, thr = 0.0, lb = 0.0;
+                bool sure_acc = false;
+                if (wv == 0) {
+                    rk = valid ? cand[k][2] : 0.0;
+                    thr = rk + c_px;
+                    const double dc = (double)sqrtf(fminf(fminf(fmin_w[0][lane], fmin_w[1][lane]), fminf(fmin_w[2][lane], fmin_w[3][lane])));
+                    const bool sure_rej = dc + 0.01 <= thr;                   // true minimum <= coarse minimum
+                    lb = dc - slack;                                          // true minimum >= lb
+                    sure_acc = lb > thr;
+                    const unsigned long long amb = __ballot(valid && !sure_rej && !sure_acc);
+                    if (lane == 0) { bci[5] = (int)(uint32_t)amb; bci[6] = (int)(uint32_t)(amb >> 32); }
+                }
+                __syncthreads();
+                const unsigned long long amb = ((unsigned long long)(uint32_t)bci[5]) | ((unsigned long long)(uint32_t)bci[6] << 32);
+                {   // exact minima of the undecided obstacles, dealt round-robin to the four waves
+                    unsigned long long rest = amb;
+                    for (int j = 0; rest; ++j) {
+                        const int l = __ffsll((long long)rest) - 1;
+                        rest &= rest - 1ull;
+                        if ((j & (NW - 1)) != wv) continue;
+                        const double ox = cand[k0 + l][0], oy = cand[k0 + l][1];
+                        double md = 1e300;
                         for (int q = lane; q < PPN_PATH_POINTS / 2; q += 64) {
                             const double2 pq = pimg[2 * q + 1];
                             double ppx, ppy;
@@ -306,196 +341,254 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel(MapsParams prm) {
                             const double dx = ppx - ox, dy = ppy - oy;
                             md = fmin(md, dx * dx + dy * dy);
                         }
-                        mn = sqrt(wave_min(md));
-                    }
-                    if (mn > thr) {
-                        accm |= 1ull << (k - k0);
-                        if (!(mn - cand[k][2] > touch_margin) && lane == 0) bci[12] = 1;
+                        md = sqrt(wave_min(md));
+                        if (lane == 0) dref[l] = md;
                     }
                 }
-            }
-            if (lane == 0) { bci[4 + wv] = (int)(uint32_t)accm; bci[8 + wv] = (int)(uint32_t)(accm >> 32); }
-            __syncthreads();
-            unsigned long long all = 0ull;
-            for (int w = 0; w < NW; ++w) all |= ((unsigned long long)(uint32_t)bci[4 + w]) | ((unsigned long long)(uint32_t)bci[8 + w] << 32);
-            const int k = k0 + lane;
-            if (wv == 0 && k < K) {
-                const bool a = (all >> lane) & 1ull;
-                if (O.accept) O.accept[(size_t)m * K + k] = a ? 1 : 0;
-                if (a) {
-                    const int pos = n_rand + __popcll(all & ((1ull << lane) - 1ull));
-                    obs[pos][0] = cand[k][1]; obs[pos][1] = cand[k][0]; obs[pos][2] = cand[k][2];   // [col,row,r]
-                }
-            }
-            n_rand += __popcll(all);
-            __syncthreads();
-        }
-        if (tid == 0) {
-            bci[4] = n_rand;
-            // pocket obstacles keep >= c_px from the odd path points by construction (Path.py:490-491)
-            if (n_pocket > 0 && !(c_px > touch_margin)) bci[12] = 1;
-        }
-    }
-    __syncthreads();
-    PPN_STAMP(3);
-    const int n_rand = bci[4];
-    if (tid < n_pocket) {                                                 // MapGenerate.py:83-89
-        double rx, ry;
-        rot2(c, s, praw[tid][1] - half, praw[tid][0] - half, rx, ry);
-        rx = rx + half + tr0;
-        ry = ry + half + tr1;
-        obs[n_rand + tid][0] = ry; obs[n_rand + tid][1] = rx; obs[n_rand + tid][2] = praw[tid][2];
-    }
-    // the staged points are dead from here: their bytes become the occupancy bit mask
-    for (int w = tid; w < words; w += NT) occw[w] = 0u;
-    __syncthreads();
-    const int n_obs = n_rand + n_pocket;
-    for (int n = tid; n < n_obs; n += NT) {
-        double* o = O.obstacles + ((size_t)m * (K + PPN_MAX_POCKET) + n) * 3;
-        o[0] = obs[n][0]; o[1] = obs[n][1]; o[2] = obs[n][2];
-    }
-    if (tid == 0) {
-        O.n_obstacles[(size_t)m * 2] = n_obs;
-        O.n_obstacles[(size_t)m * 2 + 1] = n_rand;
-        O.flags[m] = flags | path_flags;
-    }
-    PPN_STAMP(4);
-
-    // ------------------------------------------------------------------ raster 1: exact row spans -> LDS bit mask.
-    // One wave per obstacle, one lane per row of its bounding box.  The pixel rule "centre inside the
-    // closed disc" is monotone in |dx| under IEEE rounding, so the columns of a row form an interval:
-    // estimate it with a float sqrt, then settle both ends with the exact double predicate.
-    const int wpr = R / 32;
-    const double c3 = bc[8], s3 = bc[9];
-    // (obstacle, row) pairs are flattened over the whole workgroup: obstacle n owns rows [row_lo[n], row_lo[n] + cnt),
-    // an exclusive scan of the counts (wave 0, shuffles) gives each pair an index, a binary search gives it back.
-    int* row_lo = reinterpret_cast<int*>(poddf);                           // the float points are dead after the filter: 4000 B
-    int* row_off = row_lo + (K + PPN_MAX_POCKET);                          // [n_obs + 1] exclusive offsets (2*(K+64)+1 ints <= 641)
-    for (int n = tid; n < n_obs; n += NT) {
-        const double cy = obs[n][1], r = obs[n][2];
-        const int lo = max((int)floor(cy - r - 0.5), 0), hi = min((int)ceil(cy + r - 0.5), R - 1);
-        row_lo[n] = lo;
-        row_off[n + 1] = max(hi - lo + 1, 0);
-    }
-    __syncthreads();
-    if (wv == 0) {
-        int carry = 0;
-        for (int b0 = 0; b0 < n_obs; b0 += 64) {
-            const int n = b0 + lane;
-            int v = n < n_obs ? row_off[n + 1] : 0;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
-            if (n < n_obs) row_off[n + 1] = carry + v;
-            carry += __shfl(v, 63, 64);
-        }
-        if (lane == 0) row_off[0] = 0;
-    }
-    __syncthreads();
-    const int n_pairs = row_off[n_obs];
-    for (int pr = tid; pr < n_pairs; pr += NT) {
-        int lo_n = 0, hi_n = n_obs - 1;                                    // largest n with row_off[n] <= pr
-        while (lo_n < hi_n) { const int mid = (lo_n + hi_n + 1) >> 1; if (row_off[mid] <= pr) lo_n = mid; else hi_n = mid - 1; }
-        const int n = lo_n, i = row_lo[n] + (pr - row_off[n]);
-        const double cx = obs[n][0], cy = obs[n][1], r = obs[n][2];
-        const double rr = r * r;
-        const double dy = ((double)i + 0.5) - cy;
-        const double dy2 = dy * dy;
-        if (dy2 > rr) continue;                                           // dx*dx + dy2 >= dy2 > rr for every column
-        // real-valued ends of the interval in column units: j + 0.5 in [cx - w, cx + w]
-        const float w = sqrtf((float)(rr - dy2));
-        const float xl = (float)cx - w - 0.5f, xr = (float)cx + w - 0.5f;
-        int jl = (int)ceilf(xl), jh = (int)floorf(xr);
-        // the float estimate is good to < 1e-3 column; an end closer than that to an integer is settled
-        // with the exact double predicate (monotone in |dx|, so one step either way suffices)
-        if (fabsf(xl - rintf(xl)) < 2e-3f) {
-            jl = (int)rintf(xl);
-            while (disc_pred(jl - 1, cx, dy2, rr)) --jl;
-            while (jl <= jh + 1 && !disc_pred(jl, cx, dy2, rr)) ++jl;
-        }
-        if (fabsf(xr - rintf(xr)) < 2e-3f) {
-            jh = (int)rintf(xr);
-            while (disc_pred(jh + 1, cx, dy2, rr)) ++jh;
-            while (jh >= jl - 1 && !disc_pred(jh, cx, dy2, rr)) --jh;
-        }
-        jl = max(jl, 0); jh = min(jh, R - 1);
-        if (jl > jh) continue;
-        uint32_t* row = occw + (size_t)i * wpr;
-        for (int ww = jl >> 5; ww <= (jh >> 5); ++ww) {
-            const int lo = max(jl - ww * 32, 0), hi = min(jh - ww * 32, 31);
-            const uint32_t msk = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-            atomicOr(&row[ww], msk);
-        }
-    }
-    __syncthreads();
-    PPN_STAMP(5);
-
-    // ------------------------------------------------------------------ raster 2: the corridor wins over obstacles
-    // (MapGenerate.py:111 saturating sum): inverse-map the occupied pixels into the target path's mask,
-    // one lane per pixel, 64 consecutive pixels per wave step.  Skipped when no obstacle can touch it.
-    if (bci[12]) {
-        for (int base = wv * 64; base < R * R; base += NT) {
-            const int px = base + lane;
-            const int i = px / R, j = px - i * R;
-            const uint32_t wbits = occw[px >> 5];
-            bool clr = false;
-            if ((wbits >> (px & 31)) & 1u) {
-                const int i1 = i - t1, j1 = j - t0;                       // translate: (tx, ty) = (translation[0], [1])
-                if (i1 >= 0 && i1 < R && j1 >= 0 && j1 < R) {
-                    const double yo = ((double)i1 + 0.5) - half, xo = ((double)j1 + 0.5) - half;
-                    const double xs = c3 * xo - s3 * yo, ys = s3 * xo + c3 * yo;
-                    const int jj = (int)rint(xs + (half - 0.5)), ii = (int)rint(ys + (half - 0.5));
-                    if (ii >= 0 && ii < R && jj >= 0 && jj < R) {
-                        const int bit = ii * R + jj;
-                        clr = (P.space_bits[(size_t)pj * words + (bit >> 5)] >> (bit & 31)) & 1u;   // rare pass: straight from L2
+                if (amb) __syncthreads();                                     // uniform: every thread read the same bci words
+                if (wv == 0) {
+                    const bool refined = (amb >> lane) & 1ull;
+                    const double mn = refined ? dref[lane] : lb;              // exact, or a lower bound that settles it
+                    const bool acc = valid && (refined ? (mn > thr) : sure_acc);
+                    const unsigned long long all = __ballot(acc);
+                    // conservative for unrefined obstacles (lower bound): the flag may only be set too often
+                    if (__ballot(acc && !(mn - rk > touch_margin)) && lane == 0) bci[12] = 1;
+                    if (valid) {
+                        if (O.accept) O.accept[(size_t)m * K + k] = acc ? 1 : 0;
+                        if (acc) {
+                            const int pos = n_rand + __popcll(all & ((1ull << lane) - 1ull));
+                            obs[pos][0] = cand[k][1]; obs[pos][1] = cand[k][0]; obs[pos][2] = cand[k][2];   // [col,row,r]
+                        }
                     }
+                    n_rand += __popcll(all);
                 }
+                if (k0 + 64 < K) __syncthreads();                             // fmin_w / bci[5..6] / dref are reused by the next group
             }
-            const unsigned long long cm = __ballot(clr);
-            if (cm) {
-                if (lane == 0 && (uint32_t)cm) occw[px >> 5] = wbits & ~(uint32_t)cm;
-                if (lane == 32 && (uint32_t)(cm >> 32)) occw[px >> 5] = wbits & ~(uint32_t)(cm >> 32);
+            if (tid == 0) {
+                bci[4] = n_rand;
+                // pocket obstacles keep >= c_px from the odd path points by construction (Path.py:490-491)
+                if (n_pocket > 0 && !(c_px > touch_margin)) bci[12] = 1;
             }
         }
         __syncthreads();
-    }
-    PPN_STAMP(6);
-
-    // ------------------------------------------------------------------ raster 3: bits -> bytes, two 16-byte stores
-    // per lane per step (8 bits -> 8 bytes through the LDS table; the two 7x7 marker squares touch <= 28 words)
-    {
-        const int r_init = (int)rint(bc[2]), c_init = (int)rint(bc[3]);   // process_map.py:127-135
-        const int r_end = (int)rint(bc[4]), c_end = (int)rint(bc[5]);
-        const int sh = (wpr & (wpr - 1)) == 0 ? 31 - __clz(wpr) : -1;     // log2(words per row) when R/32 is a power of two
-        uint8_t* g = O.grid + (size_t)m * R * R;
-        for (int w = tid; w < words; w += NT) {
-            const int i = sh >= 0 ? (w >> sh) : (w / wpr);
-            const int j0 = (w - i * wpr) * 32;
-            const uint32_t occ = occw[w];
-            uint64_t q0 = lut[occ & 0xffu], q1 = lut[(occ >> 8) & 0xffu], q2 = lut[(occ >> 16) & 0xffu], q3 = lut[occ >> 24];
-            const bool ri = (i >= r_init - 3) && (i <= r_init + 3), re = (i >= r_end - 3) && (i <= r_end + 3);
-            if (ri || re) {
-                uint32_t mark = 0u;
-                if (ri) {
-                    const int lo = max(c_init - 3 - j0, 0), hi = min(c_init + 3 - j0, 31);
-                    if (lo <= hi) mark |= (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-                }
-                if (re) {
-                    const int lo = max(c_end - 3 - j0, 0), hi = min(c_end + 3 - j0, 31);
-                    if (lo <= hi) mark |= (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-                }
-                if (mark) {                                               // MARK = 0x80 over whatever is there
-                    const uint64_t m0 = ~lut[mark & 0xffu], m1 = ~lut[(mark >> 8) & 0xffu], m2 = ~lut[(mark >> 16) & 0xffu],
-                                   m3 = ~lut[mark >> 24];                 // 0xFF where marked
-                    q0 = (q0 & ~m0) | (m0 & 0x8080808080808080ull); q1 = (q1 & ~m1) | (m1 & 0x8080808080808080ull);
-                    q2 = (q2 & ~m2) | (m2 & 0x8080808080808080ull); q3 = (q3 & ~m3) | (m3 & 0x8080808080808080ull);
-                }
-            }
-            uint4* dst = reinterpret_cast<uint4*>(g + (size_t)i * R + j0);
-            dst[0] = make_uint4((uint32_t)q0, (uint32_t)(q0 >> 32), (uint32_t)q1, (uint32_t)(q1 >> 32));
-            dst[1] = make_uint4((uint32_t)q2, (uint32_t)(q2 >> 32), (uint32_t)q3, (uint32_t)(q3 >> 32));
+        PPN_STAMP(3);
+        const int n_rand = bci[4];
+        if (tid < n_pocket) {                                                 // MapGenerate.py:83-89
+            double rx, ry;
+            rot2(c, s, praw[tid][1] - half, praw[tid][0] - half, rx, ry);
+            rx = rx + half + tr0;
+            ry = ry + half + tr1;
+            obs[n_rand + tid][0] = ry; obs[n_rand + tid][1] = rx; obs[n_rand + tid][2] = praw[tid][2];
+        }
+        __syncthreads();
+        n_obs = n_rand + n_pocket;
+        for (int n = tid; n < n_obs; n += NT) {
+            double* o = O.obstacles + ((size_t)m * (K + PPN_MAX_POCKET) + n) * 3;
+            o[0] = obs[n][0]; o[1] = obs[n][1]; o[2] = obs[n][2];
+        }
+        if (tid == 0) {
+            O.n_obstacles[(size_t)m * 2] = n_obs;
+            O.n_obstacles[(size_t)m * 2 + 1] = n_rand;
+            // PPN_FLAG_CORRIDOR_PASS tells the raster kernel that some obstacle may touch the corridor
+            O.flags[m] = flags | path_flags | (bci[12] ? PPN_FLAG_CORRIDOR_PASS : 0u);
+        }
+        compose = bci[12] != 0;                                           // same thread wrote it or a barrier lies between
+        PPN_STAMP(4);
+    } else {
+        n_obs = O.n_obstacles[(size_t)m * 2];
+        t0 = O.translation[(size_t)m * 2]; t1 = O.translation[(size_t)m * 2 + 1];
+        compose = prm.force_compose || (O.flags[m] & PPN_FLAG_CORRIDOR_PASS);
+        for (int n = tid; n < n_obs; n += NT) {
+            const double* o = O.obstacles + ((size_t)m * (K + PPN_MAX_POCKET) + n) * 3;
+            obs[n][0] = o[0]; obs[n][1] = o[1]; obs[n][2] = o[2];
+        }
+        if (tid == 0) {
+            bc[2] = O.segpoint[(size_t)m * 22];      bc[3] = O.segpoint[(size_t)m * 22 + 1];        // init = segpoint[0]
+            bc[4] = O.segpoint[(size_t)m * 22 + 20]; bc[5] = O.segpoint[(size_t)m * 22 + 21];       // end  = segpoint[10]
+            double s3v, c3v;
+            sincos_small((-O.angle[m]) * PI / 180.0, s3v, c3v);           // rotate_nearest(space, -angle)
+            bc[8] = c3v; bc[9] = s3v;
         }
     }
-    PPN_STAMP(7);
+
+    if constexpr (PHASE & 2) {
+        // fused: the staged points are dead from here, their bytes become the occupancy bit mask
+        for (int w = tid; w < words; w += NT) occw[w] = 0u;
+        {   // byte-expansion table: bit k set (= occupied) -> byte k 0x00, clear -> 0xFF
+            uint64_t v = 0ull;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v |= ((tid >> k) & 1) ? 0ull : (0xFFull << (8 * k));
+            lut[tid] = v;
+        }
+        int* row_lo = reinterpret_cast<int*>(poddf);                       // the float points are dead after the filter
+        int* row_off = row_lo + (K + PPN_MAX_POCKET);                      // [n_obs + 1] exclusive offsets (2*(K+64)+1 ints <= 641)
+        __syncthreads();
+
+        // ------------------------------------------------------------------ raster 1: exact row spans -> LDS bit mask.
+        // One wave per obstacle, one lane per row of its bounding box.  The pixel rule "centre inside the
+        // closed disc" is monotone in |dx| under IEEE rounding, so the columns of a row form an interval:
+        // estimate it with a float sqrt, then settle both ends with the exact double predicate.
+        const int wpr = R / 32;
+        const double c3 = bc[8], s3 = bc[9];
+        // (obstacle, row) pairs are flattened over the whole workgroup: obstacle n owns rows [row_lo[n], row_lo[n] + cnt),
+        // an exclusive scan of the counts (wave 0, shuffles) gives each pair an index, a binary search gives it back.
+        for (int n = tid; n < n_obs; n += NT) {
+            const double cy = obs[n][1], r = obs[n][2];
+            const int lo = max((int)floor(cy - r - 0.5), 0), hi = min((int)ceil(cy + r - 0.5), R - 1);
+            row_lo[n] = lo;
+            row_off[n + 1] = max(hi - lo + 1, 0);
+        }
+        __syncthreads();
+        if (wv == 0) {
+            int carry = 0;
+            for (int b0 = 0; b0 < n_obs; b0 += 64) {
+                const int n = b0 + lane;
+                int v = n < n_obs ? row_off[n + 1] : 0;
+    #pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+                if (n < n_obs) row_off[n + 1] = carry + v;
+                carry += __shfl(v, 63, 64);
+            }
+            if (lane == 0) row_off[0] = 0;
+        }
+        __syncthreads();
+        const int n_pairs = row_off[n_obs];
+        // each thread takes a contiguous run of pairs: one binary search for the first, then it walks rows / obstacles
+        const int run = (n_pairs + NT - 1) / NT;
+        int pr = tid * run;
+        const int pr_end = min(pr + run, n_pairs);
+        int n = 0;
+        if (pr < pr_end) {
+            int lo_n = 0, hi_n = n_obs - 1;                                // largest n with row_off[n] <= pr
+            while (lo_n < hi_n) { const int mid = (lo_n + hi_n + 1) >> 1; if (row_off[mid] <= pr) lo_n = mid; else hi_n = mid - 1; }
+            n = lo_n;
+        }
+        int nxt = pr < pr_end ? row_off[n + 1] : 0;                        // first pair of the next obstacle
+        for (; pr < pr_end; ++pr) {
+            while (pr >= nxt) { ++n; nxt = row_off[n + 1]; }               // obstacles with an empty row range are skipped
+            const int i = row_lo[n] + (pr - row_off[n]);
+            const double cx = obs[n][0], cy = obs[n][1], r = obs[n][2];
+            const double rr = r * r;
+            const double dy = ((double)i + 0.5) - cy;
+            const double dy2 = dy * dy;
+            if (dy2 > rr) continue;                                       // dx*dx + dy2 >= dy2 > rr for every column
+            // real-valued ends of the interval in column units: j + 0.5 in [cx - w, cx + w]
+            const float w = __builtin_amdgcn_sqrtf((float)(rr - dy2));     // 1-ulp hardware sqrt: an estimate is all it is
+            const float xl = (float)cx - w - 0.5f, xr = (float)cx + w - 0.5f;
+            int jl = (int)ceilf(xl), jh = (int)floorf(xr);
+            // the float estimate is good to < 1e-3 column; an end closer than that to an integer is settled
+            // with the exact double predicate (monotone in |dx|, so one step either way suffices)
+            if (fabsf(xl - rintf(xl)) < 2e-3f) {
+                jl = (int)rintf(xl);
+                while (disc_pred(jl - 1, cx, dy2, rr)) --jl;
+                while (jl <= jh + 1 && !disc_pred(jl, cx, dy2, rr)) ++jl;
+            }
+            if (fabsf(xr - rintf(xr)) < 2e-3f) {
+                jh = (int)rintf(xr);
+                while (disc_pred(jh + 1, cx, dy2, rr)) ++jh;
+                while (jh >= jl - 1 && !disc_pred(jh, cx, dy2, rr)) --jh;
+            }
+            jl = max(jl, 0); jh = min(jh, R - 1);
+            if (jl > jh) continue;
+            uint32_t* row = occw + (size_t)i * wpr;
+            for (int ww = jl >> 5; ww <= (jh >> 5); ++ww) {
+                const int lo = max(jl - ww * 32, 0), hi = min(jh - ww * 32, 31);
+                const uint32_t msk = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+                atomicOr(&row[ww], msk);
+            }
+        }
+        __syncthreads();
+        PPN_STAMP(5);
+
+        // ------------------------------------------------------------------ raster 2: the corridor wins over obstacles
+        // (MapGenerate.py:111 saturating sum): inverse-map the occupied pixels into the target path's mask,
+        // one lane per pixel, 64 consecutive pixels per wave step.  Skipped when no obstacle can touch it.
+        if (compose) {
+            for (int base = wv * 64; base < R * R; base += NT) {
+                const int px = base + lane;
+                const int i = px / R, j = px - i * R;
+                const uint32_t wbits = occw[px >> 5];
+                bool clr = false;
+                if ((wbits >> (px & 31)) & 1u) {
+                    const int i1 = i - t1, j1 = j - t0;                       // translate: (tx, ty) = (translation[0], [1])
+                    if (i1 >= 0 && i1 < R && j1 >= 0 && j1 < R) {
+                        const double yo = ((double)i1 + 0.5) - half, xo = ((double)j1 + 0.5) - half;
+                        const double xs = c3 * xo - s3 * yo, ys = s3 * xo + c3 * yo;
+                        const int jj = (int)rint(xs + (half - 0.5)), ii = (int)rint(ys + (half - 0.5));
+                        if (ii >= 0 && ii < R && jj >= 0 && jj < R) {
+                            const int bit = ii * R + jj;
+                            clr = (P.space_bits[(size_t)pj * words + (bit >> 5)] >> (bit & 31)) & 1u;   // rare pass: straight from L2
+                        }
+                    }
+                }
+                const unsigned long long cm = __ballot(clr);
+                if (cm) {
+                    if (lane == 0 && (uint32_t)cm) occw[px >> 5] = wbits & ~(uint32_t)cm;
+                    if (lane == 32 && (uint32_t)(cm >> 32)) occw[px >> 5] = wbits & ~(uint32_t)(cm >> 32);
+                }
+            }
+            __syncthreads();
+        }
+        PPN_STAMP(6);
+
+        // ------------------------------------------------------------------ raster 3: bits -> bytes, two 16-byte stores
+        // per lane per step (8 bits -> 8 bytes through the LDS table; the two 7x7 marker squares touch <= 28 words)
+        {
+            const int r_init = (int)rint(bc[2]), c_init = (int)rint(bc[3]);   // process_map.py:127-135
+            const int r_end = (int)rint(bc[4]), c_end = (int)rint(bc[5]);
+            uint8_t* g = O.grid + (size_t)m * R * R;
+            // words of the marker rows: [w_i0, w_i1) and [w_e0, w_e1); the rest never needs its row or column
+            const int w_i0 = (r_init - 3) * wpr, w_i1 = (r_init + 4) * wpr, w_e0 = (r_end - 3) * wpr, w_e1 = (r_end + 4) * wpr;
+            for (int w = tid; w < words; w += NT) {
+                const uint32_t occ = occw[w];
+                uint64_t q0 = lut[occ & 0xffu], q1 = lut[(occ >> 8) & 0xffu], q2 = lut[(occ >> 16) & 0xffu], q3 = lut[occ >> 24];
+                const bool ri = (w >= w_i0) && (w < w_i1), re = (w >= w_e0) && (w < w_e1);
+                if (ri || re) {
+                    const int i = w / wpr;
+                    const int j0 = (w - i * wpr) * 32;
+                    uint32_t mark = 0u;
+                    if (ri) {
+                        const int lo = max(c_init - 3 - j0, 0), hi = min(c_init + 3 - j0, 31);
+                        if (lo <= hi) mark |= (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+                    }
+                    if (re) {
+                        const int lo = max(c_end - 3 - j0, 0), hi = min(c_end + 3 - j0, 31);
+                        if (lo <= hi) mark |= (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+                    }
+                    if (mark) {                                           // MARK = 0x80 over whatever is there
+                        const uint64_t m0 = ~lut[mark & 0xffu], m1 = ~lut[(mark >> 8) & 0xffu], m2 = ~lut[(mark >> 16) & 0xffu],
+                                       m3 = ~lut[mark >> 24];             // 0xFF where marked
+                        q0 = (q0 & ~m0) | (m0 & 0x8080808080808080ull); q1 = (q1 & ~m1) | (m1 & 0x8080808080808080ull);
+                        q2 = (q2 & ~m2) | (m2 & 0x8080808080808080ull); q3 = (q3 & ~m3) | (m3 & 0x8080808080808080ull);
+                    }
+                }
+                uint4* dst = reinterpret_cast<uint4*>(g + (size_t)w * 32);
+                dst[0] = make_uint4((uint32_t)q0, (uint32_t)(q0 >> 32), (uint32_t)q1, (uint32_t)(q1 >> 32));
+                dst[1] = make_uint4((uint32_t)q2, (uint32_t)(q2 >> 32), (uint32_t)q3, (uint32_t)(q3 >> 32));
+            }
+        }
+        PPN_STAMP(7);
+    }
+}
+
+template <int PHASE>
+static int launch_phase(const MapsParams& prm, hipStream_t stream) {
+    const int R = prm.R, K = prm.K;
+    const size_t lds = (size_t)maps_region_bytes(PHASE, R) + ((PHASE & 1) ? (size_t)K * 24 : 0) + (size_t)(K + PPN_MAX_POCKET) * 24 +
+                       maps_tab_bytes(K) + ((PHASE & 2) ? 256 * 8 : 0) + ((PHASE & 1) ? (size_t)PPN_MAX_POCKET * 24 : 0);
+    if (hipFuncSetAttribute((const void*)edage_maps_kernel_t<PHASE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PPN_E_HIP;
+    hipLaunchKernelGGL(edage_maps_kernel_t<PHASE>, dim3((unsigned)prm.n_maps), dim3(NT), lds, stream, prm);
+    return hipGetLastError() == hipSuccess ? PPN_OK : PPN_E_HIP;
+}
+
+int edage_maps_launch(int phase, const MapsParams& prm, hipStream_t stream) {
+    switch (phase) {
+        case 1: return launch_phase<1>(prm, stream);
+        case 2: return launch_phase<2>(prm, stream);
+        case 3: return launch_phase<3>(prm, stream);
+    }
+    return PPN_E_INVALID;
 }
 
 #ifdef PPN_PHASE_TIMING

@@ -39,7 +39,8 @@ struct MapsParams {
 };
 
 __global__ void edage_paths_kernel(PathsParams prm);
-__global__ void edage_maps_kernel(MapsParams prm);
+// phase: 1 = placement / labels / filter, 2 = obstacle lists -> grid, 3 = both in one kernel
+int edage_maps_launch(int phase, const MapsParams& prm, hipStream_t stream);
 __global__ void boundary_check_kernel(const double* hull, int hull_n, const double* angle_deg,
                                       const double* trans_rc, int n, int R, uint8_t* ok, double* hull_out);
 __global__ void obstacle_filter_kernel(const double* pathpoint, const double* draws, int n, int K, int R,

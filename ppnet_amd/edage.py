@@ -121,8 +121,12 @@ def generate_paths(n_paths, resolution=224, map_size=50, clearance=1, seed=0, fi
 
 
 def generate_maps(paths, placements, obstacles_size=5, obstacles_num=50, seed=0, first_map_id=0, place_draws=None,
-                  obst_draws=None, want_pathpoint=True, want_accept=True, out=None):
-    """Stage B: `placements` maps for each target path in `paths` (a PathsBatch)."""
+                  obst_draws=None, want_pathpoint=True, want_accept=True, out=None, phase="both"):
+    """Stage B: `placements` maps for each target path in `paths` (a PathsBatch).
+
+    phase="place" runs only the placement / label / filter kernel (everything but `grid`), phase="raster" only the
+    grid kernel on a MapsBatch a "place" call filled (pass it as `out`); "both" is the two back to back."""
+    assert phase in ("both", "place", "raster")
     n = paths.n * placements
     K = int(obstacles_num)
     mb = out if out is not None else MapsBatch(n, paths.R, K, paths.device, want_pathpoint, want_accept)
@@ -131,10 +135,16 @@ def generate_maps(paths, placements, obstacles_size=5, obstacles_num=50, seed=0,
     if obst_draws is not None:
         assert obst_draws.dtype == torch.float64 and obst_draws.is_contiguous() and tuple(obst_draws.shape) == (n, 3 * K)
     with torch.cuda.device(paths.device):
-        rc = L.lib.ppn_edage_maps(C.byref(paths.struct), paths.n, placements, first_map_id, paths.R, paths.map_size,
-                                  float(obstacles_size), K, paths.clearance, seed, _ptr(place_draws), _ptr(obst_draws),
-                                  C.byref(mb.struct), _stream_ptr(paths.device))
-    L.check(rc, "ppn_edage_maps")
+        if phase == "raster":
+            assert out is not None, "phase='raster' needs the MapsBatch of the matching 'place' call"
+            rc = L.lib.ppn_edage_maps_raster(C.byref(paths.struct), paths.n, placements, paths.R, K,
+                                             C.byref(mb.struct), _stream_ptr(paths.device))
+        else:
+            fn = L.lib.ppn_edage_maps if phase == "both" else L.lib.ppn_edage_maps_place
+            rc = fn(C.byref(paths.struct), paths.n, placements, first_map_id, paths.R, paths.map_size,
+                    float(obstacles_size), K, paths.clearance, seed, _ptr(place_draws), _ptr(obst_draws),
+                    C.byref(mb.struct), _stream_ptr(paths.device))
+    L.check(rc, "ppn_edage_maps" if phase == "both" else "ppn_edage_maps_" + phase)
     return mb
 
 

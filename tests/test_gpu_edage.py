@@ -109,7 +109,7 @@ def test_config1_labels_vs_reference_golden(dev, golden_dir):
     """Stage B fed with the reference's own accepted (angle, translation) and obstacle draws for
     BASELINE config 1 (100 maps, R=64): labels, accept masks and obstacle lists match the reference."""
     import torch
-    from ppnet_amd import edage
+    from ppnet_amd import edage, _lib
     g = np.load(os.path.join(golden_dir, "g10_config1_R64.npz"))
     R, K, P = 64, 20, 10
     # rebuild stage-A inputs of stage B from the golden target paths
@@ -146,7 +146,7 @@ def test_config1_labels_vs_reference_golden(dev, golden_dir):
     torch.cuda.synchronize()
     assert np.array_equal(_np(mb.translation), g["translation"])
     _close(_np(mb.angle), g["angle"], 1e-9)
-    assert (_np(mb.attempts) == 1).all() and (_np(mb.flags) == 0).all()
+    assert (_np(mb.attempts) == 1).all() and ((_np(mb.flags) & ~_lib.FLAG_CORRIDOR_PASS) == 0).all()
     _close(_np(mb.segpoint), g["segpoint"])
     _close(_np(mb.pathpoint), g["pathpoint"])
     n_obs = _np(mb.n_obstacles)[:, 0]
@@ -159,7 +159,7 @@ def test_config1_labels_vs_reference_golden(dev, golden_dir):
 @pytest.mark.parametrize("R,clearance,seed,n", [(64, 3, 1, 12), (256, 3, 0, 12), (224, 1, 5, 6), (128, 3, 9, 8), (512, 3, 2, 3)])
 def test_paths_and_maps_philox_vs_oracle(dev, R, clearance, seed, n):
     import torch
-    from ppnet_amd import edage
+    from ppnet_amd import edage, _lib
     K, placements, osz = 20, 5, 5
     pb = edage.generate_paths(n, R, 50, clearance, seed=seed, device=dev, debug=True)
     mb = edage.generate_maps(pb, placements, obstacles_size=osz, obstacles_num=K, seed=seed)
@@ -198,7 +198,7 @@ def test_paths_and_maps_philox_vs_oracle(dev, R, clearance, seed, n):
         nt, nr = _np(mb.n_obstacles[m]).tolist()
         assert nt == len(om["obstacles"]) and nr == om["n_random"]
         _close(_np(mb.obstacles[m])[:nt], om["obstacles"], POCKET_TOL)
-        assert int(mb.flags[m]) == (om["flags"] | precs[m // placements]["flags"])
+        assert (int(mb.flags[m]) & ~_lib.FLAG_CORRIDOR_PASS) == (om["flags"] | precs[m // placements]["flags"])
         assert np.array_equal(grid[m], om["grid"]), f"grid {m}: {(grid[m] != om['grid']).sum()} px differ"   # exact
 
 
@@ -283,6 +283,34 @@ def test_corridor_compose_skip_is_exact(dev, R, clearance):
         del os.environ["PPN_FORCE_COMPOSE"]
     assert torch.equal(a.grid, b.grid)
     assert torch.equal(a.pathpoint, b.pathpoint)
+
+
+def test_split_phases_equal_single_call(dev):
+    """ppn_edage_maps_place + ppn_edage_maps_raster (separate launches, the raster on another stream behind an
+    event) fill a MapsBatch exactly as ppn_edage_maps does; the place phase alone leaves `grid` untouched."""
+    import torch
+    from ppnet_amd import edage, _lib
+    P, placements, K, R = 30, 20, 50, 256
+    pb = edage.generate_paths(P, R, 50, 1, seed=5, device=dev)        # clearance 1: the compose pass runs on some maps
+    a = edage.generate_maps(pb, placements, 5, K, seed=5)
+    b = edage.MapsBatch(P * placements, R, K, dev)
+    b.grid.fill_(7)
+    edage.generate_maps(pb, placements, 5, K, seed=5, out=b, phase="place")
+    torch.cuda.synchronize()
+    assert (b.grid == 7).all()
+    for f in ("angle", "translation", "attempts", "segpoint", "pathpoint", "accept", "n_obstacles", "flags"):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        edage.generate_maps(pb, placements, 5, K, out=b, phase="raster")
+    side.synchronize()
+    assert torch.equal(a.grid, b.grid)
+    # clearance 1: the band (c_px, touch_margin] is populated on practically every map, so the compose pass ran;
+    # clearance 3: touch_margin < c_px, no accepted obstacle can touch the corridor and the pass is skipped
+    assert int((a.flags & _lib.FLAG_CORRIDOR_PASS != 0).sum()) > 0.9 * P * placements
+    pb3 = edage.generate_paths(P, R, 50, 3, seed=5, device=dev)
+    a3 = edage.generate_maps(pb3, placements, 5, K, seed=5)
+    assert int((a3.flags & _lib.FLAG_CORRIDOR_PASS).sum()) == 0
 
 
 def test_label_masks_vs_oracle_and_reference_golden(dev, golden_dir):
