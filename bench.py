@@ -146,43 +146,54 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    # buffers are allocated once and reused every step (resident in HBM).  Stage A of batch i+1 runs on its
-    # own HIP stream while stage B of batch i writes its maps: two path buffers, events for the hand-off.
-    pbs = [edage.PathsBatch(PATHS, R, MAP_SIZE, CLEARANCE, dev) for _ in range(2)]
+    # buffers are allocated once and reused every step (resident in HBM).  Stage A is a latency chain (one workgroup
+    # per path, ~0.19 ms for 100 paths) that leaves most of the chip idle, so it runs DEPTH batches ahead of stage B on
+    # its own HIP streams: while stage B of batch i writes its maps, stage A of batches i+1 .. i+DEPTH is in flight.
+    # DEPTH+1 path buffers, events for the hand-off.  Every step launches exactly one stage-A and one stage-B kernel.
+    DEPTH = 2
+    TIMED_EVERY = 4
+    NPB = DEPTH + 1
+    pbs = [edage.PathsBatch(PATHS, R, MAP_SIZE, CLEARANCE, dev) for _ in range(NPB)]
     mb = edage.MapsBatch(PATHS * PLACEMENTS, R, K, dev)
-    s_paths = torch.cuda.Stream(dev)
+    s_paths = [torch.cuda.Stream(dev) for _ in range(DEPTH)]
     s_maps = torch.cuda.current_stream(dev)
-    ready = [None, None]          # paths of buffer b are complete
-    consumed = [None, None]       # maps kernel reading buffer b has finished
+    ready = [None] * NPB          # paths of buffer b are complete
+    consumed = [None] * NPB       # the maps kernel reading buffer b has finished
+    launched = [-1]               # newest batch whose stage A has been launched
 
     def launch_paths(it):
-        b = it % 2
+        b = it % NPB
+        sp = s_paths[it % DEPTH]
         first_path, _, _ = shard.local_ids(PATHS * world, PLACEMENTS, rank, world, batch_index=it)
-        with torch.cuda.stream(s_paths):
+        with torch.cuda.stream(sp):
             if consumed[b] is not None:
-                s_paths.wait_event(consumed[b])
+                sp.wait_event(consumed[b])
             edage.generate_paths(PATHS, R, MAP_SIZE, CLEARANCE, seed=SEED, first_path_id=first_path, device=dev, out=pbs[b])
             ready[b] = torch.cuda.Event()
-            ready[b].record(s_paths)
+            ready[b].record(sp)
+        launched[0] = it
     n_local = PATHS * PLACEMENTS
 
-    def step(it, last=False):
+    def step(it):
         # a fresh batch every step: path / map ids advance so no two steps generate the same instances
-        b = it % 2
-        first_path, _, first_map = shard.local_ids(PATHS * world, PLACEMENTS, rank, world, batch_index=it)
-        if ready[b] is None:
-            launch_paths(it)                  # pipeline fill (first step only)
-        if not last:
-            launch_paths(it + 1)              # stage A of the next batch, overlapped with this batch's stage B
+        b = it % NPB
+        _, _, first_map = shard.local_ids(PATHS * world, PLACEMENTS, rank, world, batch_index=it)
+        while launched[0] < it + DEPTH - 1:
+            launch_paths(launched[0] + 1)     # pipeline fill (first step only)
+        launch_paths(it + DEPTH)              # this step's stage A: the batch stage B will reach DEPTH steps from now
         s_maps.wait_event(ready[b])
         ready[b] = None
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
-        ev0.record()
+        # every event is a marker packet the queue has to drain before the next kernel starts (~5 us each on this
+        # runtime), so the stream carries one per step (it doubles as the buffer hand-off) and a start marker only on
+        # every TIMED_EVERY-th step: those launches are the sample the roofline's kernel duration is averaged over
+        ev0 = None
+        if it % TIMED_EVERY == 0 or args.steps < TIMED_EVERY:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         edage.generate_maps(pbs[b], PLACEMENTS, OBST_SIZE, K, seed=SEED, first_map_id=first_map, out=mb)
+        ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        consumed[b] = torch.cuda.Event()
-        consumed[b].record(s_maps)
+        consumed[b] = ev1
         if world > 1:                         # end-of-batch gather of the fixed-size records (RCCL over xGMI)
             shard.gather_records(shard.pack_records(mb.angle, mb.flags, mb.translation, mb.segpoint), world)
         return ev0, ev1
@@ -193,7 +204,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    evs = [step(args.warmup + it, last=(it == args.steps - 1)) for it in range(args.steps)]
+    evs = [step(args.warmup + it) for it in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -203,7 +214,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    maps_kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+    timed = [(a, b) for a, b in evs if a is not None]
+    maps_kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / len(timed)
     k_tot = float(mb.n_obstacles[:, 0].double().mean().item())
     k_pocket = float(pbs[0].n_obstacles.double().mean().item())
     placed = float(((mb.flags & 2) == 0).double().mean().item())
@@ -234,7 +246,7 @@ def main():
                        "rng": "philox4x32-10", "parallelism": f"instances sharded over {world} GPU(s), end-of-batch all-gather"},
             "roofline": {"bound": "hbm", "kernel": "edage_maps_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(),
-                         "kernel_ms": round(maps_kernel_ms, 4), "units_per_launch": n_local,
+                         "kernel_ms": round(maps_kernel_ms, 4), "timed_launches": len(timed), "units_per_launch": n_local,
                          "algorithmic_bytes_per_map": round(algorithmic_bytes_per_map(k_tot, k_pocket), 1),
                          "survey_bytes_per_map": round(2 * R * R + 16384 + 12.0 * k_tot, 1)},
             "placement_success": round(placed, 4),

@@ -29,6 +29,10 @@ __device__ unsigned long long g_phase_cycles[16];
 #define PPN_STAMP_INIT do {} while (0)
 #endif
 
+#ifndef PPN_MAPS_WAVES_PER_EU
+#define PPN_MAPS_WAVES_PER_EU 7   // register budget of the stage-B kernel: waves per SIMD it must allow (7 -> <= 72 VGPRs)
+#endif
+
 namespace {
 constexpr int NT = 256;
 constexpr int NW = NT / 64;
@@ -37,10 +41,9 @@ constexpr double PI = 3.141592653589793;
 constexpr int NCOARSE = PPN_PATH_POINTS / 8 + 1;   // coarse points of the clearance filter: odd points 0, 4, .., 496 and 499
 }
 
-// bytes of the first dynamic-LDS region: staged path points (phase 1) and / or the occupancy bit mask (phase 2)
+// bytes of the first dynamic-LDS region: the occupancy bit mask (phase 2)
 __host__ __device__ constexpr int maps_region_bytes(int phase, int R) {
-    const int pts = (phase & 1) ? PPN_PATH_POINTS * 16 : 0, occ = (phase & 2) ? R * R / 8 : 0;
-    return pts > occ ? pts : occ;
+    return (phase & 2) ? R * R / 8 : 0;
 }
 
 // bytes of the region that holds the filter's coarse float points, then the raster's row tables (2*(K+64)+1 ints)
@@ -64,10 +67,9 @@ __device__ __forceinline__ uint32_t expand4(uint32_t b) {
 // labels, clearance filter: every output but `grid`) and PHASE 2 (obstacle lists -> `grid`, reading what PHASE 1 left in
 // global memory) are the same code as two launches (ppn_edage_maps_place / _raster).
 template <int PHASE>
-__global__ __launch_bounds__(NT) void edage_maps_kernel_t(MapsParams prm) {
+__global__ __launch_bounds__(NT, PPN_MAPS_WAVES_PER_EU) void edage_maps_kernel_t(MapsParams prm) {
     // dynamic LDS carve (all 8-byte aligned):
-    //   regionP             PHASE&1: the target path's 1000 image-frame points (double2, staged by waves 1-3 while wave 0
-    //                       runs the placement loop); PHASE&2: the R*R-bit occupancy mask (after the filter when fused)
+    //   occw  [R*R/32] u32  the R*R-bit occupancy mask                                 (PHASE&2)
     //   cand  [K][3] f64    candidates (row, col, r)                                   (PHASE&1)
     //   obs   [K+64][3] f64 kept + pocket obstacles (col, row, r)
     //   poddf [2][128] f32  float copy of the 126 coarse odd points as planes x | y (filter
@@ -100,7 +102,8 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel_t(MapsParams prm) {
     const int words = R * R / 32;
     const int regionP_bytes = maps_region_bytes(PHASE, R);
     unsigned char* lds = reinterpret_cast<unsigned char*>(lds_raw);
-    double2* pimg = reinterpret_cast<double2*>(lds);
+    // the target path's 1000 image-frame points: read straight from global memory (100 placements share them in L2)
+    const double2* pimg = reinterpret_cast<const double2*>(P.pathpoint_image) + (size_t)pj * PPN_PATH_POINTS;
     uint32_t* occw = reinterpret_cast<uint32_t*>(lds);
     const size_t cand_bytes = (PHASE & 1) ? (size_t)K * 24 : 0;
     double (*cand)[3] = reinterpret_cast<double (*)[3]>(lds + regionP_bytes);
@@ -121,6 +124,14 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel_t(MapsParams prm) {
         const int hn = P.hull_n[pj];
         const int n_pocket = P.n_obstacles[pj];
         const uint32_t path_flags = P.flags[pj];
+        // this thread's label points (L2 hits: 100 placements share a path): waves 1-3 have them in flight while the
+        // placement runs, wave 0 asks for them once its loop is over (they would cost it 16 VGPRs across the loop)
+        constexpr int PER = (PPN_PATH_POINTS + NT - 1) / NT;
+        double2 pq_r[PER];
+        if (wv != 0) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) { const int q = tid + k * NT; pq_r[k] = pimg[q < PPN_PATH_POINTS ? q : 0]; }
+        }
         if (wv == 0) {
             // wave 0: hull, then straight into the placement loop (same wave: LDS keeps program order)
             hullc[lane][0] = P.hull[((size_t)pj * PPN_MAX_HULL + lane) * 2] - half;
@@ -129,15 +140,6 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel_t(MapsParams prm) {
         } else {
             // waves 1..3, concurrently with the placement: stage everything that does not depend on it
             const int t3 = tid - 64;
-            {   // 1000 points over 192 lanes: issue every load before the first LDS store (one L2 round trip, not six)
-                constexpr int PER = (PPN_PATH_POINTS + (NT - 64) - 1) / (NT - 64);
-                const double2* src = reinterpret_cast<const double2*>(P.pathpoint_image) + (size_t)pj * PPN_PATH_POINTS;
-                double2 r[PER];
-    #pragma unroll
-                for (int k = 0; k < PER; ++k) { const int q = t3 + k * (NT - 64); r[k] = src[q < PPN_PATH_POINTS ? q : 0]; }
-    #pragma unroll
-                for (int k = 0; k < PER; ++k) { const int q = t3 + k * (NT - 64); if (q < PPN_PATH_POINTS) pimg[q] = r[k]; }
-            }
             for (int q = t3; q < n_pocket; q += NT - 64) {
                 const double* o = P.obstacles + ((size_t)pj * PPN_MAX_POCKET + q) * 3;
                 praw[q][0] = o[0]; praw[q][1] = o[1]; praw[q][2] = o[2];
@@ -215,6 +217,8 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel_t(MapsParams prm) {
                 t1 = __shfl(a1, src, 64);
                 break;
             }
+#pragma unroll
+            for (int k = 0; k < PER; ++k) { const int q = tid + k * NT; pq_r[k] = pimg[q < PPN_PATH_POINTS ? q : 0]; }
             if (lane == 0) {
                 bc[0] = angle; bc[6] = ca; bc[7] = sa;
                 if constexpr (PHASE & 2) {
@@ -236,8 +240,11 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel_t(MapsParams prm) {
         const double tr0 = (double)t1, tr1 = (double)t0;                      // [translation[1], translation[0]]
 
         // ------------------------------------------------------------------ labels
-        for (int q = tid; q < PPN_PATH_POINTS; q += NT) {                     // MapGenerate.py:76-80
-            const double2 pq = pimg[q];
+#pragma unroll
+        for (int kk = 0; kk < PER; ++kk) {                                    // MapGenerate.py:76-80
+            const int q = tid + kk * NT;
+            if (q >= PPN_PATH_POINTS) break;
+            const double2 pq = pq_r[kk];
             double rx, ry;
             rot2(c, s, pq.x - half, pq.y - half, rx, ry);
             rx = rx + half + tr0;
@@ -412,7 +419,6 @@ __global__ __launch_bounds__(NT) void edage_maps_kernel_t(MapsParams prm) {
     }
 
     if constexpr (PHASE & 2) {
-        // fused: the staged points are dead from here, their bytes become the occupancy bit mask
         for (int w = tid; w < words; w += NT) occw[w] = 0u;
         {   // byte-expansion table: bit k set (= occupied) -> byte k 0x00, clear -> 0xFF
             uint64_t v = 0ull;
