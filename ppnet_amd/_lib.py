@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libppnet_hip.so")
+# PPNET_HIP_LIB points at another build of the same library (A/B runs of kernel variants); there is no non-HIP fallback
+LIB_PATH = os.environ.get("PPNET_HIP_LIB") or os.path.join(_HERE, "libppnet_hip.so")
 
 PPN_OK = 0
 SEGS = 10

@@ -74,14 +74,10 @@ __global__ __launch_bounds__(NT, PPN_MAPS_WAVES_PER_EU) void edage_maps_kernel_t
     //   obs   [K+64][3] f64 kept + pocket obstacles (col, row, r)
     //   poddf [2][128] f32  float copy of the 126 coarse odd points as planes x | y (filter
     //                       pre-pass); afterwards the raster's row tables
-    //   lut   [256] u64     8 occupancy bits -> 8 grid bytes                           (PHASE&2)
-    //   praw  [64][3] f64   the path's pocket obstacles as stored by stage A           (PHASE&1)
+    //   lut   [256] u64     8 occupancy bits -> 8 grid bytes (PHASE&2); during the filter its bytes hold fmin_w and dref
     extern __shared__ uint64_t lds_raw[];
-    __shared__ double hullc[PPN_MAX_HULL][2];     // hull - R/2
     __shared__ double bc[12];
     __shared__ int bci[16];                       // [0..3] placement, [4] kept count, [12] corridor-touch flag
-    __shared__ float fmin_w[NW][64];              // per-wave partial minima (squared, float) of the clearance filter
-    __shared__ double dref[64];                   // exact minima of the obstacles the coarse filter left undecided
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // XCD-aware block -> map assignment: blocks b and b+8 share an XCD (round-robin dispatch), so
@@ -110,8 +106,11 @@ __global__ __launch_bounds__(NT, PPN_MAPS_WAVES_PER_EU) void edage_maps_kernel_t
     double (*obs)[3] = reinterpret_cast<double (*)[3]>(lds + regionP_bytes + cand_bytes);
     float* poddf = reinterpret_cast<float*>(lds + regionP_bytes + cand_bytes + (size_t)(K + PPN_MAX_POCKET) * 24);
     uint64_t* lut = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(poddf) + maps_tab_bytes(K));
-    double (*praw)[3] = reinterpret_cast<double (*)[3]>(reinterpret_cast<unsigned char*>(lut) + ((PHASE & 2) ? 256 * 8 : 0));
-    (void)mid; (void)pimg; (void)occw; (void)cand; (void)praw; (void)hullc; (void)bci; (void)fmin_w; (void)dref; (void)lane; (void)wv; (void)words;
+    // regions that are dead when their second tenant arrives (barriers lie between):
+    double (*hullc)[2] = reinterpret_cast<double (*)[2]>(poddf);          // hull - R/2 [64][2]: placement only, before the labels write poddf
+    float (*fmin_w)[64] = reinterpret_cast<float (*)[64]>(lut);           // [NW][64] per-wave partial minima (squared, float) of the filter
+    double* dref = reinterpret_cast<double*>(lut) + 128;                  // [64] exact minima of the obstacles the coarse filter left undecided
+    (void)mid; (void)pimg; (void)occw; (void)cand; (void)hullc; (void)bci; (void)fmin_w; (void)dref; (void)lane; (void)wv; (void)words;
     PPN_STAMP_INIT;
 
     // the hand-over from the placement half to the raster half
@@ -140,10 +139,6 @@ __global__ __launch_bounds__(NT, PPN_MAPS_WAVES_PER_EU) void edage_maps_kernel_t
         } else {
             // waves 1..3, concurrently with the placement: stage everything that does not depend on it
             const int t3 = tid - 64;
-            for (int q = t3; q < n_pocket; q += NT - 64) {
-                const double* o = P.obstacles + ((size_t)pj * PPN_MAX_POCKET + q) * 3;
-                praw[q][0] = o[0]; praw[q][1] = o[1]; praw[q][2] = o[2];
-            }
             // K random obstacle candidates (MapGenerate.py:128-136): draws [0,K) rows, [K,2K) columns, [2K,3K) sizes
             if (prm.obst_draws) {
                 const double* d = prm.obst_draws + (size_t)m * 3 * K;
@@ -382,10 +377,11 @@ __global__ __launch_bounds__(NT, PPN_MAPS_WAVES_PER_EU) void edage_maps_kernel_t
         const int n_rand = bci[4];
         if (tid < n_pocket) {                                                 // MapGenerate.py:83-89
             double rx, ry;
-            rot2(c, s, praw[tid][1] - half, praw[tid][0] - half, rx, ry);
+            const double* o = P.obstacles + ((size_t)pj * PPN_MAX_POCKET + tid) * 3;   // stage A's (row, col, r), L2-resident
+            rot2(c, s, o[1] - half, o[0] - half, rx, ry);
             rx = rx + half + tr0;
             ry = ry + half + tr1;
-            obs[n_rand + tid][0] = ry; obs[n_rand + tid][1] = rx; obs[n_rand + tid][2] = praw[tid][2];
+            obs[n_rand + tid][0] = ry; obs[n_rand + tid][1] = rx; obs[n_rand + tid][2] = o[2];
         }
         __syncthreads();
         n_obs = n_rand + n_pocket;
@@ -461,6 +457,7 @@ __global__ __launch_bounds__(NT, PPN_MAPS_WAVES_PER_EU) void edage_maps_kernel_t
         const int n_pairs = row_off[n_obs];
         // each thread takes a contiguous run of pairs: one binary search for the first, then it walks rows / obstacles
         const int run = (n_pairs + NT - 1) / NT;
+        const float amb_eps = 1.0e-6f * (float)R;
         int pr = tid * run;
         const int pr_end = min(pr + run, n_pairs);
         int n = 0;
@@ -482,17 +479,17 @@ __global__ __launch_bounds__(NT, PPN_MAPS_WAVES_PER_EU) void edage_maps_kernel_t
             const float w = __builtin_amdgcn_sqrtf((float)(rr - dy2));     // 1-ulp hardware sqrt: an estimate is all it is
             const float xl = (float)cx - w - 0.5f, xr = (float)cx + w - 0.5f;
             int jl = (int)ceilf(xl), jh = (int)floorf(xr);
-            // the float estimate is good to < 1e-3 column; an end closer than that to an integer is settled
-            // with the exact double predicate (monotone in |dx|, so one step either way suffices)
-            if (fabsf(xl - rintf(xl)) < 2e-3f) {
-                jl = (int)rintf(xl);
-                while (disc_pred(jl - 1, cx, dy2, rr)) --jl;
-                while (jl <= jh + 1 && !disc_pred(jl, cx, dy2, rr)) ++jl;
+            // The float estimate is off by < 3.6e-7 * R columns (conversion of cx, 1-ulp sqrt, two subtractions of
+            // values < R); an end within amb_eps = 1e-6 * R of an integer is settled with the exact double predicate,
+            // which is monotone in |dx|: the true end is the estimate's nearest integer or its inward neighbour.
+            // (A wide window costs: one lane in the slow path holds up its whole wave.)
+            if (fabsf(xl - rintf(xl)) < amb_eps) {
+                const int j0 = (int)rintf(xl);
+                jl = disc_pred(j0, cx, dy2, rr) ? j0 : j0 + 1;
             }
-            if (fabsf(xr - rintf(xr)) < 2e-3f) {
-                jh = (int)rintf(xr);
-                while (disc_pred(jh + 1, cx, dy2, rr)) ++jh;
-                while (jh >= jl - 1 && !disc_pred(jh, cx, dy2, rr)) --jh;
+            if (fabsf(xr - rintf(xr)) < amb_eps) {
+                const int j0 = (int)rintf(xr);
+                jh = disc_pred(j0, cx, dy2, rr) ? j0 : j0 - 1;
             }
             jl = max(jl, 0); jh = min(jh, R - 1);
             if (jl > jh) continue;
@@ -581,7 +578,7 @@ template <int PHASE>
 static int launch_phase(const MapsParams& prm, hipStream_t stream) {
     const int R = prm.R, K = prm.K;
     const size_t lds = (size_t)maps_region_bytes(PHASE, R) + ((PHASE & 1) ? (size_t)K * 24 : 0) + (size_t)(K + PPN_MAX_POCKET) * 24 +
-                       maps_tab_bytes(K) + ((PHASE & 2) ? 256 * 8 : 0) + ((PHASE & 1) ? (size_t)PPN_MAX_POCKET * 24 : 0);
+                       maps_tab_bytes(K) + 256 * 8;
     if (hipFuncSetAttribute((const void*)edage_maps_kernel_t<PHASE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PPN_E_HIP;
     hipLaunchKernelGGL(edage_maps_kernel_t<PHASE>, dim3((unsigned)prm.n_maps), dim3(NT), lds, stream, prm);

@@ -39,7 +39,10 @@ namespace ppn {
 
 namespace {
 
-constexpr int NT = PPN_PATHS_THREADS;      // 512: one path per workgroup; 256/512/1024 measured 35.9/36.4/34.7 M instances/s with stage B overlapped
+// One path per workgroup.  256 threads: the chain is latency-bound (alone 256/512/1024 threads take the same time), and
+// beside stage B a 4-wave workgroup leaves its CU one more stage-B workgroup than an 8-wave one does (registers: 97 x 1
+// vs 81 x 2 per SIMD): 0.200 vs 0.210 ms per bench step.
+constexpr int NT = PPN_PATHS_THREADS;
 constexpr int NW = NT / 64;
 
 struct SegLds {

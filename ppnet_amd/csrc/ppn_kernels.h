@@ -5,7 +5,7 @@
 #include "../../include/ppnet_hip.h"
 
 #ifndef PPN_PATHS_THREADS
-#define PPN_PATHS_THREADS 512
+#define PPN_PATHS_THREADS 256
 #endif
 
 namespace ppn {

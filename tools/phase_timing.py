@@ -11,13 +11,13 @@ L.lib = tl
 from ppnet_amd import edage
 dev = torch.device("cuda:0")
 pb = edage.generate_paths(100, 256, 50, 3, seed=0, device=dev)
-mb = edage.MapsBatch(10000, 256, 50, dev)
+mb = edage.MapsBatch(10000, 256, 20, dev)
 buf = (C.c_ulonglong * 16)()
 for it in range(3):
-    edage.generate_maps(pb, 100, 5, 50, seed=0, out=mb)
+    edage.generate_maps(pb, 100, 5, 20, seed=0, out=mb)
 torch.cuda.synchronize()
 tl.ppn_debug_phase_cycles(buf, 1)
-edage.generate_maps(pb, 100, 5, 50, seed=0, out=mb)
+edage.generate_maps(pb, 100, 5, 20, seed=0, out=mb)
 torch.cuda.synchronize()
 tl.ppn_debug_phase_cycles(buf, 1)
 names = ["load space/hull/cand", "placement", "labels", "filter+compact", "pocket+zero+obs out", "raster1 spans", "raster2 corridor", "raster3 store"]

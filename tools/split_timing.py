@@ -5,7 +5,7 @@ import torch
 from ppnet_amd import edage
 
 dev = torch.device("cuda", 0)
-PATHS, PL, R, K = 100, 100, 256, 50
+PATHS, PL, R, K = 100, 100, 256, int(sys.argv[1]) if len(sys.argv) > 1 else 20
 pbs = [edage.generate_paths(PATHS, R, 50, 3, seed=0, first_path_id=i * PATHS, device=dev) for i in range(4)]
 mbs = [edage.MapsBatch(PATHS * PL, R, K, dev) for _ in range(2)]
 torch.cuda.synchronize()
