@@ -244,7 +244,7 @@ def main():
             "config": {"workload": "EDaGe-PP config 2: 100 target paths x 100 placements = 10000 maps+paths per GPU per step",
                        "resolution": R, "obstacles_num": K, "clearance": CLEARANCE, "map_size": MAP_SIZE,
                        "rng": "philox4x32-10", "parallelism": f"instances sharded over {world} GPU(s), end-of-batch all-gather"},
-            "roofline": {"bound": "hbm", "kernel": "edage_maps_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "edage_maps_kernel_t<3>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(),
                          "kernel_ms": round(maps_kernel_ms, 4), "timed_launches": len(timed), "units_per_launch": n_local,
                          "algorithmic_bytes_per_map": round(algorithmic_bytes_per_map(k_tot, k_pocket), 1),
