@@ -14,6 +14,11 @@
 // staged in LDS (rows padded to a conflict-free stride for ds_read_b128), each lane keeps its 49 logits in
 // registers, then the same LDS buffer is refilled with V.  HBM traffic is q, k, v read once (+ halo overlap)
 // and out written once; head_dim = 32 (every NAT/DiNAT level), kernel 7.
+//
+// The kernel is VALU-bound (SQ_ACTIVE_INST_VALU ~ 80 %), so the bf16 path keeps both products on v_dot2c_f32_bf16:
+// QK over channel pairs, AV over NEIGHBOUR pairs (V staged as row pairs, probabilities rounded to bf16 pairs, float32
+// accumulation): 1680 dot2 per query instead of 784 dot2 + 1.6 k unpack + 1.6 k FMA — 0.85 -> 0.69 ms on the 64x64
+// level at batch 256.  The float32 path keeps float32 probabilities and FMAs.
 #include <hip/hip_bf16.h>
 #include "ppn_device.h"
 #include "ppn_kernels.h"
@@ -65,16 +70,16 @@ __device__ __forceinline__ void load_row(const __hip_bfloat16* row, float (&r)[H
 template <typename T, int TILE, int THREADS>
 __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ rpb,
                                                            T* __restrict__ out, int B, int H, int W, int Hr, int Wr, int heads,
-                                                           int dil, float scale, int total_tiles, int halo_r, int halo_c) {
+                                                           int dil, float scale, int total_tiles, int halo_r, int halo_c, int tile_bytes, int kpitch, int vpitch) {
     constexpr int STRIDE = Row<T>::STRIDE;
     constexpr int NT = TILE * TILE, TPB = THREADS / NT;                      // tiles per workgroup
     // halo_r x halo_c = min(TILE + KS - 1, sub-image extent): the LDS footprint (and so the occupancy) follows the
     // sub-image — DiNAT's padded dilated layers have 7x7 groups, 49 rows per tile instead of 196
-    const int HALO = halo_c;                                                  // row pitch of the staged tile
+    // kpitch: elements between staged rows of K (or V rows, f32 path); vpitch: dwords between staged row pairs of V
     extern __shared__ unsigned char na_lds[];
     const int sub = threadIdx.x / NT;                                        // which tile of this workgroup
-    T* tile = reinterpret_cast<T*>(na_lds) + (size_t)sub * halo_r * halo_c * STRIDE;
-    float* bias = reinterpret_cast<float*>(na_lds + ((((size_t)TPB * halo_r * halo_c * STRIDE * sizeof(T)) + 15) & ~(size_t)15));   // [13][13]
+    T* tile = reinterpret_cast<T*>(na_lds + (size_t)sub * tile_bytes);
+    float* bias = reinterpret_cast<float*>(na_lds + (size_t)TPB * tile_bytes);   // [13][13]
 
     const int tid = threadIdx.x % NT, ty = tid / TILE, tx = tid % TILE;
     const int h = blockIdx.y;
@@ -110,11 +115,38 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
             const int rr = row / nc, cc = row - rr * nc;
             const int y = gi + (r0 + rr) * dil, x = gj + (c0 + cc) * dil;
             const T* src = qkv + ((size_t)(b * H + y) * W + x) * tok + ((size_t)which * heads + h) * HD + piece * EPP;
-            *reinterpret_cast<uint4*>(tile + (size_t)(rr * HALO + cc) * STRIDE + piece * EPP) = *reinterpret_cast<const uint4*>(src);
+            *reinterpret_cast<uint4*>(tile + (size_t)rr * kpitch + (size_t)cc * STRIDE + piece * EPP) = *reinterpret_cast<const uint4*>(src);
         }
     };
 
     constexpr bool BF16 = sizeof(T) == 2;
+    // bf16 AV runs on v_dot2 over PAIRS of neighbours: V is staged as row pairs, entry (rp, c) = 32 dwords
+    // {V[2rp][c][ch], V[2rp+1][c][ch]} (+4 pad: 144 B pitch, conflict-free ds_read_b128), rows >= nr zero.  A window that
+    // starts on an odd halo row uses the aligned pairs around it with probability 0 on the extra row, so one copy serves
+    // both parities: 28 pairs x 32 dot2 instead of 49 rows x (32 unpack + 32 FMA).
+    constexpr int VP = 36;                                                  // dwords per (row pair, column) entry
+    auto load_tile_vpairs = [&]() {
+        if constexpr (BF16) {
+            if (!tile_in) return;
+            uint32_t* vp = reinterpret_cast<uint32_t*>(tile);
+            const int nrp = (nr + 2) >> 1;                                  // pairs covering rows 0 .. nr
+            for (int p = tid; p < nrp * nc * 4; p += NT) {
+                const int e = p >> 2, piece = p & 3;
+                const int rp = e / nc, cc = e - rp * nc;
+                const int ra = 2 * rp, rb = ra + 1;
+                const int x = gj + (c0 + cc) * dil;
+                uint4 a = make_uint4(0u, 0u, 0u, 0u), bb = a;
+                if (ra < nr) a = *reinterpret_cast<const uint4*>(qkv + ((size_t)(b * H + gi + (r0 + ra) * dil) * W + x) * tok + ((size_t)2 * heads + h) * HD + piece * 8);
+                if (rb < nr) bb = *reinterpret_cast<const uint4*>(qkv + ((size_t)(b * H + gi + (r0 + rb) * dil) * W + x) * tok + ((size_t)2 * heads + h) * HD + piece * 8);
+                uint32_t* dst = vp + (size_t)rp * vpitch + (size_t)cc * VP + piece * 8;
+                // v_perm_b32: bytes 0-3 = second operand, 4-7 = first
+                *reinterpret_cast<uint4*>(dst) = make_uint4(__builtin_amdgcn_perm(bb.x, a.x, 0x05040100u), __builtin_amdgcn_perm(bb.x, a.x, 0x07060302u),
+                                                            __builtin_amdgcn_perm(bb.y, a.y, 0x05040100u), __builtin_amdgcn_perm(bb.y, a.y, 0x07060302u));
+                *reinterpret_cast<uint4*>(dst + 4) = make_uint4(__builtin_amdgcn_perm(bb.z, a.z, 0x05040100u), __builtin_amdgcn_perm(bb.z, a.z, 0x07060302u),
+                                                                __builtin_amdgcn_perm(bb.w, a.w, 0x05040100u), __builtin_amdgcn_perm(bb.w, a.w, 0x07060302u));
+            }
+        }
+    };
     float q[BF16 ? 1 : HD];
     uint32_t qp[BF16 ? HD / 2 : 1];                                         // bf16: q stays packed, two channels per register
     if (valid) {
@@ -143,7 +175,7 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
         for (int ki = 0; ki < KS; ++ki) {
 #pragma unroll
             for (int kj = 0; kj < KS; ++kj) {
-                const T* krow = tile + (size_t)((wi - r0 + ki) * HALO + (wj - c0 + kj)) * STRIDE;
+                const T* krow = tile + (size_t)(wi - r0 + ki) * kpitch + (size_t)(wj - c0 + kj) * STRIDE;
                 float acc = 0.0f;
                 if constexpr (BF16) {
                     // v_dot2c_f32_bf16: two channels per instruction, float32 accumulate; the bf16 q cannot carry the
@@ -172,7 +204,7 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
         }
     }
     __syncthreads();
-    load_tile(2);
+    if constexpr (BF16) load_tile_vpairs(); else load_tile(2);
     __syncthreads();
     if (valid) {
         float sum = 0.0f;
@@ -181,16 +213,45 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
         float o[HD];
 #pragma unroll
         for (int c = 0; c < HD; ++c) o[c] = 0.0f;
+        if constexpr (BF16) {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+            const uint32_t* vp = reinterpret_cast<const uint32_t*>(tile);
+            const int hr = wi - r0;                                         // window start in halo rows
+            const bool odd = hr & 1;
+            const int rp0 = hr >> 1;
 #pragma unroll
-        for (int ki = 0; ki < KS; ++ki) {
+            for (int t = 0; t < 4; ++t) {
 #pragma unroll
-            for (int kj = 0; kj < KS; ++kj) {
-                float vr[HD];
-                load_row(tile + (size_t)((wi - r0 + ki) * HALO + (wj - c0 + kj)) * STRIDE, vr);
-                const float p = logit[ki * KS + kj];
+                for (int kj = 0; kj < KS; ++kj) {
+                    // rows 2(rp0+t), 2(rp0+t)+1 are window rows (2t, 2t+1) for an even start, (2t-1, 2t) for an odd one
+                    const float pe_a = logit[(2 * t) * KS + kj], pe_b = (2 * t + 1 < KS) ? logit[(2 * t + 1) * KS + kj] : 0.0f;
+                    const float po_a = (t > 0) ? logit[(2 * t - 1) * KS + kj] : 0.0f, po_b = logit[(2 * t) * KS + kj];
+                    const float pa = odd ? po_a : pe_a, pb = odd ? po_b : pe_b;
+                    const bf2 pp = {(__bf16)pa, (__bf16)pb};
+                    const uint32_t* ent = vp + (size_t)(rp0 + t) * vpitch + (size_t)(wj - c0 + kj) * VP;
 #pragma unroll
-                for (int c = 0; c < HD; ++c) o[c] = fmaf(p, vr[c], o[c]);
-                asm volatile("" ::: "memory");
+                    for (int p4 = 0; p4 < HD / 4; ++p4) {
+                        const uint4 w4 = *reinterpret_cast<const uint4*>(ent + 4 * p4);
+                        o[4 * p4]     = __builtin_amdgcn_fdot2_f32_bf16(pp, __builtin_bit_cast(bf2, w4.x), o[4 * p4], false);
+                        o[4 * p4 + 1] = __builtin_amdgcn_fdot2_f32_bf16(pp, __builtin_bit_cast(bf2, w4.y), o[4 * p4 + 1], false);
+                        o[4 * p4 + 2] = __builtin_amdgcn_fdot2_f32_bf16(pp, __builtin_bit_cast(bf2, w4.z), o[4 * p4 + 2], false);
+                        o[4 * p4 + 3] = __builtin_amdgcn_fdot2_f32_bf16(pp, __builtin_bit_cast(bf2, w4.w), o[4 * p4 + 3], false);
+                    }
+                    asm volatile("" ::: "memory");
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ki = 0; ki < KS; ++ki) {
+#pragma unroll
+                for (int kj = 0; kj < KS; ++kj) {
+                    float vr[HD];
+                    load_row(tile + (size_t)(wi - r0 + ki) * kpitch + (size_t)(wj - c0 + kj) * STRIDE, vr);
+                    const float p = logit[ki * KS + kj];
+#pragma unroll
+                    for (int c = 0; c < HD; ++c) o[c] = fmaf(p, vr[c], o[c]);
+                    asm volatile("" ::: "memory");
+                }
             }
         }
         const float inv = 1.0f / sum;
@@ -210,11 +271,20 @@ static int launch_variant(const void* qkv, const float* rpb, void* out, int B, i
     const long long total = (long long)((hq + TILE - 1) / TILE) * ((wq + TILE - 1) / TILE) * B * dil * dil;
     const dim3 grid((unsigned)((total + TPB - 1) / TPB), heads, 1);
     const int halo_r = hs < HALO ? hs : HALO, halo_c = ws < HALO ? ws : HALO;
-    const size_t lds = (((size_t)TPB * halo_r * halo_c * Row<T>::STRIDE * sizeof(T) + 15) & ~(size_t)15) + 169 * sizeof(float);
+    // row pitches: padding them to 256 B (so that the two tile rows of a 16-lane LDS group start on the same bank) was
+    // measured and does not pay (0.701 vs 0.695 ms on the 64x64 level)
+    const size_t kpitch_b = (size_t)halo_c * Row<T>::STRIDE * sizeof(T), vpitch_b = (size_t)halo_c * 144;
+    size_t tile_bytes = (size_t)halo_r * kpitch_b;
+    if (sizeof(T) == 2) {                                                    // bf16: V is staged as row pairs, 144 B per (pair, column)
+        const size_t vpairs = (size_t)((halo_r + 2) / 2) * vpitch_b;
+        if (vpairs > tile_bytes) tile_bytes = vpairs;
+    }
+    tile_bytes = (tile_bytes + 15) & ~(size_t)15;
+    const size_t lds = (size_t)TPB * tile_bytes + 169 * sizeof(float);
     hipError_t e = hipFuncSetAttribute((const void*)na2d_fwd_kernel<T, TILE, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((na2d_fwd_kernel<T, TILE, THREADS>), grid, dim3(THREADS), lds, stream, (const T*)qkv, rpb, (T*)out, B, H, W, Hr,
-                       Wr, heads, dil, scale, (int)total, halo_r, halo_c);
+                       Wr, heads, dil, scale, (int)total, halo_r, halo_c, (int)tile_bytes, (int)(kpitch_b / sizeof(T)), (int)(vpitch_b / 4));
     return (int)hipGetLastError();
 }
 
