@@ -294,8 +294,8 @@ int ppn_na2d_fwd(const void* qkv, const float* rpb, void* out, int32_t B, int32_
     return ppn_na2d_fwd_padded(qkv, rpb, out, B, H, W, H, W, heads, dilation, scale, dtype, stream);
 }
 
-int ppn_na2d_fwd_padded(const void* qkv, const float* rpb, void* out, int32_t B, int32_t H, int32_t W, int32_t Hr, int32_t Wr,
-                        int32_t heads, int32_t dilation, float scale, int32_t dtype, void* stream) {
+static int na2d_checked(const void* qkv, const void* pad_kv, const float* rpb, void* out, int32_t B, int32_t H, int32_t W, int32_t Hr,
+                        int32_t Wr, int32_t heads, int32_t dilation, float scale, int32_t dtype, void* stream) {
     if (!qkv || !rpb || !out || B <= 0 || heads <= 0 || dilation < 1 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
     if (Hr <= 0 || Wr <= 0 || Hr > H || Wr > W) return PPN_E_INVALID;
     if (H < 7 * dilation || W < 7 * dilation) return PPN_E_INVALID;      // caller pads, like NATTEN's module
@@ -303,9 +303,20 @@ int ppn_na2d_fwd_padded(const void* qkv, const float* rpb, void* out, int32_t B,
         const long long hs = (H + dilation - 1) / dilation, ws = (W + dilation - 1) / dilation;
         if (((hs + 15) / 16) * ((ws + 15) / 16) * (long long)B * dilation * dilation > 0x7fffffffLL) return PPN_E_INVALID;
     }
-    const int e = ppn::na2d_launch(qkv, rpb, out, B, H, W, Hr, Wr, heads, dilation, scale, dtype, (hipStream_t)stream);
+    const int e = ppn::na2d_launch(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dilation, scale, dtype, (hipStream_t)stream);
     if (e != 0) return hip_fail((hipError_t)e);
     return PPN_OK;
+}
+
+int ppn_na2d_fwd_padded(const void* qkv, const float* rpb, void* out, int32_t B, int32_t H, int32_t W, int32_t Hr, int32_t Wr,
+                        int32_t heads, int32_t dilation, float scale, int32_t dtype, void* stream) {
+    return na2d_checked(qkv, nullptr, rpb, out, B, H, W, Hr, Wr, heads, dilation, scale, dtype, stream);
+}
+
+int ppn_na2d_fwd_vpad(const void* qkv, const void* pad_kv, const float* rpb, void* out, int32_t B, int32_t H, int32_t W, int32_t Hr,
+                      int32_t Wr, int32_t heads, int32_t dilation, float scale, int32_t dtype, void* stream) {
+    if (!pad_kv) return PPN_E_INVALID;
+    return na2d_checked(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dilation, scale, dtype, stream);
 }
 
 int ppn_residual_layernorm(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out,

@@ -68,7 +68,7 @@ __device__ __forceinline__ void load_row(const __hip_bfloat16* row, float (&r)[H
 // qkv is laid out for the padded H x W token grid (the module pads before the qkv projection, like NATTEN);
 // out is the unpadded [B][Hr][Wr][heads*32] tensor — padded positions are keys/values only, never queries.
 template <typename T, int TILE, int THREADS>
-__global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ rpb,
+__global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ pad_kv, const float* __restrict__ rpb,
                                                            T* __restrict__ out, int B, int H, int W, int Hr, int Wr, int heads,
                                                            int dil, float scale, int total_tiles, int halo_r, int halo_c, int tile_bytes, int kpitch, int vpitch) {
     constexpr int STRIDE = Row<T>::STRIDE;
@@ -103,6 +103,14 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
     const int nr = clampi(umax - NS, 0, hs - KS) + KS - r0, nc = clampi(vmax - NS, 0, ws - KS) + KS - c0;
     const int wi = clampi(u - NS, 0, hs - KS), wj = clampi(v - NS, 0, ws - KS);   // window start of this query
     const size_t tok = (size_t)3 * heads * HD;                              // elements per token in qkv
+    // pad_kv == null: qkv is stored for the whole H x W grid.  pad_kv != null ("virtual padding"): qkv holds only the
+    // Hr x Wr real tokens and every padded position has the same k / v, pad_kv[3][heads][32] (the qkv bias: NATTEN's module
+    // zero-pads BEFORE its projection) — the projection and this kernel then never touch the 1.7-3x larger padded grid.
+    const int Hs = pad_kv ? Hr : H, Ws = pad_kv ? Wr : W;
+    auto kv_src = [&](int which, int y, int x) -> const T* {
+        return (!pad_kv || (y < Hr && x < Wr)) ? qkv + ((size_t)(b * Hs + y) * Ws + x) * tok + ((size_t)which * heads + h) * HD
+                                                : pad_kv + ((size_t)which * heads + h) * HD;
+    };
 
     for (int t = threadIdx.x; t < 13 * 13; t += THREADS) bias[t] = rpb[(size_t)h * 169 + t];
 
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
             const int row = p / PIECES, piece = p - row * PIECES;
             const int rr = row / nc, cc = row - rr * nc;
             const int y = gi + (r0 + rr) * dil, x = gj + (c0 + cc) * dil;
-            const T* src = qkv + ((size_t)(b * H + y) * W + x) * tok + ((size_t)which * heads + h) * HD + piece * EPP;
+            const T* src = kv_src(which, y, x) + piece * EPP;
             *reinterpret_cast<uint4*>(tile + (size_t)rr * kpitch + (size_t)cc * STRIDE + piece * EPP) = *reinterpret_cast<const uint4*>(src);
         }
     };
@@ -136,8 +144,8 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
                 const int ra = 2 * rp, rb = ra + 1;
                 const int x = gj + (c0 + cc) * dil;
                 uint4 a = make_uint4(0u, 0u, 0u, 0u), bb = a;
-                if (ra < nr) a = *reinterpret_cast<const uint4*>(qkv + ((size_t)(b * H + gi + (r0 + ra) * dil) * W + x) * tok + ((size_t)2 * heads + h) * HD + piece * 8);
-                if (rb < nr) bb = *reinterpret_cast<const uint4*>(qkv + ((size_t)(b * H + gi + (r0 + rb) * dil) * W + x) * tok + ((size_t)2 * heads + h) * HD + piece * 8);
+                if (ra < nr) a = *reinterpret_cast<const uint4*>(kv_src(2, gi + (r0 + ra) * dil, x) + piece * 8);
+                if (rb < nr) bb = *reinterpret_cast<const uint4*>(kv_src(2, gi + (r0 + rb) * dil, x) + piece * 8);
                 uint32_t* dst = vp + (size_t)rp * vpitch + (size_t)cc * VP + piece * 8;
                 // v_perm_b32: bytes 0-3 = second operand, 4-7 = first
                 *reinterpret_cast<uint4*>(dst) = make_uint4(__builtin_amdgcn_perm(bb.x, a.x, 0x05040100u), __builtin_amdgcn_perm(bb.x, a.x, 0x07060302u),
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
     uint32_t qp[BF16 ? HD / 2 : 1];                                         // bf16: q stays packed, two channels per register
     if (valid) {
         const int y = gi + u * dil, x = gj + v * dil;
-        const T* src = qkv + ((size_t)(b * H + y) * W + x) * tok + (size_t)h * HD;
+        const T* src = qkv + ((size_t)(b * Hs + y) * Ws + x) * tok + (size_t)h * HD;   // queries are real tokens
         if constexpr (BF16) {
 #pragma unroll
             for (int p4 = 0; p4 < HD / 8; ++p4) {
@@ -209,7 +217,9 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
     if (valid) {
         float sum = 0.0f;
 #pragma unroll
-        for (int t = 0; t < KS * KS; ++t) { logit[t] = expf(logit[t] - mx); sum += logit[t]; }
+        // exp(x) = 2^(x * log2 e) on the hardware v_exp_f32 (1 ulp; arguments are <= 0, underflow flushes to 0): expf()'s
+        // range handling is ~8 more instructions per neighbour in a VALU-bound kernel
+        for (int t = 0; t < KS * KS; ++t) { logit[t] = __builtin_amdgcn_exp2f((logit[t] - mx) * 1.4426950408889634f); sum += logit[t]; }
         float o[HD];
 #pragma unroll
         for (int c = 0; c < HD; ++c) o[c] = 0.0f;
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
 }
 
 template <typename T, int TILE, int THREADS>
-static int launch_variant(const void* qkv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
+static int launch_variant(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
                           float scale, hipStream_t stream) {
     constexpr int HALO = TILE + KS - 1, TPB = THREADS / (TILE * TILE);
     const int hs = (H + dil - 1) / dil, ws = (W + dil - 1) / dil;            // largest key sub-image
@@ -283,13 +293,13 @@ static int launch_variant(const void* qkv, const float* rpb, void* out, int B, i
     const size_t lds = (size_t)TPB * tile_bytes + 169 * sizeof(float);
     hipError_t e = hipFuncSetAttribute((const void*)na2d_fwd_kernel<T, TILE, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((na2d_fwd_kernel<T, TILE, THREADS>), grid, dim3(THREADS), lds, stream, (const T*)qkv, rpb, (T*)out, B, H, W, Hr,
+    hipLaunchKernelGGL((na2d_fwd_kernel<T, TILE, THREADS>), grid, dim3(THREADS), lds, stream, (const T*)qkv, (const T*)pad_kv, rpb, (T*)out, B, H, W, Hr,
                        Wr, heads, dil, scale, (int)total, halo_r, halo_c, (int)tile_bytes, (int)(kpitch_b / sizeof(T)), (int)(vpitch_b / 4));
     return (int)hipGetLastError();
 }
 
 template <typename T>
-static int launch_typed(const void* qkv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
+static int launch_typed(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
                         float scale, hipStream_t stream) {
     const int hq = (Hr + dil - 1) / dil, wq = (Wr + dil - 1) / dil;
     // lane utilisation of each tiling on the query sub-image
@@ -297,15 +307,15 @@ static int launch_typed(const void* qkv, const float* rpb, void* out, int B, int
     int best = 16;
     if (util(8) > util(best) + 0.05) best = 8;
     if (util(4) > util(best) + 0.05) best = 4;
-    if (best == 4) return launch_variant<T, 4, 128>(qkv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
-    if (best == 8) return launch_variant<T, 8, 256>(qkv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
-    return launch_variant<T, 16, 256>(qkv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
+    if (best == 4) return launch_variant<T, 4, 128>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
+    if (best == 8) return launch_variant<T, 8, 256>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
+    return launch_variant<T, 16, 256>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
 }
 
-int na2d_launch(const void* qkv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil, float scale,
+int na2d_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil, float scale,
                 int dtype, hipStream_t stream) {
-    return dtype == 0 ? launch_typed<float>(qkv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream)
-                      : launch_typed<__hip_bfloat16>(qkv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
+    return dtype == 0 ? launch_typed<float>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream)
+                      : launch_typed<__hip_bfloat16>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
 }
 
 }  // namespace ppn

@@ -60,7 +60,7 @@ __global__ void resize_pass_kernel(const uint8_t* in, int n, int inH, int inW, i
 __global__ void philox_doubles_kernel(uint64_t seed, uint32_t stream_id, uint64_t instance, uint32_t first, int count,
                                       double* out);
 
-int na2d_launch(const void* qkv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
+int na2d_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
                 float scale, int dtype, hipStream_t stream);
 
 int norm_launch(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,

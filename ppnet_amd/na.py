@@ -10,10 +10,13 @@ import torch.nn.functional as F
 from . import _lib as L
 
 
-def na2d_forward(qkv, rpb, heads, dilation, scale, real_hw=None):
+def na2d_forward(qkv, rpb, heads, dilation, scale, real_hw=None, pad_kv=None, padded_hw=None):
     """qkv: [B,H,W,3*C] contiguous CUDA tensor (float32 or bfloat16) straight from the qkv Linear;
-    rpb: [heads,13,13]. Returns [B,Hr,Wr,C] in the layout the output projection consumes; real_hw=(Hr,Wr) when the
-    H x W grid is the zero-padded one (padded tokens are keys/values only), default (H, W)."""
+    rpb: [heads,13,13]. Returns [B,Hr,Wr,C] in the layout the output projection consumes.
+
+    Padded layers, two forms.  Materialised: qkv covers the zero-padded H x W grid and real_hw=(Hr,Wr) names the real
+    tokens (padded tokens are keys/values only).  Virtual: qkv covers only the real tokens, padded_hw=(H,W) names the
+    padded grid and pad_kv [3*C] is the k / v every padded position has (the qkv bias)."""
     if not qkv.is_cuda:
         raise RuntimeError("ppnet_amd.na: the neighbourhood-attention kernel runs on the GPU only (no CPU fallback)")
     B, H, W, C3 = qkv.shape
@@ -25,12 +28,24 @@ def na2d_forward(qkv, rpb, heads, dilation, scale, real_hw=None):
         raise NotImplementedError(f"dtype {qkv.dtype}")
     qkv = qkv.contiguous()
     rpb = rpb.detach().to(torch.float32).contiguous()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)
+    if pad_kv is not None:
+        Hp, Wp = padded_hw
+        pad_kv = pad_kv.detach().to(qkv.dtype).contiguous()
+        assert pad_kv.numel() == C3 and real_hw is None
+        out = torch.empty(B, H, W, ch, dtype=qkv.dtype, device=qkv.device)
+        with torch.cuda.device(qkv.device):
+            rc = L.lib.ppn_na2d_fwd_vpad(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(pad_kv.data_ptr()),
+                                         ctypes.c_void_p(rpb.data_ptr()), ctypes.c_void_p(out.data_ptr()), B, Hp, Wp, H, W,
+                                         heads, dilation, float(scale), dtype, stream)
+        L.check(rc, "ppn_na2d_fwd_vpad")
+        return out
     Hr, Wr = real_hw if real_hw is not None else (H, W)
     out = torch.empty(B, Hr, Wr, ch, dtype=qkv.dtype, device=qkv.device)
     with torch.cuda.device(qkv.device):
         rc = L.lib.ppn_na2d_fwd_padded(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(rpb.data_ptr()),
                                        ctypes.c_void_p(out.data_ptr()), B, H, W, Hr, Wr, heads, dilation, float(scale), dtype,
-                                       ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream))
+                                       stream)
     L.check(rc, "ppn_na2d_fwd_padded")
     return out
 
@@ -62,13 +77,19 @@ class NeighborhoodAttention2D(nn.Module):
         return max(H, self.window_size), max(W, self.window_size)
 
     def forward(self, x, real_hw=None):
-        """x [B,H,W,C]. real_hw=(Hr,Wr): x is ALREADY zero-padded bottom/right from (Hr,Wr) to this layer's padded
-        grid (the fused LayerNorm kernel writes it that way); otherwise the padding happens here. Padding comes
-        BEFORE the qkv projection (NATTEN's module), and only the real tokens are queries, so no crop is needed."""
-        if real_hw is None:
-            real_hw = (x.shape[1], x.shape[2])
-            pad = self.padded_hw(*real_hw)
-            if pad is not None:
-                x = F.pad(x, (0, 0, 0, pad[1] - real_hw[1], 0, pad[0] - real_hw[0]))
-        o = na2d_forward(self.qkv(x), self.rpb, self.num_heads, self.dilation, self.scale, real_hw)
+        """x [B,H,W,C].  NATTEN's module zero-pads bottom/right to kernel*dilation BEFORE the qkv projection, so every
+        padded token's q/k/v is the projection's bias and only the real tokens are queries (no crop needed).  The padded
+        grid is never built here: the projection runs on the real tokens and the kernel substitutes the bias for padded
+        keys/values (ppn_na2d_fwd_vpad).  real_hw=(Hr,Wr) keeps the materialised form for a caller that already holds a
+        zero-padded x."""
+        if real_hw is not None:
+            o = na2d_forward(self.qkv(x), self.rpb, self.num_heads, self.dilation, self.scale, real_hw)
+            return self.proj_drop(self.proj(o))
+        pad = self.padded_hw(x.shape[1], x.shape[2])
+        qkv = self.qkv(x)
+        if pad is None:
+            o = na2d_forward(qkv, self.rpb, self.num_heads, self.dilation, self.scale)
+        else:
+            bias = self.qkv.bias if self.qkv.bias is not None else torch.zeros(qkv.shape[-1], dtype=qkv.dtype, device=qkv.device)
+            o = na2d_forward(qkv, self.rpb, self.num_heads, self.dilation, self.scale, pad_kv=bias, padded_hw=pad)
         return self.proj_drop(self.proj(o))

@@ -64,14 +64,16 @@ class NATLayer(nn.Module):
             self.gamma2 = nn.Parameter(layer_scale * torch.ones(dim))
 
     def forward(self, x, y=None, next_norm=None, next_pad=None):
-        """x: residual stream [B,H,W,C]; y = norm1(x) if the caller already has it (zero-padded to this layer's
-        attention grid when that is larger). Returns (x', next_norm(x')) with the second padded to next_pad.
+        """x: residual stream [B,H,W,C]; y = norm1(x) if the caller already has it. Returns (x', next_norm(x')).
+        The attention's zero-padding to kernel*dilation is virtual (na.NeighborhoodAttention2D.forward), so next_pad
+        stays None; the argument is kept for a caller that wants the materialised padded grid.
         Residual add, LayerScale and the following LayerNorm are one fused kernel each (DropPath is the identity
         at inference, nat.py:140-153)."""
         hw = (x.shape[1], x.shape[2])
         if y is None:
-            y = fused.layer_norm(x, self.norm1, self.attn.padded_hw(*hw))
-        x, y2 = fused.residual_layer_norm(x, self.attn(y, hw), self.gamma1 if self.layer_scale else None, self.norm2)
+            y = fused.layer_norm(x, self.norm1)
+        real = hw if (y.shape[1], y.shape[2]) != hw else None               # a materialised padded y still works
+        x, y2 = fused.residual_layer_norm(x, self.attn(y, real), self.gamma1 if self.layer_scale else None, self.norm2)
         return fused.residual_layer_norm(x, self.mlp(y2), self.gamma2 if self.layer_scale else None, next_norm, next_pad)
 
 
@@ -92,7 +94,7 @@ class NATBlock(nn.Module):
         hw = (x.shape[1], x.shape[2])
         for i, blk in enumerate(self.blocks):
             if i + 1 < n:
-                x, y = blk(x, y, self.blocks[i + 1].norm1, self.blocks[i + 1].attn.padded_hw(*hw))
+                x, y = blk(x, y, self.blocks[i + 1].norm1, None)
             else:
                 x, y = blk(x, y, out_norm, None)
         xo = y if out_norm is not None else x

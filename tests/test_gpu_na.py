@@ -88,3 +88,24 @@ def test_no_cpu_fallback():
     from ppnet_amd import na
     with pytest.raises(RuntimeError):
         na.na2d_forward(torch.zeros(1, 7, 7, 96), torch.zeros(1, 13, 13), 1, 1, 1.0)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("H,W,Hr,Wr,d,heads", [(28, 28, 16, 16, 4, 2), (112, 112, 64, 64, 16, 1), (14, 14, 8, 8, 2, 3), (21, 21, 16, 13, 3, 2)])
+def test_virtual_padding_equals_materialised_padding(dev, H, W, Hr, Wr, d, heads, dtype):
+    """ppn_na2d_fwd_vpad (real tokens + one k/v for every padded position) gives the bits of ppn_na2d_fwd_padded on the
+    grid that holds that k/v at every padded position — what projecting a zero-padded input produces."""
+    import torch
+    from ppnet_amd import na
+    rng = np.random.RandomState(11)
+    C = heads * 32
+    dt = getattr(torch, dtype)
+    real = torch.tensor(rng.standard_normal((2, Hr, Wr, 3 * C)).astype(np.float32), device=dev).to(dt)
+    bias = torch.tensor(rng.standard_normal(3 * C).astype(np.float32), device=dev).to(dt)
+    rpb = torch.tensor(rng.standard_normal((heads, 13, 13)).astype(np.float32), device=dev)
+    full = bias.expand(2, H, W, 3 * C).clone()
+    full[:, :Hr, :Wr] = real
+    want = na.na2d_forward(full, rpb, heads, d, 32 ** -0.5, real_hw=(Hr, Wr))
+    got = na.na2d_forward(real, rpb, heads, d, 32 ** -0.5, pad_kv=bias, padded_hw=(H, W))
+    assert got.shape == want.shape == (2, Hr, Wr, C)
+    assert torch.equal(got, want)
