@@ -236,7 +236,7 @@ int ppn_na2d_fwd_vpad(const void* qkv, const void* pad_kv, const float* rpb, voi
 /* Fused residual + LayerScale + LayerNorm around the NAT layer's dense ops (SegNet/nat.py:140-153):
  *   a == NULL : y_out = LayerNorm(x)                                   (x_out ignored)
  *   a != NULL : x_out = x + gamma * a  (gamma NULL = 1);  y_out = LayerNorm(x_out) unless y_out is NULL.
- * rows x C row-major, C a multiple of 8 with C/8 a power of two <= 64, or C = 1024; w, b, gamma are [C] in the
+ * rows x C row-major, C a multiple of 8 with C/8 a power of two <= 64, or C = 1024, or any C <= 64; w, b, gamma are [C] in the
  * same dtype (0 = float32, 1 = bfloat16; statistics in float32). x_out may alias x. */
 int ppn_residual_layernorm(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out,
                            void* y_out, int64_t rows, int32_t C, float eps, int32_t dtype, void* stream);
@@ -252,6 +252,14 @@ int ppn_residual_layernorm_padded(const void* x, const void* a, const void* gamm
  * setr_up_head.py:53-66). C a multiple of 8; dtype 0 = float32, 1 = bfloat16. */
 int ppn_upsample2x_nhwc(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t relu,
                         int32_t dtype, void* stream);
+/* Same with a per-channel bias [C] added before the ReLU: the preceding convolution then runs without its (BatchNorm-
+ * folded) bias and its separate add pass (mmcv ConvModule conv -> bn -> ReLU -> Upsample, setr_up_head.py:56-66). */
+int ppn_upsample2x_nhwc_bias(const void* x, const void* bias, void* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                             int32_t relu, int32_t dtype, void* stream);
+/* In place x = leaky_relu(x + bias[c], negative_slope) on n elements of an NHWC tensor with C channels (C % 8 == 0;
+ * slope 0 = ReLU, 1 = bias only): bias + BatchNorm(folded) + LeakyReLU of GenNet's conv stages (ae_vit.py:17-55) as
+ * one pass behind a bias-free library convolution. */
+int ppn_bias_act_nhwc(void* x, const void* bias, int64_t n, int32_t C, float negative_slope, int32_t dtype, void* stream);
 
 /* PIL.Image.resize(size, BILINEAR) for 8-bit single-channel images, bit-exact: Pillow's ImagingResample
  * (support = max(scale,1), 22-bit fixed-point coefficients, horizontal pass then vertical pass, each rounded

@@ -341,8 +341,21 @@ int ppn_residual_layernorm_padded(const void* x, const void* a, const void* gamm
 
 int ppn_upsample2x_nhwc(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t relu, int32_t dtype,
                         void* stream) {
+    return ppn_upsample2x_nhwc_bias(x, nullptr, y, B, H, W, C, relu, dtype, stream);
+}
+
+int ppn_upsample2x_nhwc_bias(const void* x, const void* bias, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t relu,
+                             int32_t dtype, void* stream) {
     if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
-    const int e = ppn::upsample2x_launch(x, y, B, H, W, C, relu, dtype, (hipStream_t)stream);
+    const int e = ppn::upsample2x_launch(x, bias, y, B, H, W, C, relu, dtype, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
+int ppn_bias_act_nhwc(void* x, const void* bias, int64_t n, int32_t C, float negative_slope, int32_t dtype, void* stream) {
+    if (!x || !bias || n < 0 || C <= 0 || (C % 8) != 0 || (n % C) != 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
+    if (n == 0) return PPN_OK;
+    const int e = ppn::bias_act_launch(x, bias, n, C, negative_slope, dtype, (hipStream_t)stream);
     if (e != 0) return hip_fail((hipError_t)e);
     return PPN_OK;
 }

@@ -70,9 +70,10 @@ def residual_layer_norm(x, a, gamma, ln_next, pad_to=None):
     return x, y
 
 
-def upsample2x_nhwc(x_nchw_cl, relu=False):
-    """Bilinear x2 (align_corners=False) of a channels_last [B,C,H,W] tensor, optionally with a ReLU folded into the
-    loads. Returns a channels_last [B,C,2H,2W] tensor (zero-copy views on both sides)."""
+def upsample2x_nhwc(x_nchw_cl, relu=False, bias=None):
+    """Bilinear x2 (align_corners=False) of a channels_last [B,C,H,W] tensor, optionally with a per-channel bias and a
+    ReLU folded into the loads (conv -> folded BN -> ReLU -> Upsample with a bias-free library convolution).  Returns a
+    channels_last [B,C,2H,2W] tensor (zero-copy views on both sides)."""
     if not x_nchw_cl.is_cuda:
         raise RuntimeError("ppnet_amd.fused: GPU tensors only (no CPU fallback)")
     x = x_nchw_cl.permute(0, 2, 3, 1)
@@ -81,7 +82,23 @@ def upsample2x_nhwc(x_nchw_cl, relu=False):
     B, H, W, C = x.shape
     y = torch.empty(B, 2 * H, 2 * W, C, dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
-        rc = L.lib.ppn_upsample2x_nhwc(_p(x), _p(y), B, H, W, C, 1 if relu else 0, _DT[x.dtype],
-                                       ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
-    L.check(rc, "ppn_upsample2x_nhwc")
+        bias = bias.detach().to(x.dtype).contiguous() if bias is not None else None
+        rc = L.lib.ppn_upsample2x_nhwc_bias(_p(x), _p(bias), _p(y), B, H, W, C, 1 if relu else 0, _DT[x.dtype],
+                                            ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    L.check(rc, "ppn_upsample2x_nhwc_bias")
     return y.permute(0, 3, 1, 2)
+
+
+def bias_act_(x_nchw_cl, bias, negative_slope):
+    """In place leaky_relu(x + bias[c], negative_slope) on a channels_last [B,C,H,W] tensor (slope 0 = ReLU, 1 = bias
+    only).  Returns x."""
+    if not x_nchw_cl.is_cuda:
+        raise RuntimeError("ppnet_amd.fused: GPU tensors only (no CPU fallback)")
+    assert x_nchw_cl.is_contiguous(memory_format=torch.channels_last)
+    C = x_nchw_cl.shape[1]
+    with torch.cuda.device(x_nchw_cl.device):
+        rc = L.lib.ppn_bias_act_nhwc(_p(x_nchw_cl), _p(bias.detach().to(x_nchw_cl.dtype).contiguous()), x_nchw_cl.numel(), C,
+                                     float(negative_slope), _DT[x_nchw_cl.dtype],
+                                     ctypes.c_void_p(torch.cuda.current_stream(x_nchw_cl.device).cuda_stream))
+    L.check(rc, "ppn_bias_act_nhwc")
+    return x_nchw_cl

@@ -50,12 +50,40 @@ class _Block(nn.Module):
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x):                     # DropPath is the identity at inference (vit.py:158-161)
-        x = x + self.attn(self.norm1(x))
-        return x + self.mlp(self.norm2(x))
+        x = x + self.attn(_ln(x, self.norm1))
+        return x + self.mlp(_ln(x, self.norm2))
 
 
 def _stage(conv):
     return nn.Sequential(conv, nn.BatchNorm2d(conv.out_channels), nn.LeakyReLU())
+
+
+class _FusedStage(nn.Module):
+    """A conv stage after prepare_inference(): the (transposed) convolution with the BatchNorm folded in runs WITHOUT its
+    bias on the library, and bias + LeakyReLU are one in-place pass of the HIP kernel (ppn_bias_act_nhwc) instead of the
+    library's separate add and activation kernels.  C % 8 != 0 or a CPU tensor: plain torch ops."""
+
+    def __init__(self, conv, slope):
+        super().__init__()
+        self.conv, self.slope = conv, slope
+
+    def forward(self, x):
+        c = self.conv
+        if not (x.is_cuda and c.out_channels % 8 == 0):
+            return F.leaky_relu(c(x), self.slope)
+        if isinstance(c, nn.ConvTranspose2d):
+            y = F.conv_transpose2d(x, c.weight, None, c.stride, c.padding, c.output_padding, c.groups, c.dilation)
+        else:
+            y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+        from . import fused
+        return fused.bias_act_(y.contiguous(memory_format=torch.channels_last), c.bias, self.slope)
+
+
+def _ln(x, ln):
+    if x.is_cuda:
+        from . import fused
+        return fused.layer_norm(x, ln)                                       # thread-per-row HIP kernel (C = 24)
+    return ln(x)
 
 
 class AEViT(nn.Module):
@@ -81,6 +109,9 @@ class AEViT(nn.Module):
             conv.bias = nn.Parameter(((conv.bias.detach() if conv.bias is not None else 0) - bn.running_mean) * scale + bn.bias.detach())
             stage[1] = nn.Identity()
         self.to(memory_format=torch.channels_last)
+        self.conv_first = _FusedStage(self.conv_first[0], self.conv_first[2].negative_slope)
+        self.enc_conv = nn.ModuleList(_FusedStage(st[0], st[2].negative_slope) for st in self.enc_conv)
+        self.dec_conv = nn.ModuleList(_FusedStage(st[0], st[2].negative_slope) for st in self.dec_conv)
         return self
 
     def forward(self, x):

@@ -159,9 +159,11 @@ class _Upsample(nn.Module):
         super().__init__()
         self.scale_factor, self.align_corners = float(scale_factor), align_corners
 
-    def forward(self, x, relu=False):
+    def forward(self, x, relu=False, bias=None):
         if self.scale_factor == 2.0 and not self.align_corners and x.shape[1] % 8 == 0 and x.is_cuda:
-            return fused.upsample2x_nhwc(x, relu)                            # HIP kernel, ReLU folded into the loads
+            return fused.upsample2x_nhwc(x, relu, bias)                      # HIP kernel, bias + ReLU folded into the loads
+        if bias is not None:
+            x = x + bias.view(1, -1, 1, 1)
         if relu:
             x = F.relu(x)
         size = [int(t * self.scale_factor) for t in x.shape[-2:]]            # mmseg/ops/wrappers.py:43-51
@@ -188,7 +190,11 @@ class SETRUPHead(nn.Module):
         x = fused.layer_norm(x.permute(0, 2, 3, 1), self.norm).permute(0, 3, 1, 2)
         for up in self.up_convs[:-1]:
             cm = up[0]
-            x = up[1](cm.bn(cm.conv(x)), relu=True)                          # conv -> (folded) BN -> ReLU + x2 bilinear in one kernel
+            if isinstance(cm.bn, nn.Identity) and cm.conv.bias is not None:  # prepared: the folded-BN bias rides in the upsample kernel
+                c = cm.conv
+                x = up[1](F.conv2d(x, c.weight, None, c.stride, c.padding), relu=True, bias=c.bias)
+            else:
+                x = up[1](cm.bn(cm.conv(x)), relu=True)                      # conv -> BN -> ReLU + x2 bilinear in one kernel
         # last stage: conv_seg is a 1x1 convolution and bilinear interpolation is linear with weights summing to 1,
         # so conv_seg(upsample(y)) == upsample(conv_seg(y)): classify at the low resolution and upsample 2 channels
         # instead of `channels` (the reference materialises a [B,512,R/2,R/2] tensor here, setr_up_head.py:78-80)

@@ -41,6 +41,17 @@ def test_aevit_gpu_matches_reference(golden_dir, R):
     assert np.abs(got - y).max() < 1e-3 * max(1.0, np.abs(y).max())          # float32 on MIOpen / rocBLAS
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [64, 224])
+def test_aevit_prepared_gpu_matches_reference(golden_dir, R):
+    """prepare_inference(): BN folded, bias + LeakyReLU and the ViT LayerNorms on the HIP kernels."""
+    m, x, y = _model_and_data(golden_dir, R)
+    m = m.prepare_inference().cuda()
+    with torch.no_grad():
+        got = m(x.cuda().contiguous(memory_format=torch.channels_last)).float().cpu().numpy()
+    assert np.abs(got - y).max() < 1e-3 * max(1.0, np.abs(y).max())
+
+
 @pytest.mark.parametrize("R", [64])
 def test_bn_folding_is_exact(golden_dir, R):
     import copy

@@ -90,7 +90,8 @@ def test_small_nat_gpu_vs_oracle_composition():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("C,dtype", [(128, "float32"), (256, "bfloat16"), (512, "bfloat16"), (1024, "bfloat16"), (64, "float32")])
+@pytest.mark.parametrize("C,dtype", [(128, "float32"), (256, "bfloat16"), (512, "bfloat16"), (1024, "bfloat16"), (64, "float32"),
+                                     (24, "float32"), (24, "bfloat16"), (8, "float32"), (56, "bfloat16")])   # C <= 64: thread-per-row kernel
 def test_fused_residual_layernorm_vs_torch(C, dtype):
     from ppnet_amd import fused
     dt = getattr(torch, dtype)
@@ -125,6 +126,25 @@ def test_upsample2x_relu_vs_torch(dtype):
                                               align_corners=False)
         assert got.shape == ref.shape
         assert (got.float() - ref).abs().max() < (1e-5 if dt == torch.float32 else 2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_bias_act_and_biased_upsample_vs_torch(dtype):
+    from ppnet_amd import fused
+    dt = getattr(torch, dtype)
+    torch.manual_seed(4)
+    tol = 1e-5 if dt == torch.float32 else 3e-2
+    for C in (24, 64):
+        x = torch.randn(3, C, 9, 13, device="cuda", dtype=dt).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(C, device="cuda", dtype=dt)
+        for slope in (0.01, 0.0, 1.0):
+            ref = torch.nn.functional.leaky_relu(x.float() + b.float().view(1, -1, 1, 1), slope)
+            got = fused.bias_act_(x.clone(memory_format=torch.channels_last), b, slope)
+            assert (got.float() - ref).abs().max() < tol
+        ref = torch.nn.functional.interpolate(torch.relu(x.float() + b.float().view(1, -1, 1, 1)), scale_factor=2, mode="bilinear",
+                                              align_corners=False)
+        assert (fused.upsample2x_nhwc(x, True, b).float() - ref).abs().max() < tol
 
 
 @pytest.mark.gpu
