@@ -92,9 +92,12 @@ class NATBlock(nn.Module):
                      qk_scale, norm_layer=norm_layer, layer_scale=layer_scale) for i in range(depth))
         self.downsample = ConvDownsampler(dim, norm_layer) if downsample else None
 
-    def forward(self, x, out_norm=None):
-        """Returns (next level's input, out_norm(x) or x): the level's output norm rides on the last fused kernel."""
-        x = x.clone()                                  # the fused kernels update the residual stream in place
+    def forward(self, x, out_norm=None, inplace=False):
+        """Returns (next level's input, out_norm(x) or x): the level's output norm rides on the last fused kernel.
+        The fused kernels update the residual stream in place: inplace=True lets them use the caller's tensor (NAT hands
+        over the tokenizer's / downsampler's fresh output), otherwise it is copied first."""
+        if not inplace:
+            x = x.clone()
         y = None
         n = len(self.blocks)
         hw = (x.shape[1], x.shape[2])
@@ -140,7 +143,7 @@ class NAT(nn.Module):
         outs = []
         for idx, level in enumerate(self.levels):
             want = idx in self.compute_indices
-            x, xo = level(x, getattr(self, f"norm{idx}") if want else None)
+            x, xo = level(x, getattr(self, f"norm{idx}") if want else None, inplace=True)   # x: fresh LayerNorm output
             if want:
                 outs.append(xo.permute(0, 3, 1, 2))    # [B,C,H,W] in channels_last memory format (zero-copy view)
         return outs
