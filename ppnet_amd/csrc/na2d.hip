@@ -67,7 +67,7 @@ __device__ __forceinline__ void load_row(const __hip_bfloat16* row, float (&r)[H
 //
 // qkv is laid out for the padded H x W token grid (the module pads before the qkv projection, like NATTEN);
 // out is the unpadded [B][Hr][Wr][heads*32] tensor — padded positions are keys/values only, never queries.
-template <typename T, int TILE, int THREADS>
+template <typename T, int TILE, int THREADS, bool VPAD>
 __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ pad_kv, const float* __restrict__ rpb,
                                                            T* __restrict__ out, int B, int H, int W, int Hr, int Wr, int heads,
                                                            int dil, float scale, int total_tiles, int halo_r, int halo_c, int tile_bytes, int kpitch, int vpitch) {
@@ -107,6 +107,12 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
     // Hr x Wr real tokens and every padded position has the same k / v, pad_kv[3][heads][32] (the qkv bias: NATTEN's module
     // zero-pads BEFORE its projection) — the projection and this kernel then never touch the 1.7-3x larger padded grid.
     const int Hs = pad_kv ? Hr : H, Ws = pad_kv ? Wr : W;
+    // VPAD (bf16 launches with pad_kv): the real keys of a dilation group are the top-left hq x wq corner of its sub-image
+    // and every other key is the same vector, so only real rows are staged, a padded neighbour's logit is the one dot
+    // product q . k_pad (+ its own position bias), and the padded neighbours' probabilities are summed into one
+    // p_pad * v_pad term — DiNAT's 7x7 groups with a 4x4 real corner do a third of the staging, QK and AV work.
+    constexpr bool SKIP = VPAD && sizeof(T) == 2;
+    const int rreal = SKIP ? clampi(hq - r0, 0, nr) : nr, creal = SKIP ? clampi(wq - c0, 0, nc) : nc;   // real part of the halo
     auto kv_src = [&](int which, int y, int x) -> const T* {
         return (!pad_kv || (y < Hr && x < Wr)) ? qkv + ((size_t)(b * Hs + y) * Ws + x) * tok + ((size_t)which * heads + h) * HD
                                                 : pad_kv + ((size_t)which * heads + h) * HD;
@@ -118,9 +124,9 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
         // one 16-byte piece per lane: HD*sizeof(T)/16 pieces per row
         constexpr int PIECES = HD * (int)sizeof(T) / 16, EPP = 16 / (int)sizeof(T);
         if (!tile_in) return;
-        for (int p = tid; p < nr * nc * PIECES; p += NT) {
+        for (int p = tid; p < rreal * creal * PIECES; p += NT) {
             const int row = p / PIECES, piece = p - row * PIECES;
-            const int rr = row / nc, cc = row - rr * nc;
+            const int rr = row / creal, cc = row - rr * creal;
             const int y = gi + (r0 + rr) * dil, x = gj + (c0 + cc) * dil;
             const T* src = kv_src(which, y, x) + piece * EPP;
             *reinterpret_cast<uint4*>(tile + (size_t)rr * kpitch + (size_t)cc * STRIDE + piece * EPP) = *reinterpret_cast<const uint4*>(src);
@@ -137,15 +143,15 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
         if constexpr (BF16) {
             if (!tile_in) return;
             uint32_t* vp = reinterpret_cast<uint32_t*>(tile);
-            const int nrp = (nr + 2) >> 1;                                  // pairs covering rows 0 .. nr
-            for (int p = tid; p < nrp * nc * 4; p += NT) {
+            const int nrp = SKIP ? (rreal + 1) >> 1 : (nr + 2) >> 1;        // pairs covering rows 0 .. nr (the real rows when SKIP)
+            for (int p = tid; p < nrp * creal * 4; p += NT) {
                 const int e = p >> 2, piece = p & 3;
-                const int rp = e / nc, cc = e - rp * nc;
+                const int rp = e / creal, cc = e - rp * creal;
                 const int ra = 2 * rp, rb = ra + 1;
                 const int x = gj + (c0 + cc) * dil;
                 uint4 a = make_uint4(0u, 0u, 0u, 0u), bb = a;
-                if (ra < nr) a = *reinterpret_cast<const uint4*>(kv_src(2, gi + (r0 + ra) * dil, x) + piece * 8);
-                if (rb < nr) bb = *reinterpret_cast<const uint4*>(kv_src(2, gi + (r0 + rb) * dil, x) + piece * 8);
+                if (ra < rreal) a = *reinterpret_cast<const uint4*>(kv_src(2, gi + (r0 + ra) * dil, x) + piece * 8);
+                if (rb < rreal) bb = *reinterpret_cast<const uint4*>(kv_src(2, gi + (r0 + rb) * dil, x) + piece * 8);
                 uint32_t* dst = vp + (size_t)rp * vpitch + (size_t)cc * VP + piece * 8;
                 // v_perm_b32: bytes 0-3 = second operand, 4-7 = first
                 *reinterpret_cast<uint4*>(dst) = make_uint4(__builtin_amdgcn_perm(bb.x, a.x, 0x05040100u), __builtin_amdgcn_perm(bb.x, a.x, 0x07060302u),
@@ -179,13 +185,30 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
     float mx = -3.0e38f;
     if (valid) {
         const int pbi = wi - u + (KS - 1), pbj = wj - v + (KS - 1);         // bias index of window member (0,0)
+        float qk_pad = 0.0f;
+        if constexpr (SKIP) {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+            const T* kp = pad_kv + ((size_t)heads + h) * HD;
+#pragma unroll
+            for (int p4 = 0; p4 < HD / 8; ++p4) {
+                const uint4 w4 = *reinterpret_cast<const uint4*>(kp + 8 * p4);
+                qk_pad = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, qp[4 * p4]), __builtin_bit_cast(bf2, w4.x), qk_pad, false);
+                qk_pad = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, qp[4 * p4 + 1]), __builtin_bit_cast(bf2, w4.y), qk_pad, false);
+                qk_pad = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, qp[4 * p4 + 2]), __builtin_bit_cast(bf2, w4.z), qk_pad, false);
+                qk_pad = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, qp[4 * p4 + 3]), __builtin_bit_cast(bf2, w4.w), qk_pad, false);
+            }
+            qk_pad *= scale;
+        }
 #pragma unroll
         for (int ki = 0; ki < KS; ++ki) {
 #pragma unroll
             for (int kj = 0; kj < KS; ++kj) {
                 const T* krow = tile + (size_t)(wi - r0 + ki) * kpitch + (size_t)(wj - c0 + kj) * STRIDE;
                 float acc = 0.0f;
-                if constexpr (BF16) {
+                const bool real = !SKIP || ((wi - r0 + ki) < rreal && (wj - c0 + kj) < creal);
+                if (!real) {
+                    acc = qk_pad;
+                } else if constexpr (BF16) {
                     // v_dot2c_f32_bf16: two channels per instruction, float32 accumulate; the bf16 q cannot carry the
                     // scale without another rounding, so the scale multiplies the finished dot product instead
                     typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
@@ -229,6 +252,7 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
             const int hr = wi - r0;                                         // window start in halo rows
             const bool odd = hr & 1;
             const int rp0 = hr >> 1;
+            float p_pad = 0.0f;                                             // SKIP: total probability of the padded neighbours
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -236,7 +260,14 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
                     // rows 2(rp0+t), 2(rp0+t)+1 are window rows (2t, 2t+1) for an even start, (2t-1, 2t) for an odd one
                     const float pe_a = logit[(2 * t) * KS + kj], pe_b = (2 * t + 1 < KS) ? logit[(2 * t + 1) * KS + kj] : 0.0f;
                     const float po_a = (t > 0) ? logit[(2 * t - 1) * KS + kj] : 0.0f, po_b = logit[(2 * t) * KS + kj];
-                    const float pa = odd ? po_a : pe_a, pb = odd ? po_b : pe_b;
+                    float pa = odd ? po_a : pe_a, pb = odd ? po_b : pe_b;
+                    if constexpr (SKIP) {                                   // real rows are a prefix: row b real => row a real
+                        const bool c_real = (wj - c0 + kj) < creal;
+                        const bool a_real = c_real && 2 * (rp0 + t) < rreal, b_real = c_real && 2 * (rp0 + t) + 1 < rreal;
+                        p_pad += (a_real ? 0.0f : pa) + (b_real ? 0.0f : pb);
+                        pa = a_real ? pa : 0.0f; pb = b_real ? pb : 0.0f;
+                        if (!a_real) continue;                              // nothing staged here
+                    }
                     const bf2 pp = {(__bf16)pa, (__bf16)pb};
                     const uint32_t* ent = vp + (size_t)(rp0 + t) * vpitch + (size_t)(wj - c0 + kj) * VP;
 #pragma unroll
@@ -249,6 +280,12 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
                     }
                     asm volatile("" ::: "memory");
                 }
+            }
+            if constexpr (SKIP) {
+                float vr[HD];
+                load_row(pad_kv + ((size_t)2 * heads + h) * HD, vr);
+#pragma unroll
+                for (int c = 0; c < HD; ++c) o[c] = fmaf(p_pad, vr[c], o[c]);
             }
         } else {
 #pragma unroll
@@ -272,8 +309,8 @@ __global__ __launch_bounds__(THREADS) void na2d_fwd_kernel(const T* __restrict__
     }
 }
 
-template <typename T, int TILE, int THREADS>
-static int launch_variant(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
+template <typename T, int TILE, int THREADS, bool VPAD>
+static int launch_variant_v(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
                           float scale, hipStream_t stream) {
     constexpr int HALO = TILE + KS - 1, TPB = THREADS / (TILE * TILE);
     const int hs = (H + dil - 1) / dil, ws = (W + dil - 1) / dil;            // largest key sub-image
@@ -291,11 +328,18 @@ static int launch_variant(const void* qkv, const void* pad_kv, const float* rpb,
     }
     tile_bytes = (tile_bytes + 15) & ~(size_t)15;
     const size_t lds = (size_t)TPB * tile_bytes + 169 * sizeof(float);
-    hipError_t e = hipFuncSetAttribute((const void*)na2d_fwd_kernel<T, TILE, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)na2d_fwd_kernel<T, TILE, THREADS, VPAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((na2d_fwd_kernel<T, TILE, THREADS>), grid, dim3(THREADS), lds, stream, (const T*)qkv, (const T*)pad_kv, rpb, (T*)out, B, H, W, Hr,
+    hipLaunchKernelGGL((na2d_fwd_kernel<T, TILE, THREADS, VPAD>), grid, dim3(THREADS), lds, stream, (const T*)qkv, (const T*)pad_kv, rpb, (T*)out, B, H, W, Hr,
                        Wr, heads, dil, scale, (int)total, halo_r, halo_c, (int)tile_bytes, (int)(kpitch_b / sizeof(T)), (int)(vpitch_b / 4));
     return (int)hipGetLastError();
+}
+
+template <typename T, int TILE, int THREADS>
+static int launch_variant(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
+                          float scale, hipStream_t stream) {
+    return pad_kv ? launch_variant_v<T, TILE, THREADS, true>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream)
+                  : launch_variant_v<T, TILE, THREADS, false>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
 }
 
 template <typename T>

@@ -23,9 +23,10 @@ def _use_tuned_gemms():
         if os.path.exists(_TUNED) and torch.cuda.is_available():
             import tempfile
             tn.enable(True)
-            tn.tuning_enable(False)
+            retune = os.environ.get("PPNET_TUNE_GEMMS")          # maintainer knob: path of a table to (re)record
+            tn.tuning_enable(bool(retune))
             # TunableOp saves its table to its filename at exit: point that at a scratch path, never at the shipped table
-            tn.set_filename(os.path.join(tempfile.gettempdir(), f"ppnet_amd_tunableop_{os.getpid()}.csv"))
+            tn.set_filename(retune or os.path.join(tempfile.gettempdir(), f"ppnet_amd_tunableop_{os.getpid()}.csv"))
             tn.read_file(_TUNED)
     except Exception as e:                                   # an optional speed-up must never break inference
         print(f"ppnet_amd: tuned GEMM table not used ({e})")

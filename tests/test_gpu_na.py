@@ -108,4 +108,11 @@ def test_virtual_padding_equals_materialised_padding(dev, H, W, Hr, Wr, d, heads
     want = na.na2d_forward(full, rpb, heads, d, 32 ** -0.5, real_hw=(Hr, Wr))
     got = na.na2d_forward(real, rpb, heads, d, 32 ** -0.5, pad_kv=bias, padded_hw=(H, W))
     assert got.shape == want.shape == (2, Hr, Wr, C)
-    assert torch.equal(got, want)
+    if dt == torch.float32:
+        assert torch.equal(got, want)
+    else:
+        # bf16: the padded neighbours' probabilities are pooled into one p_pad * v_pad term (float32) instead of being
+        # rounded to bf16 one by one — same logits and softmax, a different (finer) accumulation of the AV product
+        assert (got.float() - want.float()).abs().max() < 2e-2
+        ref = NA.na2d_from_qkv(full.float().cpu().numpy(), rpb.cpu().numpy(), heads, 7, d, 32 ** -0.5)[:, :Hr, :Wr]
+        assert np.abs(got.float().cpu().numpy() - ref).max() < 3e-2

@@ -13,17 +13,18 @@ for side, C, heads, dils in ((64, 128, 4, (1, 16)), (32, 256, 8, (1, 4, 8)), (16
         shapes.append((side, C, heads, d))
 for side, C, heads, d in shapes:
     pad = max(side, 7 * d)
-    qkv = torch.randn(B, pad, pad, 3 * C, device=dev, dtype=torch.bfloat16)
+    qkv = torch.randn(B, side, side, 3 * C, device=dev, dtype=torch.bfloat16)     # real tokens; the pad is virtual (as the module runs it)
     rpb = torch.randn(heads, 13, 13, device=dev)
+    kw = dict(pad_kv=torch.randn(3 * C, device=dev, dtype=torch.bfloat16), padded_hw=(pad, pad)) if pad > side else {}
     for _ in range(3):
-        na2d_forward(qkv, rpb, heads, d, 32 ** -0.5, real_hw=(side, side))
+        na2d_forward(qkv, rpb, heads, d, 32 ** -0.5, **kw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        na2d_forward(qkv, rpb, heads, d, 32 ** -0.5, real_hw=(side, side))
+        na2d_forward(qkv, rpb, heads, d, 32 ** -0.5, **kw)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     nq = B * side * side * heads
-    byts = (B * pad * pad * 3 * C + B * side * side * C) * 2
+    byts = (B * side * side * 3 * C + B * side * side * C) * 2
     print(f"side {side:3d} C {C:4d} d {d:2d} pad {pad:3d}: {ms:7.4f} ms  {nq / ms / 1e6:6.2f} q/ns  bytes {byts / 1e6:7.1f} MB  hbm-time frac {byts / 8e12 * 1e3 / ms:5.2f}")
     del qkv

@@ -22,3 +22,12 @@ for _ in range(3):
     m.plan(*args)
 torch.cuda.synchronize()
 print("ms per batch", (time.perf_counter() - t) / 3 * 1e3)
+if os.environ.get("PPNET_TUNE_GEMMS"):
+    import torch.cuda.tunable as tn
+    res = tn.get_results()
+    print("tunable results:", len(res))
+    with open(os.environ["PPNET_TUNE_GEMMS"], "w") as f:
+        for k, v in tn.get_validators():
+            f.write(f"Validator,{k},{v}\n")
+        for r in res:
+            f.write(",".join(str(t) for t in r) + "\n")
