@@ -139,7 +139,7 @@ int ppn_edage_paths_ex(int32_t n_paths, uint64_t first_path_id, int32_t R, doubl
     prm.force_straight = force_straight;
     int rc = polyfit_table_device(&prm.W);
     if (rc != PPN_OK) return rc;
-    const size_t lds = (size_t)(2 * R) * (2 * R) / 8;
+    const size_t lds = (size_t)PPN_PATH_POINTS * 24 + (size_t)(2 * R) * (2 * R) / 8;      // path points + lattice + canvas bits
     PPN_HIP(hipFuncSetAttribute((const void*)ppn::edage_paths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(ppn::edage_paths_kernel, dim3(n_paths), dim3(PPN_PATHS_THREADS), lds, (hipStream_t)stream, prm);
     PPN_HIP(hipGetLastError());

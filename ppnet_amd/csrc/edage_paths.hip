@@ -42,6 +42,9 @@ namespace {
 // One path per workgroup.  256 threads: the chain is latency-bound (alone 256/512/1024 threads take the same time), and
 // beside stage B a 4-wave workgroup leaves its CU one more stage-B workgroup than an 8-wave one does (registers: 97 x 1
 // vs 81 x 2 per SIMD): 0.200 vs 0.210 ms per bench step.
+#ifndef PPN_PATHS_WAVES_PER_EU
+#define PPN_PATHS_WAVES_PER_EU 6      // register cap (<= 80 VGPRs): what a stage-A wave leaves of its SIMD's file is stage B's
+#endif
 constexpr int NT = PPN_PATHS_THREADS;
 constexpr int NW = NT / 64;
 
@@ -83,11 +86,15 @@ __device__ __forceinline__ void boundary_sample(const SegLds& S, int s, int j, d
 
 }  // namespace
 
-__global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
-    extern __shared__ uint32_t canvas[];          // (2R)^2 / 32 words
+__global__ __launch_bounds__(NT, PPN_PATHS_WAVES_PER_EU) void edage_paths_kernel(PathsParams prm) {
+    // dynamic LDS: pp [1000][2] f64 path points (world, later image) | lat [1000][2] i32 integer lattice (hull input) |
+    // canvas (2R)^2 / 32 words.  They are dynamic rather than static so that the compiler's occupancy estimate is not
+    // pinned by 24 KB of static LDS and the register cap below is honoured.
+    extern __shared__ uint64_t paths_lds[];
+    double (*pp)[2] = reinterpret_cast<double (*)[2]>(paths_lds);
+    int (*lat)[2] = reinterpret_cast<int (*)[2]>(reinterpret_cast<unsigned char*>(paths_lds) + PPN_PATH_POINTS * 16);
+    uint32_t* canvas = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(paths_lds) + PPN_PATH_POINTS * 24);
     __shared__ SegLds S;
-    __shared__ double pp[PPN_PATH_POINTS][2];     // path points: world, later image
-    __shared__ int lat[PPN_PATH_POINTS][2];       // integer lattice (hull input)
     __shared__ double hull[PPN_MAX_HULL][2];
     __shared__ int hull_i[PPN_MAX_HULL][2];
     __shared__ double fit_part[PPN_SEGS][4];
@@ -440,27 +447,87 @@ __global__ __launch_bounds__(NT) void edage_paths_kernel(PathsParams prm) {
     }
 
     PPN_PSTAMP(5);
-    // corridor mask Path.Space: rotate (nearest, about the canvas centre) then translate + crop,
-    // composed per output pixel; 32 pixels (one mask word) per thread iteration
+    // corridor mask Path.Space: rotate (nearest, about the canvas centre) then translate + crop, composed per output
+    // pixel, 32 pixels (one mask word) per thread iteration.  The corridor covers a few per cent of the canvas, so a
+    // coarse map (one bit per 16x16 canvas tile) first rules most words out: the 32 pixels of a word map onto a straight
+    // run of canvas pixels between the images of its two ends (the inverse map is affine in the column), so if every
+    // tile of that run's bounding box (+1 px for the roundings) is empty the word is zero.  The surviving words are
+    // compacted into a list and processed densely (a cull without compaction saves nothing: one live lane holds its wave).
     {
+        __shared__ int n_live;
+        uint32_t* ctile = reinterpret_cast<uint32_t*>(lat);                  // [128] tile occupancy bits; lat is dead after the hull
+        unsigned short* live = reinterpret_cast<unsigned short*>(ctile + 128);   // word indices that may be non-zero (3744 slots; more fall back in place)
+        const int tps = 2 * R / 16;                                 // tiles per canvas side
+        for (int w = tid; w < 128; w += NT) ctile[w] = 0u;
+        if (tid == 0) n_live = 0;
+        __syncthreads();
+        const int cwpr = 2 * R / 32;
+        for (int w = tid; w < canvas_words; w += NT) {
+            const uint32_t v = canvas[w];
+            if (v) {
+                const int row = w / cwpr, ty = row >> 4, tx = (w - row * cwpr) * 2;
+                if (v & 0xffffu) { const int t = ty * tps + tx; atomicOr(&ctile[t >> 5], 1u << (t & 31)); }
+                if (v >> 16) { const int t = ty * tps + tx + 1; atomicOr(&ctile[t >> 5], 1u << (t & 31)); }
+            }
+        }
+        __syncthreads();
         const double c2 = bc[5], s2 = bc[6];
         const int words = R * R / 32, wpr = R / 32;
+        const int live_cap = (PPN_PATH_POINTS * 8 - 512) / 2;      // entries the lat region holds behind ctile
         for (int w = tid; w < words; w += NT) {
             const int i = w / wpr, j0 = (w - i * wpr) * 32;
             const int i1 = (int)rint((double)i - t_row);         // translate_nearest: ty = t_row
-            uint32_t m = 0u;
+            bool maybe = false;
             if (i1 >= 0 && i1 < 2 * R) {
+                const double yo = ((double)i1 + 0.5) - Rd;
+                const double xa = (rint((double)j0 - t_col) + 0.5) - Rd, xb = (rint((double)(j0 + 31) - t_col) + 0.5) - Rd;
+                const int ja = (int)rint(c2 * xa - s2 * yo + (Rd - 0.5)), ia = (int)rint(s2 * xa + c2 * yo + (Rd - 0.5));
+                const int jb = (int)rint(c2 * xb - s2 * yo + (Rd - 0.5)), ib = (int)rint(s2 * xb + c2 * yo + (Rd - 0.5));
+                const int x0 = max(min(ja, jb) - 1, 0), x1 = min(max(ja, jb) + 1, 2 * R - 1);
+                const int y0 = max(min(ia, ib) - 1, 0), y1 = min(max(ia, ib) + 1, 2 * R - 1);
+                for (int ty = y0 >> 4; ty <= (y1 >> 4); ++ty)
+                    for (int tx = x0 >> 4; tx <= (x1 >> 4); ++tx) {
+                        const int t = ty * tps + tx;
+                        maybe = maybe || ((ctile[t >> 5] >> (t & 31)) & 1u);
+                    }
+            }
+            int slot = -1;
+            if (maybe) slot = atomicAdd(&n_live, 1);
+            if (maybe && slot < live_cap) live[slot] = (unsigned short)w;
+            else if (!maybe) O.space_bits[(size_t)p * words + w] = 0u;
+            else slot = -2;                                       // list full (cannot happen for R <= 256): do it here
+            if (slot == -2) {
+                uint32_t m = 0u;
                 const double yo = ((double)i1 + 0.5) - Rd;
                 for (int b = 0; b < 32; ++b) {
                     const int j1 = (int)rint((double)(j0 + b) - t_col);
                     if (j1 < 0 || j1 >= 2 * R) continue;
                     const double xo = ((double)j1 + 0.5) - Rd;
-                    const double xs = c2 * xo - s2 * yo, ys = s2 * xo + c2 * yo;
-                    const int jj = (int)rint(xs + (Rd - 0.5)), ii = (int)rint(ys + (Rd - 0.5));
+                    const int jj = (int)rint(c2 * xo - s2 * yo + (Rd - 0.5)), ii = (int)rint(s2 * xo + c2 * yo + (Rd - 0.5));
                     if (ii < 0 || ii >= 2 * R || jj < 0 || jj >= 2 * R) continue;
                     const int bit = ii * 2 * R + jj;
                     m |= ((canvas[bit >> 5] >> (bit & 31)) & 1u) << b;
                 }
+                O.space_bits[(size_t)p * words + w] = m;
+            }
+        }
+        __syncthreads();
+        const int nl = min(n_live, live_cap);
+        for (int e = tid; e < nl; e += NT) {
+            const int w = live[e];
+            const int i = w / wpr, j0 = (w - i * wpr) * 32;
+            const int i1 = (int)rint((double)i - t_row);
+            const double yo = ((double)i1 + 0.5) - Rd;
+            uint32_t m = 0u;
+            for (int b = 0; b < 32; ++b) {
+                const int j1 = (int)rint((double)(j0 + b) - t_col);
+                if (j1 < 0 || j1 >= 2 * R) continue;
+                const double xo = ((double)j1 + 0.5) - Rd;
+                const double xs = c2 * xo - s2 * yo, ys = s2 * xo + c2 * yo;
+                const int jj = (int)rint(xs + (Rd - 0.5)), ii = (int)rint(ys + (Rd - 0.5));
+                if (ii < 0 || ii >= 2 * R || jj < 0 || jj >= 2 * R) continue;
+                const int bit = ii * 2 * R + jj;
+                m |= ((canvas[bit >> 5] >> (bit & 31)) & 1u) << b;
             }
             O.space_bits[(size_t)p * words + w] = m;
         }
