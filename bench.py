@@ -154,7 +154,16 @@ def main():
     TIMED_EVERY = 4
     NPB = DEPTH + 1
     pbs = [edage.PathsBatch(PATHS, R, MAP_SIZE, CLEARANCE, dev) for _ in range(NPB)]
-    mb = edage.MapsBatch(PATHS * PLACEMENTS, R, K, dev)
+    # N > 1: the end-of-batch all-gather of the fixed-size records runs on its own stream beside the next batch, so the
+    # maps are double-buffered (batch i+1 must not overwrite the labels batch i's records are packed from).
+    exchange = world > 1 or bool(os.environ.get("BENCH_FORCE_EXCHANGE"))      # the env knob rehearses the stream logic on one GPU
+    NMB = 2 if exchange else 1
+    mbs = [edage.MapsBatch(PATHS * PLACEMENTS, R, K, dev) for _ in range(NMB)]
+    mb = mbs[0]
+    if exchange:
+        s_comm = torch.cuda.Stream(dev)
+        gathered = [torch.empty(max(world, 1) * PATHS * PLACEMENTS, shard.RECORD_WIDTH, dtype=torch.float64, device=dev) for _ in range(NMB)]
+        sent = [None] * NMB       # the records of the batch in maps buffer m have been read by the collective (it may be rewritten)
     s_paths = [torch.cuda.Stream(dev) for _ in range(DEPTH)]
     s_maps = torch.cuda.current_stream(dev)
     ready = [None] * NPB          # paths of buffer b are complete
@@ -190,12 +199,22 @@ def main():
         if it % TIMED_EVERY == 0 or args.steps < TIMED_EVERY:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record()
-        edage.generate_maps(pbs[b], PLACEMENTS, OBST_SIZE, K, seed=SEED, first_map_id=first_map, out=mb)
+        m = it % NMB
+        if exchange and sent[m] is not None:
+            s_maps.wait_event(sent[m])        # the records of batch it-2 have left this maps buffer
+        edage.generate_maps(pbs[b], PLACEMENTS, OBST_SIZE, K, seed=SEED, first_map_id=first_map, out=mbs[m])
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
         consumed[b] = ev1
-        if world > 1:                         # end-of-batch gather of the fixed-size records (RCCL over xGMI)
-            shard.gather_records(shard.pack_records(mb.angle, mb.flags, mb.translation, mb.segpoint), world)
+        if exchange:                          # end-of-batch gather of the fixed-size records (RCCL over xGMI), off the compute stream
+            with torch.cuda.stream(s_comm):
+                s_comm.wait_event(ev1)
+                if world > 1:                 # stage B wrote the packed records itself (ppn_maps_t.records): no pack pass
+                    shard.gather_records(mbs[m].records, world, out=gathered[m])
+                else:
+                    gathered[m].copy_(mbs[m].records)     # rehearsal stand-in for the collective
+                sent[m] = torch.cuda.Event()
+                sent[m].record(s_comm)
         return ev0, ev1
 
     for it in range(args.warmup):
@@ -216,6 +235,7 @@ def main():
 
     timed = [(a, b) for a, b in evs if a is not None]
     maps_kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / len(timed)
+    mb = mbs[(args.warmup + args.steps - 1) % NMB]     # the newest batch
     k_tot = float(mb.n_obstacles[:, 0].double().mean().item())
     k_pocket = float(pbs[0].n_obstacles.double().mean().item())
     placed = float(((mb.flags & 2) == 0).double().mean().item())

@@ -139,7 +139,11 @@ typedef struct ppn_maps {
     double*   obstacles;        /* [n][K+64][3] kept random obstacles then pocket obstacles */
     int32_t*  n_obstacles;      /* [n][2] (total, of which random)                      */
     uint32_t* flags;            /* [n]                                                  */
+    double*   records;          /* [n][PPN_RECORD_WIDTH] optional: angle, flags, translation[2], segpoint[11][2] as doubles —
+                                   the fixed-size per-instance record the ranks all-gather at the end of a batch
+                                   (SURVEY 8e), written by the kernel so that no pack pass precedes the collective */
 } ppn_maps_t;
+#define PPN_RECORD_WIDTH 26
 
 /* place_draws : [n_maps][3] (angle, t0, t1 uniforms of the ACCEPTED attempt) or NULL = Philox
  *               rejection loop (stream PLACE, draw index 3*attempt+i);

@@ -42,7 +42,7 @@ class MapsStruct(C.Structure):
     """ppn_maps_t"""
     _fields_ = [(n, _p) for n in (
         "grid", "angle", "translation", "attempts", "segpoint", "pathpoint", "accept", "obstacles",
-        "n_obstacles", "flags")]
+        "n_obstacles", "flags", "records")]
 
 
 EXPORTS = ("ppn_version", "ppn_error_string", "ppn_last_hip_error", "ppn_polyfit_table", "ppn_edage_paths",

@@ -224,6 +224,10 @@ __global__ __launch_bounds__(NT, PPN_MAPS_WAVES_PER_EU) void edage_maps_kernel_t
                 bci[0] = t0; bci[1] = t1; bci[2] = attempts; bci[3] = (int)flags;
                 O.angle[m] = angle;
                 O.translation[(size_t)m * 2] = t0; O.translation[(size_t)m * 2 + 1] = t1;
+                if (O.records) {
+                    double* rec = O.records + (size_t)m * PPN_RECORD_WIDTH;
+                    rec[0] = angle; rec[2] = (double)t0; rec[3] = (double)t1;
+                }
                 O.attempts[m] = attempts;
             }
         }
@@ -262,6 +266,7 @@ __global__ __launch_bounds__(NT, PPN_MAPS_WAVES_PER_EU) void edage_maps_kernel_t
             ry = ry + half + tr1;
             O.segpoint[((size_t)m * 11 + tid) * 2] = rx;
             O.segpoint[((size_t)m * 11 + tid) * 2 + 1] = ry;
+            if (O.records) { O.records[(size_t)m * PPN_RECORD_WIDTH + 4 + 2 * tid] = rx; O.records[(size_t)m * PPN_RECORD_WIDTH + 5 + 2 * tid] = ry; }
             if (tid == 0) { bc[2] = rx; bc[3] = ry; }                         // init = segpoint[0]
             if (tid == PPN_SEGS) { bc[4] = rx; bc[5] = ry; }                  // end = segpoint[10]
         }
@@ -394,6 +399,7 @@ __global__ __launch_bounds__(NT, PPN_MAPS_WAVES_PER_EU) void edage_maps_kernel_t
             O.n_obstacles[(size_t)m * 2 + 1] = n_rand;
             // PPN_FLAG_CORRIDOR_PASS tells the raster kernel that some obstacle may touch the corridor
             O.flags[m] = flags | path_flags | (bci[12] ? PPN_FLAG_CORRIDOR_PASS : 0u);
+            if (O.records) O.records[(size_t)m * PPN_RECORD_WIDTH + 1] = (double)(int32_t)(flags | path_flags | (bci[12] ? PPN_FLAG_CORRIDOR_PASS : 0u));
         }
         compose = bci[12] != 0;                                           // same thread wrote it or a barrier lies between
         PPN_STAMP(4);

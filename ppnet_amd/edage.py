@@ -95,6 +95,7 @@ class MapsBatch:
         self.obstacles = torch.zeros(n, K + L.MAX_POCKET, 3, **f64)
         self.n_obstacles = e(n, 2, **i32)
         self.flags = e(n, **i32)
+        self.records = e(n, 26, **f64)             # shard.RECORD_WIDTH: angle, flags, translation, segpoint (all-gather unit)
         self.struct = L.MapsStruct(**{name: _ptr(getattr(self, name)) for name, _ in L.MapsStruct._fields_})
 
 

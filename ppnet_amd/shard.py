@@ -25,9 +25,9 @@ def local_ids(n_paths_total, placements, rank, world, batch_index=0):
     return base + lo, hi - lo, (base + lo) * placements
 
 
-def pack_records(angle, flags, translation, segpoint):
+def pack_records(angle, flags, translation, segpoint, out=None):
     n = angle.shape[0]
-    rec = torch.empty(n, RECORD_WIDTH, dtype=torch.float64, device=angle.device)
+    rec = out if out is not None else torch.empty(n, RECORD_WIDTH, dtype=torch.float64, device=angle.device)
     rec[:, 0] = angle
     rec[:, 1] = flags.to(torch.float64)
     rec[:, 2:4] = translation.to(torch.float64)
@@ -35,12 +35,14 @@ def pack_records(angle, flags, translation, segpoint):
     return rec
 
 
-def gather_records(rec, world, sizes=None, group=None):
-    """All-gather of per-instance records; `sizes` = rows per rank when shards are uneven."""
+def gather_records(rec, world, sizes=None, group=None, out=None):
+    """All-gather of per-instance records; `sizes` = rows per rank when shards are uneven; `out` = a preallocated
+    [world * rows, width] buffer for the even case (a steady-state loop should not allocate on a side stream)."""
     if world == 1:
         return rec
     if sizes is None or len(set(sizes)) == 1:
-        out = torch.empty(world * rec.shape[0], rec.shape[1], dtype=rec.dtype, device=rec.device)
+        if out is None:
+            out = torch.empty(world * rec.shape[0], rec.shape[1], dtype=rec.dtype, device=rec.device)
         dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
         return out
     m = max(sizes)

@@ -285,6 +285,16 @@ def test_corridor_compose_skip_is_exact(dev, R, clearance):
     assert torch.equal(a.pathpoint, b.pathpoint)
 
 
+def test_records_equal_packed_labels(dev):
+    """ppn_maps_t.records: the all-gather unit written by the kernel equals shard.pack_records of the same batch."""
+    import torch
+    from ppnet_amd import edage, shard
+    pb = edage.generate_paths(6, 128, 50, 2, seed=9, device=dev)
+    mb = edage.generate_maps(pb, 7, 5, 12, seed=9)
+    assert mb.records.shape == (42, shard.RECORD_WIDTH)
+    assert torch.equal(mb.records, shard.pack_records(mb.angle, mb.flags, mb.translation, mb.segpoint))
+
+
 def test_split_phases_equal_single_call(dev):
     """ppn_edage_maps_place + ppn_edage_maps_raster (separate launches, the raster on another stream behind an
     event) fill a MapsBatch exactly as ppn_edage_maps does; the place phase alone leaves `grid` untouched."""

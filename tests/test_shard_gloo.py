@@ -35,6 +35,14 @@ def _worker(rank, world, port, out_dir):
     sizes = [(shard.shard_range(PATHS, r, world)[1] - shard.shard_range(PATHS, r, world)[0]) * PLACEMENTS for r in range(world)]
     full = shard.gather_records(rec, world, sizes=sizes)
     torch.save(full, os.path.join(out_dir, f"rank{rank}.pt"))
+    # the even-shard form the bench uses: preallocated record and gather buffers (each rank contributes its first 6 rows)
+    buf = torch.empty(6, shard.RECORD_WIDTH, dtype=torch.float64)
+    packed = shard.pack_records(rec[:6, 0], rec[:6, 1].to(torch.int32), rec[:6, 2:4].to(torch.int32), rec[:6, 4:].reshape(6, 11, 2), out=buf)
+    assert packed is buf and torch.equal(buf, rec[:6])
+    out = torch.full((world * 6, shard.RECORD_WIDTH), -1.0, dtype=torch.float64)
+    got = shard.gather_records(buf, world, out=out)
+    assert got is out
+    torch.save(out, os.path.join(out_dir, f"even{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -59,3 +67,7 @@ def test_two_ranks_gloo_equal_single_process(tmp_path):
         got = torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=True)
         assert got.shape == whole.shape
         assert torch.equal(got, whole)          # bit-exact: same ids, same streams, any world size
+    n0 = (shard.shard_range(PATHS, 0, 2)[1]) * PLACEMENTS
+    even = torch.cat([whole[:6], whole[n0:n0 + 6]])
+    for r in range(2):
+        assert torch.equal(torch.load(os.path.join(tmp_path, f"even{r}.pt"), weights_only=True), even)
