@@ -40,7 +40,7 @@ def test_binding_matches_header():
     assert _lib.lib.ppn_version() >= 100
     assert _lib.lib.ppn_error_string(-1) == b"invalid argument"
     assert C.sizeof(_lib.PathsStruct) == 28 * C.sizeof(C.c_void_p)
-    assert C.sizeof(_lib.MapsStruct) == 10 * C.sizeof(C.c_void_p)
+    assert C.sizeof(_lib.MapsStruct) == 11 * C.sizeof(C.c_void_p)
 
 
 def test_invalid_arguments_return_codes_without_gpu():
