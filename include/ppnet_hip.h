@@ -265,6 +265,16 @@ int ppn_upsample2x_nhwc_bias(const void* x, const void* bias, void* y, int32_t B
  * one pass behind a bias-free library convolution. */
 int ppn_bias_act_nhwc(void* x, const void* bias, int64_t n, int32_t C, float negative_slope, int32_t dtype, void* stream);
 
+/* The single-channel 3x3 convolutions at the two ends of GenNet's AE-ViT (ae_vit.py:17-20,58; stride 1, padding 1) as
+ * direct kernels, float32 accumulation, weights and bias float32 on the device:
+ *   _c1  : x [B][H][W] -> y [B][H][W][Cout] (NHWC), y = leaky_relu(conv(x, w[Cout][1][3][3]) + bias[Cout], negative_slope)
+ *          (the BatchNorm folded into w / bias by the caller), Cout in {8,16,24,32};
+ *   _to1 : x [B][H][W][Cin] (NHWC) -> y [B][H][W], y = conv(x, w[1][Cin][3][3]) + bias, Cin in {8,16,24,32}. */
+int ppn_conv3x3_c1_nhwc(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t H, int32_t W,
+                        int32_t Cout, float negative_slope, int32_t dtype, void* stream);
+int ppn_conv3x3_to1_nhwc(const void* x, const float* w, float bias, void* y, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                         int32_t dtype, void* stream);
+
 /* PIL.Image.resize(size, BILINEAR) for 8-bit single-channel images, bit-exact: Pillow's ImagingResample
  * (support = max(scale,1), 22-bit fixed-point coefficients, horizontal pass then vertical pass, each rounded
  * to 8 bits).  Used by extract_path's down-sampling (process_map.py:301).  in [n][H][W], tmp [n][H][outW],

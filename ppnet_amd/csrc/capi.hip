@@ -360,6 +360,24 @@ int ppn_bias_act_nhwc(void* x, const void* bias, int64_t n, int32_t C, float neg
     return PPN_OK;
 }
 
+int ppn_conv3x3_c1_nhwc(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t H, int32_t W, int32_t Cout,
+                        float negative_slope, int32_t dtype, void* stream) {
+    if (!x || !w || !bias || !y || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout > 32 || (Cout % 8) != 0 || (dtype != 0 && dtype != 1))
+        return PPN_E_INVALID;
+    const int e = ppn::conv3x3_c1_launch(x, w, bias, y, B, H, W, Cout, negative_slope, dtype, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
+int ppn_conv3x3_to1_nhwc(const void* x, const float* w, float bias, void* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t dtype,
+                         void* stream) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin > 32 || (Cin % 8) != 0 || (dtype != 0 && dtype != 1))
+        return PPN_E_INVALID;
+    const int e = ppn::conv3x3_to1_launch(x, w, bias, y, B, H, W, Cin, dtype, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_resize_bilinear_u8(const uint8_t* in, int32_t n, int32_t H, int32_t W, int32_t outH, int32_t outW, uint8_t* tmp,
                            uint8_t* out, void* stream) {
     if (!in || n < 0 || H <= 0 || W <= 0 || outH <= 0 || outW <= 0 || !tmp || !out) return PPN_E_INVALID;

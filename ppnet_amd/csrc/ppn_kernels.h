@@ -67,6 +67,9 @@ int norm_launch(const void* x, const void* a, const void* gamma, const void* w, 
                 long long rows, int C, float eps, int dtype, int Hr, int Wr, int Hp, int Wp, hipStream_t stream);
 
 int upsample2x_launch(const void* x, const void* bias, void* y, int B, int H, int W, int C, int relu, int dtype, hipStream_t stream);
+int conv3x3_c1_launch(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cout, float slope, int dtype,
+                      hipStream_t stream);
+int conv3x3_to1_launch(const void* x, const float* w, float bias, void* y, int B, int H, int W, int Cin, int dtype, hipStream_t stream);
 int bias_act_launch(void* x, const void* bias, long long n, int C, float slope, int dtype, hipStream_t stream);
 
 __global__ void label_masks_kernel(ppn_paths_t paths, ppn_maps_t maps, int placements, int R, int bound, uint8_t* mask_path,

@@ -1,0 +1,147 @@
+// small_conv.hip — the two single-channel 3x3 convolutions at the ends of GenNet's AE-ViT (GenNet/networks/ae_vit.py:17-20,58:
+// conv_first 1 -> dim, conv_final dim -> 1, both stride 1, padding 1, at the full R x R resolution) as direct kernels.
+// With one input or one output channel there is no GEMM to speak of — 216 FMAs per pixel against 48 bytes moved — and the
+// library's implicit-GEMM kernels take 0.54 + 0.72 ms per 256-problem batch where the tensors' HBM time is 0.16 ms each.
+// NHWC (channels_last) on the multi-channel side, float32 accumulation, bias (+ LeakyReLU for conv_first) fused.
+#include <hip/hip_bf16.h>
+#include "ppn_device.h"
+#include "ppn_kernels.h"
+
+namespace ppn {
+
+namespace {
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {          // round-to-nearest-even, finite inputs
+    uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a = (a + 0x7fffu + ((a >> 16) & 1u)) >> 16;
+    b = (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u;
+    return a | b;
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void store8<__hip_bfloat16>(__hip_bfloat16* p, const float (&v)[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+}
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<__hip_bfloat16>(const __hip_bfloat16* p, float (&v)[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+}  // namespace
+
+// y[b][i][j][co] = leaky(bias[co] + sum_{di,dj} w[co][0][di][dj] * x[b][i+di-1][j+dj-1]), zero padding.  One thread per
+// output pixel, CG = Cout / 8 groups of 8 channels; the 9 * Cout weights sit in LDS as [tap][co] (broadcast reads).
+template <typename T, int CG>
+__global__ __launch_bounds__(256) void conv3x3_c1_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         T* __restrict__ y, int B, int H, int W, float slope) {
+    constexpr int C = CG * 8;
+    __shared__ float ws[9][C];
+    __shared__ float bs[C];
+    for (int t = threadIdx.x; t < 9 * C; t += 256) { const int co = t / 9, tap = t - co * 9; ws[tap][co] = w[t]; }
+    for (int t = threadIdx.x; t < C; t += 256) bs[t] = bias[t];
+    __syncthreads();
+    const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * H * W;
+    if (px >= total) return;
+    const int j = (int)(px % W);
+    const long long r = px / W;
+    const int i = (int)(r % H);
+    const T* xb = x + (r - i) * W;                                           // image base
+    float in[9];
+#pragma unroll
+    for (int di = 0; di < 3; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 3; ++dj) {
+            const int ii = i + di - 1, jj = j + dj - 1;
+            in[di * 3 + dj] = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? ld1(xb + (long long)ii * W + jj) : 0.0f;
+        }
+    T* out = y + px * C;
+#pragma unroll
+    for (int g = 0; g < CG; ++g) {
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = bs[g * 8 + k];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = fmaf(ws[tap][g * 8 + k], in[tap], acc[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = acc[k] > 0.0f ? acc[k] : acc[k] * slope;
+        store8<T>(out + g * 8, acc);
+    }
+}
+
+// y[b][i][j] = bias + sum_{di,dj,ci} w[0][ci][di][dj] * x[b][i+di-1][j+dj-1][ci], zero padding.  A 16 x 16 tile of outputs
+// per workgroup, its 18 x 18 x Cin halo staged in LDS as float (entry pitch Cin + 1 keeps the 16 lanes of a row on
+// different banks), weights in LDS as [tap][ci].
+template <typename T, int CG>
+__global__ __launch_bounds__(256) void conv3x3_to1_kernel(const T* __restrict__ x, const float* __restrict__ w, float bias,
+                                                          T* __restrict__ y, int B, int H, int W) {
+    constexpr int C = CG * 8, PITCH = C + 1, HT = 18;
+    __shared__ float tile[HT * HT * PITCH];
+    __shared__ float ws[9][C];
+    for (int t = threadIdx.x; t < 9 * C; t += 256) { const int ci = t / 9, tap = t - ci * 9; ws[tap][ci] = w[t]; }
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    const int b = blockIdx.x / (tiles_x * tiles_y), tt = blockIdx.x - b * tiles_x * tiles_y;
+    const int i0 = (tt / tiles_x) * 16, j0 = (tt % tiles_x) * 16;
+    const T* xb = x + (long long)b * H * W * C;
+    for (int p = threadIdx.x; p < HT * HT * CG; p += 256) {
+        const int e = p / CG, g = p - e * CG;
+        const int hi = e / HT, hj = e - hi * HT;
+        const int ii = i0 + hi - 1, jj = j0 + hj - 1;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ii >= 0 && ii < H && jj >= 0 && jj < W) load8<T>(xb + ((long long)ii * W + jj) * C + g * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[e * PITCH + g * 8 + k] = v[k];
+    }
+    __syncthreads();
+    const int ti = threadIdx.x / 16, tj = threadIdx.x % 16;
+    const int i = i0 + ti, j = j0 + tj;
+    if (i >= H || j >= W) return;
+    float acc = bias;
+#pragma unroll
+    for (int di = 0; di < 3; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 3; ++dj) {
+            const float* e = tile + ((ti + di) * HT + tj + dj) * PITCH;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc = fmaf(ws[di * 3 + dj][c], e[c], acc);
+        }
+    T* out = y + ((long long)b * H + i) * W + j;
+    if constexpr (sizeof(T) == 2) *out = __float2bfloat16(acc); else *out = acc;
+}
+
+int conv3x3_c1_launch(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cout, float slope, int dtype,
+                      hipStream_t stream) {
+    const long long total = (long long)B * H * W;
+    const dim3 grid((unsigned)((total + 255) / 256));
+#define PPN_C1(T, CG) hipLaunchKernelGGL((conv3x3_c1_kernel<T, CG>), grid, dim3(256), 0, stream, (const T*)x, w, bias, (T*)y, B, H, W, slope)
+    const int cg = Cout / 8;
+    if (dtype == 0) { if (cg == 1) PPN_C1(float, 1); else if (cg == 2) PPN_C1(float, 2); else if (cg == 3) PPN_C1(float, 3); else PPN_C1(float, 4); }
+    else { if (cg == 1) PPN_C1(__hip_bfloat16, 1); else if (cg == 2) PPN_C1(__hip_bfloat16, 2); else if (cg == 3) PPN_C1(__hip_bfloat16, 3); else PPN_C1(__hip_bfloat16, 4); }
+#undef PPN_C1
+    return (int)hipGetLastError();
+}
+
+int conv3x3_to1_launch(const void* x, const float* w, float bias, void* y, int B, int H, int W, int Cin, int dtype, hipStream_t stream) {
+    const dim3 grid((unsigned)((long long)B * ((H + 15) / 16) * ((W + 15) / 16)));
+#define PPN_TO1(T, CG) hipLaunchKernelGGL((conv3x3_to1_kernel<T, CG>), grid, dim3(256), 0, stream, (const T*)x, w, bias, (T*)y, B, H, W)
+    const int cg = Cin / 8;
+    if (dtype == 0) { if (cg == 1) PPN_TO1(float, 1); else if (cg == 2) PPN_TO1(float, 2); else if (cg == 3) PPN_TO1(float, 3); else PPN_TO1(float, 4); }
+    else { if (cg == 1) PPN_TO1(__hip_bfloat16, 1); else if (cg == 2) PPN_TO1(__hip_bfloat16, 2); else if (cg == 3) PPN_TO1(__hip_bfloat16, 3); else PPN_TO1(__hip_bfloat16, 4); }
+#undef PPN_TO1
+    return (int)hipGetLastError();
+}
+
+}  // namespace ppn

@@ -102,3 +102,38 @@ def bias_act_(x_nchw_cl, bias, negative_slope):
                                      ctypes.c_void_p(torch.cuda.current_stream(x_nchw_cl.device).cuda_stream))
     L.check(rc, "ppn_bias_act_nhwc")
     return x_nchw_cl
+
+
+def conv3x3_c1(x, w32, b32, negative_slope):
+    """leaky_relu(conv2d(x [B,1,H,W], weight [Cout,1,3,3], bias, stride 1, padding 1), slope) -> channels_last [B,Cout,H,W].
+    w32 / b32: the weight and bias as contiguous float32 device tensors."""
+    if not x.is_cuda:
+        raise RuntimeError("ppnet_amd.fused: GPU tensors only (no CPU fallback)")
+    B, _, H, W = x.shape
+    Cout = w32.shape[0]
+    x = x.contiguous()
+    y = torch.empty(B, H, W, Cout, dtype=x.dtype, device=x.device)
+    assert w32.dtype == torch.float32 and b32.dtype == torch.float32 and w32.is_contiguous() and b32.is_contiguous()
+    with torch.cuda.device(x.device):
+        rc = L.lib.ppn_conv3x3_c1_nhwc(_p(x), _p(w32), _p(b32), _p(y), B, H, W, Cout, float(negative_slope), _DT[x.dtype],
+                                       ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    L.check(rc, "ppn_conv3x3_c1_nhwc")
+    return y.permute(0, 3, 1, 2)
+
+
+def conv3x3_to1(x_nchw_cl, w32, bias):
+    """conv2d(x channels_last [B,Cin,H,W], weight [1,Cin,3,3], bias, stride 1, padding 1) -> [B,1,H,W].
+    w32: the weight as a contiguous float32 device tensor; bias: a Python float."""
+    if not x_nchw_cl.is_cuda:
+        raise RuntimeError("ppnet_amd.fused: GPU tensors only (no CPU fallback)")
+    x = x_nchw_cl.permute(0, 2, 3, 1)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, H, W, Cin = x.shape
+    y = torch.empty(B, 1, H, W, dtype=x.dtype, device=x.device)
+    assert w32.dtype == torch.float32 and w32.is_contiguous()
+    with torch.cuda.device(x.device):
+        rc = L.lib.ppn_conv3x3_to1_nhwc(_p(x), _p(w32), float(bias), _p(y), B, H, W, Cin,
+                                        _DT[x.dtype], ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    L.check(rc, "ppn_conv3x3_to1_nhwc")
+    return y

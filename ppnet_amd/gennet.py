@@ -66,11 +66,19 @@ class _FusedStage(nn.Module):
     def __init__(self, conv, slope):
         super().__init__()
         self.conv, self.slope = conv, slope
+        self._f32 = None                                  # (device, weight, bias) as float32 for the direct 1-channel kernel
 
     def forward(self, x):
         c = self.conv
         if not (x.is_cuda and c.out_channels % 8 == 0):
             return F.leaky_relu(c(x), self.slope)
+        if (isinstance(c, nn.Conv2d) and c.in_channels == 1 and c.out_channels <= 32 and c.kernel_size == (3, 3) and c.stride == (1, 1)
+                and c.padding == (1, 1) and c.dilation == (1, 1)):
+            # 1 -> dim at full resolution: the direct HIP kernel (ppn_conv3x3_c1_nhwc), bias + LeakyReLU inside
+            from . import fused
+            if self._f32 is None or self._f32[0] != x.device:
+                self._f32 = (x.device, c.weight.detach().float().contiguous(), c.bias.detach().float().contiguous())
+            return fused.conv3x3_c1(x, self._f32[1], self._f32[2], self.slope)
         if isinstance(c, nn.ConvTranspose2d):
             y = F.conv_transpose2d(x, c.weight, None, c.stride, c.padding, c.output_padding, c.groups, c.dilation)
         else:
@@ -95,6 +103,7 @@ class AEViT(nn.Module):
         self.vit_blocks = nn.Sequential(*[_Block(dim, 3, 4) for _ in range(3)])
         self.dec_conv = nn.ModuleList(_stage(nn.ConvTranspose2d(dim, dim, 3, 2, 1, output_padding=1)) for _ in range(n_down))
         self.conv_final = nn.Conv2d(dim, out_channels, 3, 1, 1)
+        self._final_f32 = None                            # set by prepare_inference(): (device, float32 weight, float bias)
 
     def prepare_inference(self):
         """After the checkpoint is loaded: fold every eval-mode BatchNorm into the (transposed) convolution in front of
@@ -112,6 +121,8 @@ class AEViT(nn.Module):
         self.conv_first = _FusedStage(self.conv_first[0], self.conv_first[2].negative_slope)
         self.enc_conv = nn.ModuleList(_FusedStage(st[0], st[2].negative_slope) for st in self.enc_conv)
         self.dec_conv = nn.ModuleList(_FusedStage(st[0], st[2].negative_slope) for st in self.dec_conv)
+        cf = self.conv_final
+        self._final_f32 = (None, cf.weight.detach().float().contiguous(), float(cf.bias.detach().float()[0]) if cf.bias is not None and cf.out_channels == 1 else 0.0)
         return self
 
     def forward(self, x):
@@ -123,7 +134,13 @@ class AEViT(nn.Module):
         x = t.transpose(1, 2).reshape(B, C, H, W)
         for blk in self.dec_conv:
             x = blk(x)
-        return self.conv_final(x)
+        c = self.conv_final
+        if x.is_cuda and self._final_f32 is not None and c.out_channels == 1 and c.in_channels % 8 == 0 and c.in_channels <= 32:
+            from . import fused                                               # dim -> 1 at full resolution: direct HIP kernel
+            if self._final_f32[0] != x.device:
+                self._final_f32 = (x.device, c.weight.detach().float().contiguous().to(x.device), self._final_f32[2])
+            return fused.conv3x3_to1(x, self._final_f32[1], self._final_f32[2])
+        return c(x)
 
 
 AE = AEViT      # predict.py:12 `from networks import AEViT as AE`

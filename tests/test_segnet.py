@@ -148,6 +148,28 @@ def test_bias_act_and_biased_upsample_vs_torch(dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_single_channel_convs_vs_torch(dtype):
+    from ppnet_amd import fused
+    dt = getattr(torch, dtype)
+    torch.manual_seed(5)
+    tol = 2e-5 if dt == torch.float32 else 3e-2
+    for C, H, W in ((24, 37, 50), (8, 16, 16), (32, 5, 70)):
+        x1 = (torch.rand(3, 1, H, W, device="cuda") > 0.5).to(dt)
+        w = torch.randn(C, 1, 3, 3, device="cuda") * 0.3
+        b = torch.randn(C, device="cuda")
+        ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x1.float(), w, b, 1, 1), 0.01)
+        got = fused.conv3x3_c1(x1, w.contiguous(), b.contiguous(), 0.01)
+        assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+        assert (got.float() - ref).abs().max() < tol
+        xc = torch.randn(3, C, H, W, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+        w1 = torch.randn(1, C, 3, 3, device="cuda") * 0.2
+        ref1 = torch.nn.functional.conv2d(xc.float(), w1, torch.tensor([0.37], device="cuda"), 1, 1)
+        got1 = fused.conv3x3_to1(xc, w1.contiguous(), 0.37)
+        assert got1.shape == ref1.shape and (got1.float() - ref1).abs().max() < tol * max(1.0, float(ref1.abs().max()))
+
+
+@pytest.mark.gpu
 def test_dinat_base_end_to_end_256():
     from ppnet_amd.segnet import SegNet, normalize_images
     torch.manual_seed(0)
