@@ -83,14 +83,14 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const T* __restrict__ x
 }
 
 // y[b][i][j] = bias + sum_{di,dj,ci} w[0][ci][di][dj] * x[b][i+di-1][j+dj-1][ci], zero padding.  A 16 x 16 tile of outputs
-// per workgroup, its 18 x 18 x Cin halo staged in LDS as float (entry pitch Cin + 1 keeps the 16 lanes of a row on
-// different banks), weights in LDS as [tap][ci].
+// per workgroup, its 18 x 18 x Cin halo staged in LDS as float (entry pitch Cin + 4 floats: 16-byte aligned, and the 16
+// lanes of a tile row then start their ds_read_b128 on 16 different banks), weights in LDS as [tap][ci].
 template <typename T, int CG>
 __global__ __launch_bounds__(256) void conv3x3_to1_kernel(const T* __restrict__ x, const float* __restrict__ w, float bias,
                                                           T* __restrict__ y, int B, int H, int W) {
-    constexpr int C = CG * 8, PITCH = C + 1, HT = 18;
-    __shared__ float tile[HT * HT * PITCH];
-    __shared__ float ws[9][C];
+    constexpr int C = CG * 8, PITCH = C + 4, HT = 18;
+    __shared__ __attribute__((aligned(16))) float tile[HT * HT * PITCH];
+    __shared__ __attribute__((aligned(16))) float ws[9][C];
     for (int t = threadIdx.x; t < 9 * C; t += 256) { const int ci = t / 9, tap = t - ci * 9; ws[tap][ci] = w[t]; }
     const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
     const int b = blockIdx.x / (tiles_x * tiles_y), tt = blockIdx.x - b * tiles_x * tiles_y;
@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void conv3x3_to1_kernel(const T* __restrict__ 
         const int ii = i0 + hi - 1, jj = j0 + hj - 1;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (ii >= 0 && ii < H && jj >= 0 && jj < W) load8<T>(xb + ((long long)ii * W + jj) * C + g * 8, v);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) tile[e * PITCH + g * 8 + k] = v[k];
+        *reinterpret_cast<float4*>(tile + e * PITCH + g * 8) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(tile + e * PITCH + g * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
     }
     __syncthreads();
     const int ti = threadIdx.x / 16, tj = threadIdx.x % 16;
@@ -114,9 +114,13 @@ __global__ __launch_bounds__(256) void conv3x3_to1_kernel(const T* __restrict__ 
     for (int di = 0; di < 3; ++di)
 #pragma unroll
         for (int dj = 0; dj < 3; ++dj) {
-            const float* e = tile + ((ti + di) * HT + tj + dj) * PITCH;
+            const float4* e = reinterpret_cast<const float4*>(tile + ((ti + di) * HT + tj + dj) * PITCH);
+            const float4* wv = reinterpret_cast<const float4*>(ws[di * 3 + dj]);
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc = fmaf(ws[di * 3 + dj][c], e[c], acc);
+            for (int c4 = 0; c4 < C / 4; ++c4) {
+                const float4 a = e[c4], b4 = wv[c4];
+                acc = fmaf(b4.x, a.x, acc); acc = fmaf(b4.y, a.y, acc); acc = fmaf(b4.z, a.z, acc); acc = fmaf(b4.w, a.w, acc);
+            }
         }
     T* out = y + ((long long)b * H + i) * W + j;
     if constexpr (sizeof(T) == 2) *out = __float2bfloat16(acc); else *out = acc;
