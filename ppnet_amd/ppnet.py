@@ -29,7 +29,8 @@ def _use_tuned_gemms():
             tn.set_filename(retune or os.path.join(tempfile.gettempdir(), f"ppnet_amd_tunableop_{os.getpid()}.csv"))
             tn.read_file(_TUNED)
     except Exception as e:                                   # an optional speed-up must never break inference
-        print(f"ppnet_amd: tuned GEMM table not used ({e})")
+        import sys
+        print(f"ppnet_amd: tuned GEMM table not used ({e})", file=sys.stderr)
 
 
 class PPNet(torch.nn.Module):
