@@ -1,4 +1,4 @@
-// edage_maps.hip — stage B of EDaGe-PP on gfx950: one 256-thread workgroup per map instance.
+// edage_maps.hip — stage B of EDaGe-PP on gfx950: one 128-thread workgroup per map instance.
 //
 // Replaces, per map (paths relative to the reference's EDaGe-PP/):
 //   the placement rejection loop + label transforms        MapGenerate.py:57-93
@@ -29,8 +29,13 @@ __device__ unsigned long long g_phase_cycles[16];
 #define PPN_STAMP_INIT do {} while (0)
 #endif
 
+// Two waves per map: the placement is one wave's work, and with four waves three of them idled through it (measured 0.204 ->
+// 0.198 ms per bench step; 22 waves per CU, LDS-limited, against 28 before).
+#ifndef PPN_MAPS_THREADS
+#define PPN_MAPS_THREADS 128
+#endif
 #ifndef PPN_MAPS_WAVES_PER_EU
-#define PPN_MAPS_WAVES_PER_EU 7   // register budget of the stage-B kernel: waves per SIMD it must allow (7 -> <= 72 VGPRs)
+#define PPN_MAPS_WAVES_PER_EU 6   // register budget of the stage-B kernel: waves per SIMD it must allow (6 -> <= 80 VGPRs, no spills)
 #endif
 
 namespace {
@@ -67,7 +72,8 @@ __device__ __forceinline__ uint32_t expand4(uint32_t b) {
 // labels, clearance filter: every output but `grid`) and PHASE 2 (obstacle lists -> `grid`, reading what PHASE 1 left in
 // global memory) are the same code as two launches (ppn_edage_maps_place / _raster).
 template <int PHASE>
-__global__ __launch_bounds__(NT, PPN_MAPS_WAVES_PER_EU) void edage_maps_kernel_t(MapsParams prm) {
+__global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage_maps_kernel_t(MapsParams prm) {
+    constexpr int NT = PPN_MAPS_THREADS, NW = NT / 64;                       // shadow the file-level 256 / 4 of the helper kernels
     // dynamic LDS carve (all 8-byte aligned):
     //   occw  [R*R/32] u32  the R*R-bit occupancy mask                                 (PHASE&2)
     //   cand  [K][3] f64    candidates (row, col, r)                                   (PHASE&1)
@@ -322,7 +328,10 @@ __global__ __launch_bounds__(NT, PPN_MAPS_WAVES_PER_EU) void edage_maps_kernel_t
                 if (wv == 0) {
                     rk = valid ? cand[k][2] : 0.0;
                     thr = rk + c_px;
-                    const double dc = (double)sqrtf(fminf(fminf(fmin_w[0][lane], fmin_w[1][lane]), fminf(fmin_w[2][lane], fmin_w[3][lane])));
+                    float mfw = fmin_w[0][lane];
+#pragma unroll
+                    for (int w = 1; w < NW; ++w) mfw = fminf(mfw, fmin_w[w][lane]);
+                    const double dc = (double)sqrtf(mfw);
                     const bool sure_rej = dc + 0.01 <= thr;                   // true minimum <= coarse minimum
                     lb = dc - slack;                                          // true minimum >= lb
                     sure_acc = lb > thr;
@@ -423,10 +432,12 @@ __global__ __launch_bounds__(NT, PPN_MAPS_WAVES_PER_EU) void edage_maps_kernel_t
     if constexpr (PHASE & 2) {
         for (int w = tid; w < words; w += NT) occw[w] = 0u;
         {   // byte-expansion table: bit k set (= occupied) -> byte k 0x00, clear -> 0xFF
-            uint64_t v = 0ull;
+            for (int e = tid; e < 256; e += NT) {
+                uint64_t v = 0ull;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v |= ((tid >> k) & 1) ? 0ull : (0xFFull << (8 * k));
-            lut[tid] = v;
+                for (int k = 0; k < 8; ++k) v |= ((e >> k) & 1) ? 0ull : (0xFFull << (8 * k));
+                lut[e] = v;
+            }
         }
         int* row_lo = reinterpret_cast<int*>(poddf);                       // the float points are dead after the filter
         int* row_off = row_lo + (K + PPN_MAX_POCKET);                      // [n_obs + 1] exclusive offsets (2*(K+64)+1 ints <= 641)
@@ -587,7 +598,7 @@ static int launch_phase(const MapsParams& prm, hipStream_t stream) {
                        maps_tab_bytes(K) + 256 * 8;
     if (hipFuncSetAttribute((const void*)edage_maps_kernel_t<PHASE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PPN_E_HIP;
-    hipLaunchKernelGGL(edage_maps_kernel_t<PHASE>, dim3((unsigned)prm.n_maps), dim3(NT), lds, stream, prm);
+    hipLaunchKernelGGL(edage_maps_kernel_t<PHASE>, dim3((unsigned)prm.n_maps), dim3(PPN_MAPS_THREADS), lds, stream, prm);
     return hipGetLastError() == hipSuccess ? PPN_OK : PPN_E_HIP;
 }
 
