@@ -46,9 +46,10 @@ constexpr double PI = 3.141592653589793;
 constexpr int NCOARSE = PPN_PATH_POINTS / 8 + 1;   // coarse points of the clearance filter: odd points 0, 4, .., 496 and 499
 }
 
+constexpr int MAPS_SCRATCH = (PPN_MAPS_THREADS / 64) * 256 + 512;        // filter scratch: fmin_w [waves][64] f32 + dref [64] f64
 // bytes of the first dynamic-LDS region: the occupancy bit mask (phase 2)
 __host__ __device__ constexpr int maps_region_bytes(int phase, int R) {
-    return (phase & 2) ? R * R / 8 : 0;
+    return (phase & 2) ? (R * R / 8 > MAPS_SCRATCH ? R * R / 8 : MAPS_SCRATCH) : 0;   // fused: the filter scratch lives here first
 }
 
 // bytes of the region that holds the filter's coarse float points, then the raster's row tables (2*(K+64)+1 ints)
@@ -56,6 +57,20 @@ __host__ __device__ constexpr int maps_tab_bytes(int K) {
     const int rows = ((2 * (K + PPN_MAX_POCKET) + 1) * 4 + 7) & ~7;
     return rows > 1024 ? rows : 1024;
 }
+
+// 8 occupancy bits -> 8 grid bytes: bit k set (= occupied) -> byte k 0x00, clear -> 0xFF.  Read-only device table (2 KB, L1 /
+// L2 resident): keeping it out of LDS leaves room for one more workgroup per CU.
+struct ByteLut {
+    uint64_t v[256];
+    constexpr ByteLut() : v() {
+        for (int e = 0; e < 256; ++e) {
+            uint64_t x = 0;
+            for (int k = 0; k < 8; ++k) x |= ((e >> k) & 1) ? 0ull : (0xFFull << (8 * k));
+            v[e] = x;
+        }
+    }
+};
+__device__ const ByteLut g_byte_lut{};
 
 // exact predicate of the obstacle raster rule for pixel column j of a row at squared row offset dy2
 __device__ __forceinline__ bool disc_pred(int j, double cx, double dy2, double rr) {
@@ -80,7 +95,7 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
     //   obs   [K+64][3] f64 kept + pocket obstacles (col, row, r)
     //   poddf [2][128] f32  float copy of the 126 coarse odd points as planes x | y (filter
     //                       pre-pass); afterwards the raster's row tables
-    //   lut   [256] u64     8 occupancy bits -> 8 grid bytes (PHASE&2); during the filter its bytes hold fmin_w and dref
+    //   (PHASE 1 only) 1.5 KB of filter scratch (fmin_w, dref); fused, the filter borrows the occupancy mask's bytes
     extern __shared__ uint64_t lds_raw[];
     __shared__ double bc[12];
     __shared__ int bci[16];                       // [0..3] placement, [4] kept count, [12] corridor-touch flag
@@ -111,11 +126,12 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
     double (*cand)[3] = reinterpret_cast<double (*)[3]>(lds + regionP_bytes);
     double (*obs)[3] = reinterpret_cast<double (*)[3]>(lds + regionP_bytes + cand_bytes);
     float* poddf = reinterpret_cast<float*>(lds + regionP_bytes + cand_bytes + (size_t)(K + PPN_MAX_POCKET) * 24);
-    uint64_t* lut = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(poddf) + maps_tab_bytes(K));
+    const uint64_t* lut = g_byte_lut.v;
+    unsigned char* scratch = (PHASE & 2) ? lds : reinterpret_cast<unsigned char*>(poddf) + maps_tab_bytes(K);   // filter scratch: the occupancy mask's bytes when fused
     // regions that are dead when their second tenant arrives (barriers lie between):
     double (*hullc)[2] = reinterpret_cast<double (*)[2]>(poddf);          // hull - R/2 [64][2]: placement only, before the labels write poddf
-    float (*fmin_w)[64] = reinterpret_cast<float (*)[64]>(lut);           // [NW][64] per-wave partial minima (squared, float) of the filter
-    double* dref = reinterpret_cast<double*>(lut) + 128;                  // [64] exact minima of the obstacles the coarse filter left undecided
+    float (*fmin_w)[64] = reinterpret_cast<float (*)[64]>(scratch);       // [NW][64] per-wave partial minima (squared, float) of the filter
+    double* dref = reinterpret_cast<double*>(scratch + NW * 256);         // [64] exact minima of the obstacles the coarse filter left undecided
     (void)mid; (void)pimg; (void)occw; (void)cand; (void)hullc; (void)bci; (void)fmin_w; (void)dref; (void)lane; (void)wv; (void)words;
     PPN_STAMP_INIT;
 
@@ -431,14 +447,6 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
 
     if constexpr (PHASE & 2) {
         for (int w = tid; w < words; w += NT) occw[w] = 0u;
-        {   // byte-expansion table: bit k set (= occupied) -> byte k 0x00, clear -> 0xFF
-            for (int e = tid; e < 256; e += NT) {
-                uint64_t v = 0ull;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v |= ((e >> k) & 1) ? 0ull : (0xFFull << (8 * k));
-                lut[e] = v;
-            }
-        }
         int* row_lo = reinterpret_cast<int*>(poddf);                       // the float points are dead after the filter
         int* row_off = row_lo + (K + PPN_MAX_POCKET);                      // [n_obs + 1] exclusive offsets (2*(K+64)+1 ints <= 641)
         __syncthreads();
@@ -595,7 +603,7 @@ template <int PHASE>
 static int launch_phase(const MapsParams& prm, hipStream_t stream) {
     const int R = prm.R, K = prm.K;
     const size_t lds = (size_t)maps_region_bytes(PHASE, R) + ((PHASE & 1) ? (size_t)K * 24 : 0) + (size_t)(K + PPN_MAX_POCKET) * 24 +
-                       maps_tab_bytes(K) + 256 * 8;
+                       maps_tab_bytes(K) + ((PHASE & 2) ? 0 : MAPS_SCRATCH);
     if (hipFuncSetAttribute((const void*)edage_maps_kernel_t<PHASE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PPN_E_HIP;
     hipLaunchKernelGGL(edage_maps_kernel_t<PHASE>, dim3((unsigned)prm.n_maps), dim3(PPN_MAPS_THREADS), lds, stream, prm);
