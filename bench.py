@@ -150,7 +150,7 @@ def main():
     # per path, ~0.19 ms for 100 paths) that leaves most of the chip idle, so it runs DEPTH batches ahead of stage B on
     # its own HIP streams: while stage B of batch i writes its maps, stage A of batches i+1 .. i+DEPTH is in flight.
     # DEPTH+1 path buffers, events for the hand-off.  Every step launches exactly one stage-A and one stage-B kernel.
-    DEPTH = 2
+    DEPTH = int(os.environ.get("BENCH_DEPTH", "2"))
     TIMED_EVERY = 4
     NPB = DEPTH + 1
     pbs = [edage.PathsBatch(PATHS, R, MAP_SIZE, CLEARANCE, dev) for _ in range(NPB)]
