@@ -244,6 +244,11 @@ int ppn_na2d_fwd_vpad(const void* qkv, const void* pad_kv, const float* rpb, voi
  * same dtype (0 = float32, 1 = bfloat16; statistics in float32). x_out may alias x. */
 int ppn_residual_layernorm(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out,
                            void* y_out, int64_t rows, int32_t C, float eps, int32_t dtype, void* stream);
+/* y_out = LayerNorm(x + xoff) with a per-channel float32 offset xoff [C] (NULL = none; float32 whatever dtype x has): for a residual stream whose constant
+ * (bias) part is carried outside the tensor — the projections then accumulate straight into x through the GEMM's
+ * beta * C term and the residual add needs no pass of its own. */
+int ppn_layernorm_offset(const void* x, const float* xoff, const void* w, const void* b, void* y_out, int64_t rows,
+                         int32_t C, float eps, int32_t dtype, void* stream);
 /* Same, with y_out scattered into a zero-padded token grid: rows = B*Hr*Wr tokens in [B][Hr][Wr] order are written to
  * y_out laid out [B][Hp][Wp][C] (the pad region is left untouched: the caller zero-fills it once). */
 int ppn_residual_layernorm_padded(const void* x, const void* a, const void* gamma, const void* w, const void* b,

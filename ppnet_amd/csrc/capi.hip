@@ -333,7 +333,17 @@ int ppn_residual_layernorm_padded(const void* x, const void* a, const void* gamm
     if (!a && !y_out) return PPN_E_INVALID;
     if (y_out && (!w || !b)) return PPN_E_INVALID;
     if (rows == 0) return PPN_OK;
-    const int e = ppn::norm_launch(x, a, gamma, w, b, x_out, y_out, rows, C, eps, dtype, Hr, Wr, Hp, Wp, (hipStream_t)stream);
+    const int e = ppn::norm_launch(x, a, gamma, w, b, x_out, y_out, rows, C, eps, dtype, Hr, Wr, Hp, Wp, nullptr, (hipStream_t)stream);
+    if (e == -1) return PPN_E_UNSUPPORTED;
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
+int ppn_layernorm_offset(const void* x, const float* xoff, const void* w, const void* b, void* y_out, int64_t rows, int32_t C, float eps,
+                         int32_t dtype, void* stream) {
+    if (!x || !y_out || !w || !b || rows < 0 || C <= 0 || (C % 8) != 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
+    if (rows == 0) return PPN_OK;
+    const int e = ppn::norm_launch(x, nullptr, nullptr, w, b, nullptr, y_out, rows, C, eps, dtype, 0, 0, 0, 0, xoff, (hipStream_t)stream);
     if (e == -1) return PPN_E_UNSUPPORTED;
     if (e != 0) return hip_fail((hipError_t)e);
     return PPN_OK;

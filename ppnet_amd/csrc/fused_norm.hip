@@ -57,7 +57,7 @@ template <typename T, int PASSES, bool RESID>
 __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ gamma,
                                                    const T* __restrict__ w, const T* __restrict__ b, T* __restrict__ x_out,
                                                    T* __restrict__ y_out, long long rows, int C, int lpr, float eps,
-                                                   int Hr, int Wr, int Hp, int Wp) {
+                                                   int Hr, int Wr, int Hp, int Wp, const float* __restrict__ xoff) {
     const int lane = threadIdx.x & 63;
     const int rows_per_wave = 64 / lpr;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -70,6 +70,12 @@ __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, cons
         const int c0 = (p * lpr + li) * 8;
         if (live) {
             Vec8<T>::load(x + row * C + c0, v[p]);
+            if (xoff) {                                                      // y = LN(x + xoff): a per-channel float32 offset carried outside x
+                float ov[8];
+                Vec8<float>::load(xoff + c0, ov);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[p][k] += ov[k];
+            }
             if (RESID) {
                 float av[8];
                 Vec8<T>::load(a + row * C + c0, av);
@@ -182,7 +188,7 @@ int upsample2x_launch(const void* x, const void* bias, void* y, int B, int H, in
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void norm_rows_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ gamma,
                                                         const T* __restrict__ w, const T* __restrict__ b, T* __restrict__ x_out,
-                                                        T* __restrict__ y_out, long long rows, float eps) {
+                                                        T* __restrict__ y_out, long long rows, float eps, const float* __restrict__ xoff) {
     constexpr int C = NV * 8;
     const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
     if (row >= rows) return;
@@ -190,6 +196,12 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
         Vec8<T>::load(x + row * C + p * 8, v[p]);
+        if (xoff) {
+            float ov[8];
+            Vec8<float>::load(xoff + p * 8, ov);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[p][k] += ov[k];
+        }
         if (a) {
             float av[8];
             Vec8<T>::load(a + row * C + p * 8, av);
@@ -261,11 +273,11 @@ int bias_act_launch(void* x, const void* bias, long long n, int C, float slope, 
 
 template <typename T>
 static int launch_norm(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,
-                       long long rows, int C, float eps, int Hr, int Wr, int Hp, int Wp, hipStream_t stream) {
+                       long long rows, int C, float eps, int Hr, int Wr, int Hp, int Wp, const void* xoff, hipStream_t stream) {
     if (C <= 64 && C % 8 == 0 && !Hp) {                                      // narrow rows: one thread per row
         const dim3 g((unsigned)((rows + 255) / 256));
 #define PPN_ROWS(NV) hipLaunchKernelGGL((norm_rows_kernel<T, NV>), g, dim3(256), 0, stream, (const T*)x, (const T*)a, (const T*)gamma, \
-    (const T*)w, (const T*)b, (T*)x_out, (T*)y_out, rows, eps)
+    (const T*)w, (const T*)b, (T*)x_out, (T*)y_out, rows, eps, (const float*)xoff)
         switch (C / 8) {
             case 1: PPN_ROWS(1); break; case 2: PPN_ROWS(2); break; case 3: PPN_ROWS(3); break; case 4: PPN_ROWS(4); break;
             case 5: PPN_ROWS(5); break; case 6: PPN_ROWS(6); break; case 7: PPN_ROWS(7); break; default: PPN_ROWS(8); break;
@@ -280,7 +292,7 @@ static int launch_norm(const void* x, const void* a, const void* gamma, const vo
     const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
     const bool resid = a != nullptr;
 #define PPN_NORM_LAUNCH(P, R) hipLaunchKernelGGL((norm_kernel<T, P, R>), grid, dim3(256), 0, stream, (const T*)x, (const T*)a, \
-    (const T*)gamma, (const T*)w, (const T*)b, (T*)x_out, (T*)y_out, rows, C, lpr, eps, Hr, Wr, Hp, Wp)
+    (const T*)gamma, (const T*)w, (const T*)b, (T*)x_out, (T*)y_out, rows, C, lpr, eps, Hr, Wr, Hp, Wp, (const float*)xoff)
     if (passes == 1) { if (resid) PPN_NORM_LAUNCH(1, true); else PPN_NORM_LAUNCH(1, false); }
     else { if (resid) PPN_NORM_LAUNCH(2, true); else PPN_NORM_LAUNCH(2, false); }
 #undef PPN_NORM_LAUNCH
@@ -288,9 +300,9 @@ static int launch_norm(const void* x, const void* a, const void* gamma, const vo
 }
 
 int norm_launch(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,
-                long long rows, int C, float eps, int dtype, int Hr, int Wr, int Hp, int Wp, hipStream_t stream) {
-    return dtype == 0 ? launch_norm<float>(x, a, gamma, w, b, x_out, y_out, rows, C, eps, Hr, Wr, Hp, Wp, stream)
-                      : launch_norm<__hip_bfloat16>(x, a, gamma, w, b, x_out, y_out, rows, C, eps, Hr, Wr, Hp, Wp, stream);
+                long long rows, int C, float eps, int dtype, int Hr, int Wr, int Hp, int Wp, const void* xoff, hipStream_t stream) {
+    return dtype == 0 ? launch_norm<float>(x, a, gamma, w, b, x_out, y_out, rows, C, eps, Hr, Wr, Hp, Wp, xoff, stream)
+                      : launch_norm<__hip_bfloat16>(x, a, gamma, w, b, x_out, y_out, rows, C, eps, Hr, Wr, Hp, Wp, xoff, stream);
 }
 
 }  // namespace ppn

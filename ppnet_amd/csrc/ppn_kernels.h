@@ -64,7 +64,7 @@ int na2d_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out
                 float scale, int dtype, hipStream_t stream);
 
 int norm_launch(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,
-                long long rows, int C, float eps, int dtype, int Hr, int Wr, int Hp, int Wp, hipStream_t stream);
+                long long rows, int C, float eps, int dtype, int Hr, int Wr, int Hp, int Wp, const void* xoff, hipStream_t stream);
 
 int upsample2x_launch(const void* x, const void* bias, void* y, int B, int H, int W, int C, int relu, int dtype, hipStream_t stream);
 int conv3x3_c1_launch(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cout, float slope, int dtype,

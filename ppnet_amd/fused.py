@@ -52,10 +52,23 @@ def _y_for(x, pad_to):
     return _padded_buffer(B, pad_to[0], pad_to[1], C, x.dtype, x.device), (Hr, Wr, pad_to[0], pad_to[1])
 
 
-def layer_norm(x, ln, pad_to=None):
+def layer_norm(x, ln, pad_to=None, offset=None):
     """y = ln(x) for a torch.nn.LayerNorm over the last dimension. pad_to=(Hp,Wp): x is [B,H,W,C] and y is the
-    zero-padded (bottom/right) [B,Hp,Wp,C] grid the next neighbourhood attention wants."""
+    zero-padded (bottom/right) [B,Hp,Wp,C] grid the next neighbourhood attention wants.  offset [C]: y = ln(x + offset)
+    (a residual stream whose constant part is carried outside the tensor, ppn_layernorm_offset)."""
     x = x.contiguous()
+    if offset is not None:
+        assert pad_to is None
+        C = x.shape[-1]
+        y = torch.empty_like(x)
+        w, b = ln.weight.detach().to(x.dtype), ln.bias.detach().to(x.dtype)
+        off = offset
+        assert off.dtype == torch.float32 and off.is_contiguous() and off.device == x.device
+        with torch.cuda.device(x.device):
+            rc = L.lib.ppn_layernorm_offset(_p(x), _p(off), _p(w), _p(b), _p(y), x.numel() // C, C, float(ln.eps), _DT[x.dtype],
+                                            ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        L.check(rc, "ppn_layernorm_offset")
+        return y
     y, pad = _y_for(x, pad_to)
     _call(x, None, None, ln, None, y, pad)
     return y

@@ -85,6 +85,10 @@ class NeighborhoodAttention2D(nn.Module):
         if real_hw is not None:
             o = na2d_forward(self.qkv(x), self.rpb, self.num_heads, self.dilation, self.scale, real_hw)
             return self.proj_drop(self.proj(o))
+        return self.proj_drop(self.proj(self.attend(x)))
+
+    def attend(self, x):
+        """The attention output BEFORE the output projection ([B,H,W,C]) for an unpadded x (padding virtual)."""
         pad = self.padded_hw(x.shape[1], x.shape[2])
         qkv = self.qkv(x)
         if pad is None:
@@ -92,4 +96,4 @@ class NeighborhoodAttention2D(nn.Module):
         else:
             bias = self.qkv.bias if self.qkv.bias is not None else torch.zeros(qkv.shape[-1], dtype=qkv.dtype, device=qkv.device)
             o = na2d_forward(qkv, self.rpb, self.num_heads, self.dilation, self.scale, pad_kv=bias, padded_hw=pad)
-        return self.proj_drop(self.proj(o))
+        return o

@@ -45,6 +45,13 @@ class Mlp(nn.Module):
         self.act = act_layer()
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
 
+    def hidden(self, x):
+        """act(fc1(x)) as a 2-D [tokens, hidden] tensor."""
+        x2 = x.reshape(-1, x.shape[-1])
+        if x.is_cuda and x.dtype == torch.bfloat16 and isinstance(self.act, nn.GELU) and self.act.approximate == "none":
+            return torch._addmm_activation(self.fc1.bias, x2, self.fc1.weight.t(), use_gelu=True)
+        return self.act(self.fc1(x2))
+
     def forward(self, x):
         if x.is_cuda and x.dtype == torch.bfloat16 and isinstance(self.act, nn.GELU) and self.act.approximate == "none":
             # bias + GELU in the projection's epilogue (hipBLASLt): one pass over the hidden activations less.  In bf16 its
@@ -69,18 +76,52 @@ class NATLayer(nn.Module):
             self.gamma1 = nn.Parameter(layer_scale * torch.ones(dim))
             self.gamma2 = nn.Parameter(layer_scale * torch.ones(dim))
 
+    folded = False        # set by NATBlock.fold(): LayerScale in the projection weights, biases carried as offsets
+    _c = _c_dev = None
+
+    def _forward_folded(self, s, y, next_norm):
+        """s: the residual stream minus the level's accumulated projection biases (see _fold_doc); y = norm1(s + c_in)."""
+        C = s.shape[-1]
+        c_in, c_mid, c_out = self.offsets(s.device)
+        if y is None:
+            y = fused.layer_norm(s, self.norm1, offset=c_in)
+        s2 = s.view(-1, C)
+        s2.addmm_(self.attn.attend(y).view(-1, C), self.attn.proj.weight.t())          # s += o W'^T  (bias in c_mid)
+        y2 = fused.layer_norm(s, self.norm2, offset=c_mid)
+        s2.addmm_(self.mlp.hidden(y2), self.mlp.fc2.weight.t())                        # s += h W2'^T (bias in c_out)
+        return s, (fused.layer_norm(s, next_norm, offset=c_out) if next_norm is not None else None)
+
+    def offsets(self, device):
+        """(c_in, c_mid, c_out) as float32 tensors on `device`: plain attributes, not buffers, so that module.to(bfloat16)
+        does not round the accumulated biases."""
+        if self._c_dev is None or self._c_dev[0].device != device:
+            self._c_dev = tuple(t.to(device) for t in self._c)
+        return self._c_dev
+
     def forward(self, x, y=None, next_norm=None, next_pad=None):
         """x: residual stream [B,H,W,C]; y = norm1(x) if the caller already has it. Returns (x', next_norm(x')).
         The attention's zero-padding to kernel*dilation is virtual (na.NeighborhoodAttention2D.forward), so next_pad
         stays None; the argument is kept for a caller that wants the materialised padded grid.
         Residual add, LayerScale and the following LayerNorm are one fused kernel each (DropPath is the identity
         at inference, nat.py:140-153)."""
+        if self.folded:
+            return self._forward_folded(x, y, next_norm)
         hw = (x.shape[1], x.shape[2])
         if y is None:
             y = fused.layer_norm(x, self.norm1)
         real = hw if (y.shape[1], y.shape[2]) != hw else None               # a materialised padded y still works
         x, y2 = fused.residual_layer_norm(x, self.attn(y, real), self.gamma1 if self.layer_scale else None, self.norm2)
         return fused.residual_layer_norm(x, self.mlp(y2), self.gamma2 if self.layer_scale else None, next_norm, next_pad)
+
+
+def _fold_doc():
+    """Folded inference form of a NAT level (SegNet.prepare_inference on the GPU path).  LayerScale is folded into the two
+    output projections (W' = diag(gamma) W, b' = gamma * b), so a sub-layer is x' = x + o W'^T + b'.  The residual stream
+    is kept WITHOUT the constant part: s = x - c, where c is the sum of the b' seen so far in the level (known when the
+    weights are).  Then s' = s + o W'^T is ONE library GEMM accumulating into s (beta = 1: `addmm_`), every LayerNorm is
+    LN(s + c) with c added in registers (ppn_layernorm_offset), and the level's end adds c once for the downsampler.
+    Per sub-layer the activations cross HBM 4 times (GEMM reads s, writes s'; LN reads s', writes y) instead of 5
+    (GEMM writes a; the fused residual+LN kernel reads x and a, writes x' and y)."""
 
 
 class NATBlock(nn.Module):
@@ -106,8 +147,34 @@ class NATBlock(nn.Module):
                 x, y = blk(x, y, self.blocks[i + 1].norm1, None)
             else:
                 x, y = blk(x, y, out_norm, None)
+        if self.blocks[0].folded:                      # x is s = x_true - c: give the true stream back where it is read itself
+            c = self.blocks[-1].offsets(x.device)[2]
+            if self.downsample is not None or out_norm is None:
+                x = fused.bias_act_(x.permute(0, 3, 1, 2), c, 1.0).permute(0, 2, 3, 1)
         xo = y if out_norm is not None else x
         return (x, xo) if self.downsample is None else (self.downsample(x), xo)
+
+    def fold(self):
+        """See _fold_doc.  After the checkpoint is loaded; float32 algebra, then back to the parameters' dtype."""
+        c = None
+        for blk in self.blocks:
+            g1 = blk.gamma1.detach().float() if blk.layer_scale else None
+            g2 = blk.gamma2.detach().float() if blk.layer_scale else None
+            for lin, g in ((blk.attn.proj, g1), (blk.mlp.fc2, g2)):
+                if g is not None:
+                    lin.weight = nn.Parameter((lin.weight.detach().float() * g[:, None]).to(lin.weight.dtype))
+                    lin.bias = nn.Parameter((lin.bias.detach().float() * g).to(lin.bias.dtype))
+            dim = blk.attn.proj.bias.shape[0]
+            zero = torch.zeros(dim, dtype=torch.float32, device=blk.attn.proj.bias.device)
+            c_in = c if c is not None else zero
+            c_mid = c_in + blk.attn.proj.bias.detach().float()
+            c_out = c_mid + blk.mlp.fc2.bias.detach().float()
+            blk._c, blk._c_dev = (c_in.clone().contiguous(), c_mid.clone().contiguous(), c_out.clone().contiguous()), None
+            if blk.layer_scale:
+                blk.gamma1 = nn.Parameter(torch.ones_like(blk.gamma1)); blk.gamma2 = nn.Parameter(torch.ones_like(blk.gamma2))
+            blk.folded = True
+            c = c_out
+        return self
 
 
 class NAT(nn.Module):
@@ -293,6 +360,10 @@ class SegNet(nn.Module):
                 conv.weight = nn.Parameter((conv.weight.detach() * scale.view(-1, 1, 1, 1)))
                 conv.bias = nn.Parameter((bn.bias - bn.running_mean * scale).detach())
                 cm.bn = nn.Identity()
+        import os
+        if not os.environ.get("PPNET_NO_FOLD"):          # A/B knob: keep the fused residual+LayerNorm form
+            for level in self.backbone.levels:
+                level.fold()
         self.to(memory_format=torch.channels_last)
         return self
 

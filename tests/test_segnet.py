@@ -90,6 +90,39 @@ def test_small_nat_gpu_vs_oracle_composition():
 
 
 @pytest.mark.gpu
+def test_folded_levels_equal_unfolded():
+    """NATBlock.fold(): LayerScale in the projection weights, biases carried as a float32 offset, residual adds inside the
+    GEMMs (addmm_) — the same function as the unfolded level, to float32 rounding."""
+    import copy
+    from ppnet_amd.segnet import NAT
+    torch.manual_seed(3)
+    cfg = dict(embed_dim=64, mlp_ratio=2.0, depths=[3, 2], num_heads=[2, 4], kernel_size=7,
+               dilations=[[1, 4, 1], [2, 1]], layer_scale=0.5, out_indices=(0, 1))
+    m = NAT(**cfg).eval()
+    with torch.no_grad():
+        for p in m.parameters():                                  # non-trivial biases and scales everywhere
+            if p.dim() == 1:
+                p.uniform_(-0.5, 0.5)
+        for lvl in m.levels:
+            for blk in lvl.blocks:
+                blk.gamma1.uniform_(0.2, 1.5); blk.gamma2.uniform_(0.2, 1.5)
+    x = torch.randn(2, 3, 64, 64)
+    f = copy.deepcopy(m)
+    for lvl in f.levels:
+        lvl.fold()
+    with torch.no_grad():
+        want = [o.float().cpu() for o in m.cuda()(x.cuda())]
+        got = [o.float().cpu() for o in f.cuda()(x.cuda())]
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and (g - w).abs().max() < 2e-4 * max(1.0, float(w.abs().max()))
+    # bf16: the folded form keeps the offsets in float32 (not rounded by module.to(bfloat16))
+    with torch.no_grad():
+        gb = [o.float().cpu() for o in copy.deepcopy(f).to(torch.bfloat16)(x.cuda().to(torch.bfloat16))]
+    for g, w in zip(gb, want):
+        assert (g - w).abs().max() < 0.15 * max(1.0, float(w.abs().max()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("C,dtype", [(128, "float32"), (256, "bfloat16"), (512, "bfloat16"), (1024, "bfloat16"), (64, "float32"),
                                      (24, "float32"), (24, "bfloat16"), (8, "float32"), (56, "bfloat16")])   # C <= 64: thread-per-row kernel
 def test_fused_residual_layernorm_vs_torch(C, dtype):
