@@ -27,7 +27,8 @@ def na2d_forward(qkv, rpb, heads, dilation, scale, real_hw=None, pad_kv=None, pa
     if dtype is None:
         raise NotImplementedError(f"dtype {qkv.dtype}")
     qkv = qkv.contiguous()
-    rpb = rpb.detach().to(torch.float32).contiguous()
+    if rpb.dtype != torch.float32 or not rpb.is_contiguous():
+        rpb = rpb.detach().to(torch.float32).contiguous()
     stream = ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)
     if pad_kv is not None:
         Hp, Wp = padded_hw
@@ -69,6 +70,7 @@ class NeighborhoodAttention2D(nn.Module):
         # attn_drop / proj_drop are identities at inference; kept for signature compatibility
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj_drop = nn.Dropout(proj_drop)
+        self._rpb32 = None
 
     def padded_hw(self, H, W):
         """Token grid after NATTEN's pad-to-kernel*dilation rule, or None when (H, W) is large enough."""
@@ -87,13 +89,24 @@ class NeighborhoodAttention2D(nn.Module):
             return self.proj_drop(self.proj(o))
         return self.proj_drop(self.proj(self.attend(x)))
 
+    def _rpb_f32(self):
+        """The position bias as the float32 tensor the kernel reads; cached while inference leaves the parameter alone
+        (a bf16 module would otherwise convert it on every call)."""
+        r = self.rpb
+        if r.dtype == torch.float32:
+            return r.detach()
+        key = (r.device, r._version, r.data_ptr())
+        if self._rpb32 is None or self._rpb32[0] != key:
+            self._rpb32 = (key, r.detach().to(torch.float32).contiguous())
+        return self._rpb32[1]
+
     def attend(self, x):
         """The attention output BEFORE the output projection ([B,H,W,C]) for an unpadded x (padding virtual)."""
         pad = self.padded_hw(x.shape[1], x.shape[2])
         qkv = self.qkv(x)
         if pad is None:
-            o = na2d_forward(qkv, self.rpb, self.num_heads, self.dilation, self.scale)
+            o = na2d_forward(qkv, self._rpb_f32(), self.num_heads, self.dilation, self.scale)
         else:
             bias = self.qkv.bias if self.qkv.bias is not None else torch.zeros(qkv.shape[-1], dtype=qkv.dtype, device=qkv.device)
-            o = na2d_forward(qkv, self.rpb, self.num_heads, self.dilation, self.scale, pad_kv=bias, padded_hw=pad)
+            o = na2d_forward(qkv, self._rpb_f32(), self.num_heads, self.dilation, self.scale, pad_kv=bias, padded_hw=pad)
         return o
