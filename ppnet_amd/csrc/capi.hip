@@ -283,8 +283,16 @@ int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const 
     if (!heat || n < 0 || H <= 0 || W <= 0 || !init || !end || max_wp <= 0 || max_wp > PPN_MAX_WAYPOINTS || !wp || !wp_n || !ok)
         return PPN_E_INVALID;
     if (n == 0) return PPN_OK;
-    hipLaunchKernelGGL(ppn::extract_paths_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, heat, n, H, W, init, end,
-                       max_wp, wp, wp_n, ok);
+    // visited bitmap over the lattice offsets (-M .. M per axis, M = max(H, W)); none (history scan) if it would not fit in LDS
+    int vis_dim = 2 * (H > W ? H : W) + 4;
+    size_t lds = (((size_t)vis_dim * vis_dim + 31) / 32) * 4;
+    if (lds > 48 * 1024) { vis_dim = 0; lds = 0; }
+    // the heat map as 8-bit codes behind the bitmap when both fit beside the 8 KB history (values must be k/255: the
+    // caller's ToTensor of an 8-bit image, process_map.py:302); H*W a multiple of 4 for the 16-byte staging loads
+    const int stage_heat = ((size_t)H * W % 4 == 0 && lds + (size_t)H * W <= 52 * 1024 && ((uintptr_t)heat % 16) == 0 && ((size_t)H * W * 4) % 16 == 0) ? 1 : 0;
+    if (stage_heat) lds += (size_t)H * W;
+    hipLaunchKernelGGL(ppn::extract_paths_kernel, dim3(n), dim3(64), lds, (hipStream_t)stream, heat, n, H, W, init, end,
+                       max_wp, wp, wp_n, ok, vis_dim, stage_heat);
     PPN_HIP(hipGetLastError());
     return PPN_OK;
 }

@@ -52,15 +52,37 @@ __global__ __launch_bounds__(256) void collision_segments_kernel(const float* s_
 
 __global__ __launch_bounds__(64) void extract_paths_kernel(const float* heat, int n, int H, int W, const double* init,
                                                            const double* end, int max_wp, double* wp, int32_t* wp_n,
-                                                           uint8_t* ok) {
+                                                           uint8_t* ok, int vis_dim, int stage_heat) {
     __shared__ short hist[PPN_MAX_WAYPOINTS][2];                         // offsets from init, exact small ints
+    // visited[(r + off) * vis_dim + (c + off)]: one bit per lattice offset, set for the points OLDER than the last two — the
+    // revisit rule (process_map.py:327: equal to any earlier point, or within 1.5 px of one that is not among the last two)
+    // is then nine bit tests around the candidate plus two comparisons, instead of a scan of the whole history per step
+    // (the walk is up to max_wp steps long: the scan made the kernel O(n^2)).  vis_dim = 0: no bitmap (very large maps).
+    // stage_heat: the heat map (values k/255 of an 8-bit image) is copied into LDS as its 8-bit codes behind the bitmap — the
+    // walk reads 8 candidates per step, one dependent L2 round trip per step otherwise.  Codes order like the values.
+    extern __shared__ uint32_t visited[];
     const int p = blockIdx.x, lane = threadIdx.x;
     const float* hm = heat + (size_t)p * H * W;
+    uint8_t* hcode = reinterpret_cast<uint8_t*>(visited + (vis_dim * vis_dim + 31) / 32);
+    if (stage_heat) {
+        bool bad = false;                                                 // a value that is not k/255, k in 0..255: keep the float reads
+        for (int q = lane; q < H * W / 4; q += 64) {
+            const float4 f = reinterpret_cast<const float4*>(hm)[q];
+            const float c0 = rintf(f.x * 255.0f), c1 = rintf(f.y * 255.0f), c2 = rintf(f.z * 255.0f), c3 = rintf(f.w * 255.0f);
+            bad = bad || !(c0 / 255.0f == f.x && c1 / 255.0f == f.y && c2 / 255.0f == f.z && c3 / 255.0f == f.w) ||
+                  !(c0 >= 0.0f && c0 <= 255.0f && c1 >= 0.0f && c1 <= 255.0f && c2 >= 0.0f && c2 <= 255.0f && c3 >= 0.0f && c3 <= 255.0f);
+            reinterpret_cast<uint32_t*>(hcode)[q] = (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16) | ((uint32_t)c3 << 24);
+        }
+        if (__ballot(bad) != 0ull) stage_heat = 0;                        // one wave per problem: uniform
+    }
     double* out = wp + (size_t)p * max_wp * 2;
     const double i0 = init[p * 2], i1 = init[p * 2 + 1];
     const double g0 = end[p * 2], g1 = end[p * 2 + 1];
     const int mr[8] = {0, 0, 1, -1, 1, 1, -1, -1};                        // motions, process_map.py:294-297
     const int mc[8] = {1, -1, 0, 0, 1, -1, 1, -1};
+    const int voff = vis_dim / 2;
+    for (int w = lane; w < (vis_dim * vis_dim + 31) / 32; w += 64) visited[w] = 0u;
+    __syncthreads();
     // a waypoint is init + integer offset: keep the offsets exact in int, rebuild doubles on demand
     int cr = 0, cc = 0, cnt = 0, success = 0;
     while (cnt < max_wp) {
@@ -70,7 +92,8 @@ __global__ __launch_bounds__(64) void extract_paths_kernel(const float* heat, in
         if (lane < 8) {
             nr = cr + mr[lane]; nc = cc + mc[lane];
             const int ri = (int)rint(i0 + (double)nr), ci = (int)rint(i1 + (double)nc);
-            if (ri >= 0 && ri < W && ci >= 0 && ci < H) v = hm[(size_t)ri * W + ci];   // :318 (size[0] bounds c[0])
+            if (ri >= 0 && ri < W && ci >= 0 && ci < H)                      // :318 (size[0] bounds c[0])
+                v = stage_heat ? (float)hcode[ri * W + ci] : hm[(size_t)ri * W + ci];
         }
         int chosen = -1;
         while (true) {
@@ -82,28 +105,49 @@ __global__ __launch_bounds__(64) void extract_paths_kernel(const float* heat, in
             }
             if (bi < 0) break;                                            // max(candidate_v) == 0 -> fail
             const int br = __shfl(nr, bi, 64), bcn = __shfl(nc, bi, 64);
-            // revisit test against history[0 .. cnt-3] (process_map.py:327: equal, or <=1.5 px and i < len-2)
             bool rej = false;
-            for (int b = 0; b < cnt; b += 64) {
-                const int q = b + lane;
+            if (vis_dim > 0) {
                 bool r = false;
-                if (q < cnt) {
-                    const int hr = hist[q][0], hc = hist[q][1];
-                    const int dr = hr - br, dc = hc - bcn;
-                    const bool same = (dr == 0 && dc == 0);
-                    const bool nearp = (dr * dr + dc * dc) <= 2;                // lattice distance <= 1.5
-                    r = same || (nearp && q < cnt - 2);
+                if (lane < 9) {                                           // the 3 x 3 cells within lattice distance^2 <= 2
+                    const int rr = br + lane / 3 - 1 + voff, cq = bcn + lane % 3 - 1 + voff;
+                    if (rr >= 0 && rr < vis_dim && cq >= 0 && cq < vis_dim) {
+                        const int bit = rr * vis_dim + cq;
+                        r = (visited[bit >> 5] >> (bit & 31)) & 1u;
+                    }
+                } else if (lane < 11) {                                   // equality with the last two points
+                    const int q = cnt - 1 - (lane - 9);
+                    if (q >= 0) r = hist[q][0] == br && hist[q][1] == bcn;
                 }
-                if (__ballot(r) != 0ull) { rej = true; break; }
+                rej = __ballot(r) != 0ull;
+            } else {
+                // revisit test against history[0 .. cnt-3] by scan (process_map.py:327: equal, or <=1.5 px and i < len-2)
+                for (int b = 0; b < cnt; b += 64) {
+                    const int q = b + lane;
+                    bool r = false;
+                    if (q < cnt) {
+                        const int hr = hist[q][0], hc = hist[q][1];
+                        const int dr = hr - br, dc = hc - bcn;
+                        const bool same = (dr == 0 && dc == 0);
+                        const bool nearp = (dr * dr + dc * dc) <= 2;            // lattice distance <= 1.5
+                        r = same || (nearp && q < cnt - 2);
+                    }
+                    if (__ballot(r) != 0ull) { rej = true; break; }
+                }
             }
             if (!rej) { chosen = bi; break; }
             if (lane == bi) v = 0.0f;                                      // candidate_v[candidate_i] = 0
         }
         if (chosen < 0) break;
         cr = __shfl(nr, chosen, 64); cc = __shfl(nc, chosen, 64);
-        if (lane == 0) { hist[cnt][0] = (short)cr; hist[cnt][1] = (short)cc; }
+        if (lane == 0) {
+            hist[cnt][0] = (short)cr; hist[cnt][1] = (short)cc;
+            if (vis_dim > 0 && cnt >= 2) {                                // the point that now drops out of "the last two"
+                const int bit = (hist[cnt - 2][0] + voff) * vis_dim + hist[cnt - 2][1] + voff;
+                visited[bit >> 5] |= 1u << (bit & 31);
+            }
+        }
         ++cnt;
-        __syncthreads();                                                  // single wave: orders the LDS store
+        __syncthreads();                                                  // single wave: orders the LDS stores
         const double d0 = (i0 + (double)cr) - g0, d1 = (i1 + (double)cc) - g1;
         if (sqrt(d0 * d0 + d1 * d1) <= 2.5) { success = 1; break; }       // :346
     }

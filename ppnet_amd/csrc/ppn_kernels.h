@@ -53,7 +53,7 @@ __global__ void collision_segments_kernel(const float* s, const float* e, const 
                                           const float* obs, const int32_t* obs_off, float clearance,
                                           uint8_t* hit);
 __global__ void extract_paths_kernel(const float* heat, int n, int H, int W, const double* init,
-                                     const double* end, int max_wp, double* wp, int32_t* wp_n, uint8_t* ok);
+                                     const double* end, int max_wp, double* wp, int32_t* wp_n, uint8_t* ok, int vis_dim, int stage_heat);
 
 __global__ void resize_pass_kernel(const uint8_t* in, int n, int inH, int inW, int outH, int outW, int horizontal,
                                    uint8_t* out);
