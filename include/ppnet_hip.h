@@ -213,7 +213,9 @@ int ppn_collision_segments(const float* s, const float* e, const int32_t* prob, 
 
 /* extract_path (process_map.py:293-365) on n heat maps `heat` [n][H][W] float32 already
  * down-sampled; init/end [n][2] doubles in down-sampled coordinates.  wp [n][max_wp][2] doubles,
- * wp_n[n], ok[n].  The 1 s wall-clock timeout becomes the max_wp step cap (<= PPN_MAX_WAYPOINTS). */
+ * wp_n[n], ok[n].  The 1 s wall-clock timeout becomes the max_wp step cap (<= PPN_MAX_WAYPOINTS).  One wave per problem;
+ * the revisit rule runs on a bitmap of visited lattice offsets, and a heat map whose values are exactly k/255 is walked
+ * from its 8-bit codes in LDS (any other values: from the float map in memory) — same waypoints either way. */
 int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const double* init,
                       const double* end, int32_t max_wp, double* wp, int32_t* wp_n, uint8_t* ok,
                       void* stream);
