@@ -267,6 +267,11 @@ int ppn_upsample2x_nhwc(const void* x, void* y, int32_t B, int32_t H, int32_t W,
  * folded) bias and its separate add pass (mmcv ConvModule conv -> bn -> ReLU -> Upsample, setr_up_head.py:56-66). */
 int ppn_upsample2x_nhwc_bias(const void* x, const void* bias, void* y, int32_t B, int32_t H, int32_t W, int32_t C,
                              int32_t relu, int32_t dtype, void* stream);
+/* The segmentor's output tail for two classes (setr_up_head.py:78-80, encoder_decoder.py:76-79,242,257): logits [B][2][h][w]
+ * (NCHW) -> bilinear x2 -> bilinear to [Ho][Wo] (both align_corners=False, each rounded to the logits' dtype as the
+ * materialised tensors are) -> float32 softmax -> argmax, labels u8 [B][Ho][Wo] in {0,1}. */
+int ppn_seg_labels_2class(const void* logits, uint8_t* labels, int32_t B, int32_t h, int32_t w, int32_t Ho, int32_t Wo,
+                          int32_t dtype, void* stream);
 /* In place x = leaky_relu(x + bias[c], negative_slope) on n elements of an NHWC tensor with C channels (C % 8 == 0;
  * slope 0 = ReLU, 1 = bias only): bias + BatchNorm(folded) + LeakyReLU of GenNet's conv stages (ae_vit.py:17-55) as
  * one pass behind a bias-free library convolution. */

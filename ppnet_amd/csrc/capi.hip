@@ -370,6 +370,14 @@ int ppn_upsample2x_nhwc_bias(const void* x, const void* bias, void* y, int32_t B
     return PPN_OK;
 }
 
+int ppn_seg_labels_2class(const void* logits, uint8_t* labels, int32_t B, int32_t h, int32_t w, int32_t Ho, int32_t Wo, int32_t dtype,
+                          void* stream) {
+    if (!logits || !labels || B <= 0 || h <= 0 || w <= 0 || Ho <= 0 || Wo <= 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
+    const int e = ppn::seg_labels_launch(logits, labels, B, h, w, Ho, Wo, dtype, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_bias_act_nhwc(void* x, const void* bias, int64_t n, int32_t C, float negative_slope, int32_t dtype, void* stream) {
     if (!x || !bias || n < 0 || C <= 0 || (C % 8) != 0 || (n % C) != 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
     if (n == 0) return PPN_OK;

@@ -271,6 +271,65 @@ int bias_act_launch(void* x, const void* bias, long long n, int C, float slope, 
     return (int)hipGetLastError();
 }
 
+// SegNet's output tail for two classes in one kernel (setr_up_head.py:78-80 Upsample x2 of the logits, encoder_decoder.py:76-79
+// resize to the input size, :242,257 softmax + argmax): lo [B][2][h][w] -> bilinear to [2h][2w] (rounded to T, as the
+// materialised tensor would be) -> bilinear to [Ho][Wo] (rounded to T) -> float32 softmax over the two classes -> label.
+// One thread per output pixel; the 16 low-resolution taps per class come from L1/L2 (the logits are a few MB).
+template <typename T>
+__device__ __forceinline__ float round_to(float v) {
+    if constexpr (sizeof(T) == 2) { const uint32_t u = Vec8<__hip_bfloat16>::pack(v, 0.0f); return __uint_as_float(u << 16); }
+    return v;
+}
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+
+__device__ __forceinline__ void bil_src(int dst, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+    const float s = fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.0f);        // area_pixel_compute_source_index, align_corners=False
+    i0 = (int)s;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = s - (float)i0; l0 = 1.0f - l1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void seg_labels_kernel(const T* __restrict__ lo, uint8_t* __restrict__ labels, int B, int h, int w, int Ho,
+                                                         int Wo) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * Ho * Wo) return;
+    const int ox = (int)(idx % Wo), oy = (int)((idx / Wo) % Ho), b = (int)(idx / ((long long)Wo * Ho));
+    const int hm = 2 * h, wm = 2 * w;                                       // the head's x2 stage
+    int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+    bil_src(oy, (float)hm / (float)Ho, hm, y0, y1, ly0, ly1);
+    bil_src(ox, (float)wm / (float)Wo, wm, x0, x1, lx0, lx1);
+    float logit[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const T* plane = lo + ((size_t)b * 2 + c) * h * w;
+        auto mid = [&](int my, int mx) {                                    // one pixel of the x2 stage, rounded to T
+            int a0, a1, c0, c1; float la0, la1, lc0, lc1;
+            bil_src(my, 0.5f, h, a0, a1, la0, la1);
+            bil_src(mx, 0.5f, w, c0, c1, lc0, lc1);
+            const float v = la0 * (lc0 * ldf<T>(plane + a0 * w + c0) + lc1 * ldf<T>(plane + a0 * w + c1)) +
+                            la1 * (lc0 * ldf<T>(plane + a1 * w + c0) + lc1 * ldf<T>(plane + a1 * w + c1));
+            return round_to<T>(v);
+        };
+        const float v = ly0 * (lx0 * mid(y0, x0) + lx1 * mid(y0, x1)) + ly1 * (lx0 * mid(y1, x0) + lx1 * mid(y1, x1));
+        logit[c] = round_to<T>(v);
+    }
+    const float m = fmaxf(logit[0], logit[1]);                              // F.softmax(logits.float(), dim=1).argmax(dim=1)
+    const float e0 = expf(logit[0] - m), e1 = expf(logit[1] - m);
+    const float sum = e0 + e1;
+    labels[idx] = (e1 / sum > e0 / sum) ? 1 : 0;                            // argmax keeps the first maximum
+}
+
+int seg_labels_launch(const void* lo, uint8_t* labels, int B, int h, int w, int Ho, int Wo, int dtype, hipStream_t stream) {
+    const long long total = (long long)B * Ho * Wo;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == 0) hipLaunchKernelGGL((seg_labels_kernel<float>), grid, dim3(256), 0, stream, (const float*)lo, labels, B, h, w, Ho, Wo);
+    else hipLaunchKernelGGL((seg_labels_kernel<__hip_bfloat16>), grid, dim3(256), 0, stream, (const __hip_bfloat16*)lo, labels, B, h, w, Ho, Wo);
+    return (int)hipGetLastError();
+}
+
 template <typename T>
 static int launch_norm(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,
                        long long rows, int C, float eps, int Hr, int Wr, int Hp, int Wp, const void* xoff, hipStream_t stream) {

@@ -150,3 +150,19 @@ def conv3x3_to1(x_nchw_cl, w32, bias):
                                         _DT[x.dtype], ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     L.check(rc, "ppn_conv3x3_to1_nhwc")
     return y
+
+
+def seg_labels_2class(logits_lo, out_hw):
+    """u8 labels [B,Ho,Wo] of a two-class segmentor from its low-resolution logits [B,2,h,w]: x2 bilinear, bilinear to out_hw,
+    float32 softmax, argmax — the three library kernels of the reference tail in one (ppn_seg_labels_2class)."""
+    if not logits_lo.is_cuda:
+        raise RuntimeError("ppnet_amd.fused: GPU tensors only (no CPU fallback)")
+    x = logits_lo.contiguous()
+    B, C2, h, w = x.shape
+    assert C2 == 2
+    labels = torch.empty(B, out_hw[0], out_hw[1], dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = L.lib.ppn_seg_labels_2class(_p(x), _p(labels), B, h, w, out_hw[0], out_hw[1], _DT[x.dtype],
+                                         ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    L.check(rc, "ppn_seg_labels_2class")
+    return labels

@@ -65,6 +65,16 @@ class PPNet(torch.nn.Module):
             return self.segnet(x)
 
     @torch.no_grad()
+    def segment_u8(self, grid_u8):
+        """segment() as u8 labels, through the fused output tail (SegNet.labels_u8)."""
+        rgb = edage.grid_to_rgb(grid_u8) * 255.0
+        x = normalize_images(rgb)
+        if self.weights_dtype is not None:
+            x = x.to(self.weights_dtype)
+        with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            return self.segnet.labels_u8(x)
+
+    @torch.no_grad()
     def heatmap(self, mask):
         """class mask [B,R,R] -> 8-bit waypoint heat map [B,R,R] (GenNet + per-sample min-max, predict.py:88-102)."""
         x = mask.to(self.weights_dtype or torch.float32).unsqueeze(1)        # my_dataset.py:15: values {0,1}
@@ -78,7 +88,7 @@ class PPNet(torch.nn.Module):
         n_obstacles [B] valid. Returns dict(ok, waypoints, counts, collision, success)."""
         B = grid_u8.shape[0]
         dev = grid_u8.device
-        heat = self.heatmap(self.segment(grid_u8))
+        heat = self.heatmap(self.segment(grid_u8) if os.environ.get("PPNET_NO_FUSED_TAIL") else self.segment_u8(grid_u8))
         ok, wp, cnt = plan.extract_paths(heat, init, end, down_sample_rate)
         # consecutive-waypoint segments of every problem -> one collision launch (process_map.py:491-495)
         M = wp.shape[1]

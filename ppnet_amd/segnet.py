@@ -260,7 +260,8 @@ class SETRUPHead(nn.Module):
             cin = channels
         self.conv_seg = nn.Conv2d(channels, num_classes, 1)                  # Dropout2d is the identity at inference
 
-    def forward(self, inputs):
+    def forward(self, inputs, lowres=False):
+        """lowres=True: the classifier's logits BEFORE the last x2 up-sampling (the caller fuses the rest of the tail)."""
         x = inputs[self.in_index]
         # LayerNorm over channels (setr_up_head.py:73-76) on the NHWC view; stays channels_last for the convolutions
         x = fused.layer_norm(x.permute(0, 2, 3, 1), self.norm).permute(0, 3, 1, 2)
@@ -280,7 +281,8 @@ class SETRUPHead(nn.Module):
             y = fused.bias_act_(F.conv2d(x, c.weight, None, c.stride, c.padding).contiguous(memory_format=torch.channels_last), c.bias, 0.0)
         else:
             y = conv(x)
-        return up(self.conv_seg(y).contiguous())                             # 2 channels: the library bilinear kernel
+        lo = self.conv_seg(y).contiguous()
+        return lo if lowres else up(lo)                                      # 2 channels: the library bilinear kernel
 
 
 class UPerHead(nn.Module):
@@ -370,6 +372,15 @@ class SegNet(nn.Module):
     def encode_decode(self, img):
         out = self.decode_head(self.backbone(img))
         return F.interpolate(out, img.shape[2:], mode="bilinear", align_corners=self.align_corners)
+
+    def labels_u8(self, img):
+        """argmax labels as u8 [B,R,R].  SETR-UP head with two classes on the GPU: the x2 up-sampling of the logits, the
+        resize to the input size, softmax and argmax are one HIP kernel (ppn_seg_labels_2class); otherwise forward()."""
+        head = self.decode_head
+        if (img.is_cuda and isinstance(head, SETRUPHead) and head.conv_seg.out_channels == 2 and not self.align_corners
+                and not head.align_corners and head.up_convs[-1][1].scale_factor == 2.0):
+            return fused.seg_labels_2class(head(self.backbone(img), lowres=True), img.shape[2:])
+        return self.forward(img).to(torch.uint8)
 
     def forward(self, img, return_logits=False):
         logits = self.encode_decode(img)

@@ -203,6 +203,29 @@ def test_single_channel_convs_vs_torch(dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_fused_segmentation_tail_vs_torch(dtype):
+    """ppn_seg_labels_2class against the three library ops it replaces (interpolate x2, interpolate to size, softmax+argmax)."""
+    from ppnet_amd import fused
+    dt = getattr(torch, dtype)
+    torch.manual_seed(6)
+    lo = (torch.randn(5, 2, 16, 16, device="cuda") * 2).to(dt)
+    mid = torch.nn.functional.interpolate(lo, scale_factor=2, mode="bilinear", align_corners=False)
+    full = torch.nn.functional.interpolate(mid, (64, 64), mode="bilinear", align_corners=False)
+    want = torch.nn.functional.softmax(full.float(), dim=1).argmax(dim=1)
+    got = fused.seg_labels_2class(lo, (64, 64))
+    assert got.shape == want.shape and got.dtype == torch.uint8
+    # identical up to exact ties / last-ulp differences of the interpolation (library build contracts FMAs)
+    assert float((got.long() == want).float().mean()) > 0.9995
+    # non-square, other ratio (R = 224: 28 -> 56 -> 224 is x4 on the second stage)
+    lo2 = (torch.randn(2, 2, 7, 9, device="cuda")).to(dt)
+    full2 = torch.nn.functional.interpolate(torch.nn.functional.interpolate(lo2, scale_factor=2, mode="bilinear", align_corners=False),
+                                            (56, 72), mode="bilinear", align_corners=False)
+    want2 = torch.nn.functional.softmax(full2.float(), dim=1).argmax(dim=1)
+    assert float((fused.seg_labels_2class(lo2, (56, 72)).long() == want2).float().mean()) > 0.999
+
+
+@pytest.mark.gpu
 def test_dinat_base_end_to_end_256():
     from ppnet_amd.segnet import SegNet, normalize_images
     torch.manual_seed(0)
@@ -218,6 +241,10 @@ def test_dinat_base_end_to_end_256():
     assert torch.isfinite(logits).all()
     # bf16 projections / convolutions (fp32 accumulate): the 2-class mask agrees on almost every pixel
     assert float((pred == pred16).float().mean()) > 0.97
+    # the fused output tail (labels_u8) gives the labels of forward()
+    with torch.no_grad():
+        lab = m.labels_u8(normalize_images(img))
+    assert lab.dtype == torch.uint8 and float((lab.long() == pred).float().mean()) > 0.9995
 
 
 @pytest.mark.gpu
