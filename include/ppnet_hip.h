@@ -267,6 +267,11 @@ int ppn_upsample2x_nhwc(const void* x, void* y, int32_t B, int32_t H, int32_t W,
  * folded) bias and its separate add pass (mmcv ConvModule conv -> bn -> ReLU -> Upsample, setr_up_head.py:56-66). */
 int ppn_upsample2x_nhwc_bias(const void* x, const void* bias, void* y, int32_t B, int32_t H, int32_t W, int32_t C,
                              int32_t relu, int32_t dtype, void* stream);
+/* SegNet's input straight from stage B's occupancy codes: img [n_pixels][3] (NHWC) = (rgb - mean3) / std3 with rgb = (255,255,255)
+ * for PPN_GRID_FREE, (255,0,0) for PPN_GRID_MARK, (0,0,0) otherwise (process_map.py:120,128; planning_seg.py:12-41).
+ * mean3 / std3 are HOST pointers to three floats; n_pixels a multiple of 8. */
+int ppn_grid_to_image(const uint8_t* grid, void* img, int64_t n_pixels, const float* mean3, const float* std3, int32_t dtype,
+                      void* stream);
 /* The segmentor's output tail for two classes (setr_up_head.py:78-80, encoder_decoder.py:76-79,242,257): logits [B][2][h][w]
  * (NCHW) -> bilinear x2 -> bilinear to [Ho][Wo] (both align_corners=False, each rounded to the logits' dtype as the
  * materialised tensors are) -> float32 softmax -> argmax, labels u8 [B][Ho][Wo] in {0,1}. */

@@ -370,6 +370,14 @@ int ppn_upsample2x_nhwc_bias(const void* x, const void* bias, void* y, int32_t B
     return PPN_OK;
 }
 
+int ppn_grid_to_image(const uint8_t* grid, void* img, int64_t n_pixels, const float* mean3, const float* std3, int32_t dtype, void* stream) {
+    if (!grid || !img || !mean3 || !std3 || n_pixels < 0 || (n_pixels % 8) != 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
+    if (n_pixels == 0) return PPN_OK;
+    const int e = ppn::grid_image_launch(grid, img, n_pixels, mean3, std3, dtype, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_seg_labels_2class(const void* logits, uint8_t* labels, int32_t B, int32_t h, int32_t w, int32_t Ho, int32_t Wo, int32_t dtype,
                           void* stream) {
     if (!logits || !labels || B <= 0 || h <= 0 || w <= 0 || Ho <= 0 || Wo <= 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;

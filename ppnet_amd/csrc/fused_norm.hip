@@ -271,6 +271,44 @@ int bias_act_launch(void* x, const void* bias, long long n, int C, float slope, 
     return (int)hipGetLastError();
 }
 
+// SegNet's input from stage B's occupancy codes in one kernel: the reference renders the map as an RGB JPEG (free white,
+// obstacle black, start / goal red, process_map.py:120,128) and normalises it (x - mean) / std per channel
+// (planning_seg.py:12-41).  Only six values exist (three channels x {0, 255}); eight pixels per thread, NHWC output.
+template <typename T>
+__global__ __launch_bounds__(256) void grid_image_kernel(const uint8_t* __restrict__ grid, T* __restrict__ img, long long n8, float lo0,
+                                                         float lo1, float lo2, float hi0, float hi1, float hi2) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const uint2 g = *reinterpret_cast<const uint2*>(grid + i * 8);
+    float v[24];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t code = ((k < 4 ? g.x : g.y) >> (8 * (k & 3))) & 0xffu;
+        const bool free_ = code == PPN_GRID_FREE, mark = code == PPN_GRID_MARK;
+        v[3 * k] = (free_ || mark) ? hi0 : lo0;
+        v[3 * k + 1] = free_ ? hi1 : lo1;
+        v[3 * k + 2] = free_ ? hi2 : lo2;
+    }
+    T* out = img + i * 24;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = v[q * 8 + k];
+        Vec8<T>::store(out + q * 8, t);
+    }
+}
+
+int grid_image_launch(const uint8_t* grid, void* img, long long n, const float* mean, const float* stdv, int dtype, hipStream_t stream) {
+    const long long n8 = n / 8;
+    const dim3 g((unsigned)((n8 + 255) / 256));
+    const float lo0 = (0.0f - mean[0]) / stdv[0], lo1 = (0.0f - mean[1]) / stdv[1], lo2 = (0.0f - mean[2]) / stdv[2];
+    const float hi0 = (255.0f - mean[0]) / stdv[0], hi1 = (255.0f - mean[1]) / stdv[1], hi2 = (255.0f - mean[2]) / stdv[2];
+    if (dtype == 0) hipLaunchKernelGGL((grid_image_kernel<float>), g, dim3(256), 0, stream, grid, (float*)img, n8, lo0, lo1, lo2, hi0, hi1, hi2);
+    else hipLaunchKernelGGL((grid_image_kernel<__hip_bfloat16>), g, dim3(256), 0, stream, grid, (__hip_bfloat16*)img, n8, lo0, lo1, lo2, hi0, hi1, hi2);
+    return (int)hipGetLastError();
+}
+
 // SegNet's output tail for two classes in one kernel (setr_up_head.py:78-80 Upsample x2 of the logits, encoder_decoder.py:76-79
 // resize to the input size, :242,257 softmax + argmax): lo [B][2][h][w] -> bilinear to [2h][2w] (rounded to T, as the
 // materialised tensor would be) -> bilinear to [Ho][Wo] (rounded to T) -> float32 softmax over the two classes -> label.

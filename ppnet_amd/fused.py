@@ -166,3 +166,17 @@ def seg_labels_2class(logits_lo, out_hw):
                                          ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
     L.check(rc, "ppn_seg_labels_2class")
     return labels
+
+
+def grid_to_image(grid_u8, mean, std, dtype):
+    """Normalised SegNet input, channels_last [B,3,R,R] of `dtype`, from stage B's u8 codes [B,R,R] (ppn_grid_to_image)."""
+    if not grid_u8.is_cuda:
+        raise RuntimeError("ppnet_amd.fused: GPU tensors only (no CPU fallback)")
+    g = grid_u8.contiguous()
+    B, H, W = g.shape
+    img = torch.empty(B, H, W, 3, dtype=dtype, device=g.device)
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    with torch.cuda.device(g.device):
+        rc = L.lib.ppn_grid_to_image(_p(g), _p(img), g.numel(), m3, s3, _DT[dtype], ctypes.c_void_p(torch.cuda.current_stream(g.device).cuda_stream))
+    L.check(rc, "ppn_grid_to_image")
+    return img.permute(0, 3, 1, 2)

@@ -66,11 +66,11 @@ class PPNet(torch.nn.Module):
 
     @torch.no_grad()
     def segment_u8(self, grid_u8):
-        """segment() as u8 labels, through the fused output tail (SegNet.labels_u8)."""
-        rgb = edage.grid_to_rgb(grid_u8) * 255.0
-        x = normalize_images(rgb)
-        if self.weights_dtype is not None:
-            x = x.to(self.weights_dtype)
+        """segment() as u8 labels: the normalised input straight from the occupancy codes (ppn_grid_to_image) and the
+        fused output tail (SegNet.labels_u8)."""
+        from .segnet import IMG_MEAN, IMG_STD
+        from . import fused
+        x = fused.grid_to_image(grid_u8, IMG_MEAN, IMG_STD, self.weights_dtype or torch.float32)
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             return self.segnet.labels_u8(x)
 

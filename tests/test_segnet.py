@@ -226,6 +226,21 @@ def test_fused_segmentation_tail_vs_torch(dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_grid_to_image_equals_render_then_normalise(dtype):
+    from ppnet_amd import edage, fused
+    from ppnet_amd.segnet import IMG_MEAN, IMG_STD, normalize_images
+    dt = getattr(torch, dtype)
+    torch.manual_seed(7)
+    codes = torch.tensor([0, 255, 128], dtype=torch.uint8, device="cuda")
+    grid = codes[torch.randint(0, 3, (3, 64, 96), device="cuda")]
+    want = normalize_images(edage.grid_to_rgb(grid) * 255.0).to(dt)
+    got = fused.grid_to_image(grid, IMG_MEAN, IMG_STD, dt)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
 def test_dinat_base_end_to_end_256():
     from ppnet_amd.segnet import SegNet, normalize_images
     torch.manual_seed(0)
