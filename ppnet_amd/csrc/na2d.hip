@@ -68,9 +68,10 @@ __device__ __forceinline__ void load_row(const __hip_bfloat16* row, float (&r)[H
 // qkv is laid out for the padded H x W token grid (the module pads before the qkv projection, like NATTEN);
 // out is the unpadded [B][Hr][Wr][heads*32] tensor — padded positions are keys/values only, never queries.
 // Register budget: the plain bf16 variants fit 128 VGPRs without spills (4 waves per SIMD: +10 % on the 8x8-tile layers); the
-// float32 and the pad-aware variants need 145-170 and are left uncapped.
+// pad-aware 8x8 variant is held to 168 (3 waves: 0.24 -> 0.19 ms on the d = 3 layers, 2 spills); the float32 and the other
+// pad-aware variants need 145-171 and are left uncapped (capping them measured slower).
 template <typename T, int TILE, int THREADS, bool VPAD>
-__global__ __launch_bounds__(THREADS, ((VPAD || sizeof(T) == 4) ? 1 : 4)) void na2d_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ pad_kv, const float* __restrict__ rpb,
+__global__ __launch_bounds__(THREADS, (sizeof(T) == 4 ? 1 : (VPAD ? (TILE == 8 ? 3 : 1) : 4))) void na2d_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ pad_kv, const float* __restrict__ rpb,
                                                            T* __restrict__ out, int B, int H, int W, int Hr, int Wr, int heads,
                                                            int dil, float scale, int total_tiles, int halo_r, int halo_c, int tile_bytes, int kpitch, int vpitch) {
     constexpr int STRIDE = Row<T>::STRIDE;
