@@ -90,7 +90,7 @@ def ppnet_leg(torch, dev, mb, batch, steps, world):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        ev[0].record(); mask = model.segment(g)
+        ev[0].record(); mask = model.segment_u8(g)
         ev[1].record(); heat = model.heatmap(mask)
         ev[2].record(); r = one() if False else None
         from ppnet_amd import plan as _plan
