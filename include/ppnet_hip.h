@@ -57,6 +57,9 @@ extern "C" {
 #define PPN_FLAG_ISLE_CAP    16u
 #define PPN_FLAG_POCKET_FULL 32u        /* more than PPN_MAX_POCKET pocket obstacles */
 #define PPN_FLAG_CORRIDOR_PASS 64u       /* informational: an obstacle may touch the corridor, the raster ran its compose pass */
+#define PPN_FLAG_POCKET_DRAWS 128u       /* caller-fed pocket draws ran out (pocket_stride too small): the path's pocket
+                                            obstacles are not the reference's — call again with a larger buffer
+                                            (3 * PPN_POCKET_TRY_CAP * PPN_MAX_ISLES floats always suffice) */
 
 int         ppn_version(void);
 const char* ppn_error_string(int code);
@@ -210,12 +213,19 @@ int ppn_disc_raster(const double* obstacles, const int32_t* counts, int32_t stri
 int ppn_collision_segments(const float* s, const float* e, const int32_t* prob, int32_t n_seg,
                            const float* obs, const int32_t* obs_off, float clearance,
                            uint8_t* hit, void* stream);
+/* The reference's bounds test hard-codes its 224-pixel maps (process_map.py:384-387: a segment with a negative row or a
+ * column above 224 is a collision); ppn_collision_segments keeps that constant.  `_bound` takes the map's resolution
+ * instead, for maps of another size (configs 3 and 5: 256 and 512). */
+int ppn_collision_segments_bound(const float* s, const float* e, const int32_t* prob, int32_t n_seg,
+                                 const float* obs, const int32_t* obs_off, float clearance, float bound,
+                                 uint8_t* hit, void* stream);
 
 /* extract_path (process_map.py:293-365) on n heat maps `heat` [n][H][W] float32 already
  * down-sampled; init/end [n][2] doubles in down-sampled coordinates.  wp [n][max_wp][2] doubles,
  * wp_n[n], ok[n].  The 1 s wall-clock timeout becomes the max_wp step cap (<= PPN_MAX_WAYPOINTS).  One wave per problem;
  * the revisit rule runs on a bitmap of visited lattice offsets, and a heat map whose values are exactly k/255 is walked
- * from its 8-bit codes in LDS (any other values: from the float map in memory) — same waypoints either way. */
+ * from its 8-bit codes in LDS (any other values: from the float map in memory) — same waypoints either way.
+ * Square maps only (H == W, else PPN_E_UNSUPPORTED): the reference's bounds test swaps the axes (process_map.py:318). */
 int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const double* init,
                       const double* end, int32_t max_wp, double* wp, int32_t* wp_n, uint8_t* ok,
                       void* stream);

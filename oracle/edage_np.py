@@ -130,13 +130,32 @@ class MTSource:
     def obst_draws(self, map_id, K):
         return np.concatenate([np.random.random(K), np.random.random(K), np.random.random(K)])  # MapGenerate.py:128-130
 
+    def map_rotation_draw(self):
+        """MapGenerate.py:103-104: torchvision's RandomRotation draws its angle from the global torch generator
+        (`torch.empty(1).uniform_(a, a)`: one draw) for every placed map."""
+        import torch
+        torch.rand(1)
+
 
 class _FloatFeed:
     """Sequential float32 feed: from an array, or lazily from torch.rand(1) (MT mode)."""
 
-    def __init__(self, arr):
+    def __init__(self, arr, rotation_draws=0):
+        """rotation_draws: how many leading entries of `arr` belong to space_normalization's RandomRotation
+        (a fixture that recorded the torch stream from the start of path_obstacles)."""
         self.arr = arr
         self.i = 0
+        self.rotation_draws = rotation_draws
+
+    def rotation_draw(self):
+        """Path.py:160-161: torchvision 0.12's RandomRotation draws its angle (`torch.empty(1).uniform_(a, a)`) from the
+        global torch generator — one draw per path, before set_obstacles' torch.rand.  Keyed (Philox) feeds have no
+        global stream to keep in step."""
+        if self.arr is None:
+            import torch
+            torch.rand(1)
+        else:
+            self.i += self.rotation_draws
 
     def next(self):
         if self.arr is None:
@@ -569,6 +588,7 @@ def make_path(draws, R, map_size, clearance, pocket_feed, hull_order="canonical"
     canvas = corridor_canvas(path, bnd, R, map_size, clearance)
     hull_raw = convexhull(path["pathpoint"], R, map_size, order=hull_order)
     nrm = space_normalization(path, bnd, canvas, hull_raw, R, map_size)
+    pocket_feed.rotation_draw()
     flags = 0
     if path["straight"]:
         isles, obstacles = [], np.zeros([0, 3])
@@ -674,6 +694,8 @@ def make_map(prec, map_id, source, R, map_size, obstacles_size, K, clearance, wa
             flags |= FLAG_PLACE_CAP
             break
     segpoint, pathpoint, pobs = place_and_label(prec, angle, t, R)
+    if hasattr(source, "map_rotation_draw"):
+        source.map_rotation_draw()                       # MapGenerate.py:103-104, before generate_map_randomly
     od = source.obst_draws(map_id, K)
     accept, kept = obstacle_filter(od, K, pathpoint, R, map_size, obstacles_size, clearance)
     obstacles_all = np.concatenate([kept, pobs], axis=0)

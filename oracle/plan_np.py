@@ -14,14 +14,15 @@ MOTIONS = [[0, 1], [0, -1], [1, 0], [-1, 0], [1, 1], [1, -1], [-1, 1], [-1, -1]]
 MAX_WAYPOINTS = 2048
 
 
-def collision_check_circle_edge(s, e, obs, clearance):
+def collision_check_circle_edge(s, e, obs, clearance, bound=224):
     """process_map.py:383-425. s, e: float32 pairs; obs: rows (ox, oy, size). Quirks kept: bounds test on
-    s[0], s[1] only against 0 / 224; the vertex test uses e twice and never s; `dir` flips persist."""
+    s[0], s[1] only against 0 / 224; the vertex test uses e twice and never s; `dir` flips persist.
+    bound: the reference's constant 224 (its map size); the resolution for maps of another size."""
     s = np.asarray(s, dtype=f32)
     e = np.asarray(e, dtype=f32)
-    if s[0] < 0 or s[1] > 224:
+    if s[0] < 0 or s[1] > bound:
         return True
-    if e[0] < 0 or e[1] > 224:
+    if e[0] < 0 or e[1] > bound:
         return True
     sx, sy, ex, ey = s[1], s[0], e[1], e[0]
     dx, dy = f32(ex - sx), f32(ey - sy)

@@ -25,6 +25,7 @@ MAX_WAYPOINTS = 2048
 GRID_OBST, GRID_FREE, GRID_MARK = 0, 255, 128
 FLAG_POCKET_CAP, FLAG_PLACE_CAP, FLAG_EMPTY_ISLE, FLAG_HULL_CAP, FLAG_ISLE_CAP, FLAG_POCKET_FULL = 1, 2, 4, 8, 16, 32
 FLAG_CORRIDOR_PASS = 64   # informational (maps only): the raster kernel ran its corridor compose pass
+FLAG_POCKET_DRAWS = 128   # the caller-fed pocket draws ran out (ppn_edage_paths: pocket_stride too small)
 
 _p = C.c_void_p
 
@@ -48,7 +49,7 @@ class MapsStruct(C.Structure):
 EXPORTS = ("ppn_version", "ppn_error_string", "ppn_last_hip_error", "ppn_polyfit_table", "ppn_edage_paths",
            "ppn_edage_paths_ex", "ppn_edage_maps", "ppn_edage_maps_place", "ppn_edage_maps_raster",
            "ppn_label_masks", "ppn_boundary_check", "ppn_boundary_check_ex",
-           "ppn_obstacle_filter", "ppn_paint_markers", "ppn_disc_raster", "ppn_collision_segments",
+           "ppn_obstacle_filter", "ppn_paint_markers", "ppn_disc_raster", "ppn_collision_segments", "ppn_collision_segments_bound",
            "ppn_extract_paths", "ppn_resize_bilinear_u8", "ppn_philox_doubles", "ppn_na2d_fwd", "ppn_na2d_fwd_padded", "ppn_na2d_fwd_vpad", "ppn_residual_layernorm", "ppn_residual_layernorm_padded", "ppn_layernorm_offset", "ppn_upsample2x_nhwc", "ppn_upsample2x_nhwc_bias", "ppn_bias_act_nhwc", "ppn_seg_labels_2class", "ppn_grid_to_image", "ppn_conv3x3_c1_nhwc", "ppn_conv3x3_to1_nhwc")
 
 
@@ -81,6 +82,7 @@ def _load():
     lib.ppn_boundary_check.argtypes = [_p, C.c_int32, _p, _p, C.c_int32, C.c_int32, _p, _p]
     lib.ppn_disc_raster.argtypes = [_p, _p, C.c_int32, C.c_int32, C.c_int32, _p, _p]
     lib.ppn_collision_segments.argtypes = [_p, _p, _p, C.c_int32, _p, _p, C.c_float, _p, _p]
+    lib.ppn_collision_segments_bound.argtypes = [_p, _p, _p, C.c_int32, _p, _p, C.c_float, C.c_float, _p, _p]
     lib.ppn_extract_paths.argtypes = [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, C.c_int32, _p, _p, _p, _p]
     lib.ppn_resize_bilinear_u8.argtypes = [_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p, _p, _p]
     lib.ppn_philox_doubles.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int32, _p, _p]

@@ -268,20 +268,28 @@ int ppn_disc_raster(const double* obstacles, const int32_t* counts, int32_t stri
     return PPN_OK;
 }
 
-int ppn_collision_segments(const float* s, const float* e, const int32_t* prob, int32_t n_seg, const float* obs,
-                           const int32_t* obs_off, float clearance, uint8_t* hit, void* stream) {
-    if (!s || !e || !prob || n_seg < 0 || !obs || !obs_off || !hit) return PPN_E_INVALID;
+int ppn_collision_segments_bound(const float* s, const float* e, const int32_t* prob, int32_t n_seg, const float* obs,
+                                 const int32_t* obs_off, float clearance, float bound, uint8_t* hit, void* stream) {
+    if (!s || !e || !prob || n_seg < 0 || !obs || !obs_off || !hit || !(bound > 0.0f)) return PPN_E_INVALID;
     if (n_seg == 0) return PPN_OK;
     hipLaunchKernelGGL(ppn::collision_segments_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, (hipStream_t)stream, s,
-                       e, prob, n_seg, obs, obs_off, clearance, hit);
+                       e, prob, n_seg, obs, obs_off, clearance, bound, hit);
     PPN_HIP(hipGetLastError());
     return PPN_OK;
+}
+
+int ppn_collision_segments(const float* s, const float* e, const int32_t* prob, int32_t n_seg, const float* obs,
+                           const int32_t* obs_off, float clearance, uint8_t* hit, void* stream) {
+    return ppn_collision_segments_bound(s, e, prob, n_seg, obs, obs_off, clearance, 224.0f, hit, stream);
 }
 
 int ppn_extract_paths(const float* heat, int32_t n, int32_t H, int32_t W, const double* init, const double* end,
                       int32_t max_wp, double* wp, int32_t* wp_n, uint8_t* ok, void* stream) {
     if (!heat || n < 0 || H <= 0 || W <= 0 || !init || !end || max_wp <= 0 || max_wp > PPN_MAX_WAYPOINTS || !wp || !wp_n || !ok)
         return PPN_E_INVALID;
+    // the walk keeps the reference's bounds test (process_map.py:318 checks the row against size[0] = width and the column
+    // against the height), which only indexes inside the map when it is square
+    if (H != W) return PPN_E_UNSUPPORTED;
     if (n == 0) return PPN_OK;
     // visited bitmap over the lattice offsets (-M .. M per axis, M = max(H, W)); none (history scan) if it would not fit in LDS
     int vis_dim = 2 * (H > W ? H : W) + 4;

@@ -594,8 +594,10 @@ __global__ __launch_bounds__(NT, PPN_PATHS_WAVES_PER_EU) void edage_paths_kernel
         const float* pfed = prm.pocket ? prm.pocket + (size_t)p * prm.pocket_stride : nullptr;
         auto next_float = [&]() -> float {
             float v;
-            if (pfed) v = (int)fdraw < prm.pocket_stride ? pfed[fdraw] : 0.5f;
-            else v = philox_float(prm.seed, STREAM_POCKET, pid, fdraw);
+            if (pfed) {
+                if ((int)fdraw < prm.pocket_stride) v = pfed[fdraw];
+                else { v = 0.5f; flags |= PPN_FLAG_POCKET_DRAWS; }           // fed draws ran out: say so (the caller re-launches)
+            } else v = philox_float(prm.seed, STREAM_POCKET, pid, fdraw);
             ++fdraw;
             return v;
         };

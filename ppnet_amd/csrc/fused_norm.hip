@@ -33,12 +33,7 @@ template <> struct Vec8<__hip_bfloat16> {
         v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
         v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
     }
-    static __device__ __forceinline__ uint32_t pack(float lo, float hi) {     // round-to-nearest-even, finite inputs
-        uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
-        a = (a + 0x7fffu + ((a >> 16) & 1u)) >> 16;
-        b = (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u;
-        return a | b;
-    }
+    static __device__ __forceinline__ uint32_t pack(float lo, float hi) { return pack_bf16x2(lo, hi); }
     static __device__ __forceinline__ void store(__hip_bfloat16* p, const float (&v)[8]) {
         *reinterpret_cast<uint4*>(p) = make_uint4(pack(v[0], v[1]), pack(v[2], v[3]), pack(v[4], v[5]), pack(v[6], v[7]));
     }

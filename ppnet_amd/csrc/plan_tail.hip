@@ -15,11 +15,12 @@ namespace ppn {
 __global__ __launch_bounds__(256) void collision_segments_kernel(const float* s_in, const float* e_in,
                                                                  const int32_t* prob, int n_seg, const float* obs,
                                                                  const int32_t* obs_off, float clearance,
-                                                                 uint8_t* hit) {
+                                                                 float bound, uint8_t* hit) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_seg) return;
     const float s0 = s_in[i * 2], s1 = s_in[i * 2 + 1], e0 = e_in[i * 2], e1 = e_in[i * 2 + 1];
-    if (s0 < 0.0f || s1 > 224.0f || e0 < 0.0f || e1 > 224.0f) { hit[i] = 1; return; }   // process_map.py:384-387
+    // process_map.py:384-387 hard-codes the reference's 224-pixel maps; `bound` carries the map's resolution
+    if (s0 < 0.0f || s1 > bound || e0 < 0.0f || e1 > bound) { hit[i] = 1; return; }
     const float sx = s1, sy = s0, ex = e1, ey = e0;                       // swap to (x, y), :388-389
     float dx = ex - sx, dy = ey - sy;
     const float nrm = sqrtf(dx * dx + dy * dy);

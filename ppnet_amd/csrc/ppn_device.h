@@ -12,6 +12,16 @@
 
 namespace ppn {
 
+// two float32 -> one dword of two bfloat16 (lo in bits 0..15), round-to-nearest-even.  A plain cast, which hipcc lowers to
+// v_cvt_pk_bf16_f32: a NaN stays a NaN (integer rounding on the float bits turns some NaNs into 0 or infinity,
+// MI355X_MICROARCH.md "Correctness boundaries").
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+
 // ------------------------------------------------------------------------------------ Philox
 // Salmon et al. SC'11, Random123 constants; counter = (block, inst_hi, inst_lo, stream).
 enum : uint32_t { STREAM_PATH = 1, STREAM_POCKET = 2, STREAM_PLACE = 3, STREAM_OBST = 4 };

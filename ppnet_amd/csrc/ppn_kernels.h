@@ -51,7 +51,7 @@ __global__ void disc_raster_kernel(const double* obstacles, const int32_t* count
                                    int n_maps, int R, uint8_t* grid);
 __global__ void collision_segments_kernel(const float* s, const float* e, const int32_t* prob, int n_seg,
                                           const float* obs, const int32_t* obs_off, float clearance,
-                                          uint8_t* hit);
+                                          float bound, uint8_t* hit);
 __global__ void extract_paths_kernel(const float* heat, int n, int H, int W, const double* init,
                                      const double* end, int max_wp, double* wp, int32_t* wp_n, uint8_t* ok, int vis_dim, int stage_heat);
 

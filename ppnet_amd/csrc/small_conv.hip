@@ -12,12 +12,7 @@ namespace ppn {
 namespace {
 __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ float ld1(const __hip_bfloat16* p) { return __bfloat162float(*p); }
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {          // round-to-nearest-even, finite inputs
-    uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a = (a + 0x7fffu + ((a >> 16) & 1u)) >> 16;
-    b = (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u;
-    return a | b;
-}
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { return pack_bf16x2(lo, hi); }
 template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);

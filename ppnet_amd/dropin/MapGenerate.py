@@ -76,6 +76,7 @@ class MapGenerate:
                     tries += SPECULATE
                     if tries > 1000000:
                         raise RuntimeError('Error:Repeated over 1000000 times!')
+                torch.rand(1)       # MapGenerate.py:103-104: RandomRotation's angle draw (torchvision 0.12), one per placed map
                 obst.append(np.concatenate([np.random.random(K), np.random.random(K), np.random.random(K)]))
         return (torch.tensor(np.array(place), device=self.device), torch.tensor(np.array(obst), device=self.device))
 

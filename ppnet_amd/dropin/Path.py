@@ -90,23 +90,36 @@ class Path:
             self._draws = torch.tensor(d[None, :], dtype=torch.float64, device=self.device)
 
     def _launch(self, R, map_size, with_pocket):
-        pocket = None
-        if rng.mode() == "mt19937" and with_pocket:
-            # torch.rand is consumed a data-dependent number of times (Path.py:479-485): pre-draw, then
+        mt_pocket = rng.mode() == "mt19937" and with_pocket
+        if mt_pocket:
+            # space_normalization's RandomRotation draws its angle from the global torch generator (torchvision 0.12:
+            # `torch.empty(1).uniform_(a, a)`, one draw, Path.py:160-161) before set_obstacles' torch.rand
+            torch.rand(1)
+            # torch.rand is then consumed a data-dependent number of times (Path.py:479-485): pre-draw, then
             # rewind and advance the global generator by what the kernel actually used
             self._torch_state = torch.get_rng_state()
-            n = 3 * L.POCKET_TRY_CAP
-            pocket = torch.tensor([[torch.rand(1).item() for _ in range(n)]], dtype=torch.float32, device=self.device)
         force = torch.tensor([1 if self.is_straight else 0], dtype=torch.int8, device=self.device)
-        pb = edage.generate_paths(1, R, map_size, self.Clearance, seed=rng.seed(), first_path_id=self._path_id,
-                                  device=self.device, draws=self._draws, pocket_draws=pocket, debug=True,
-                                  force_straight=force)
-        torch.cuda.synchronize(self.device)
-        if pocket is not None:
+        n = 3 * L.POCKET_TRY_CAP
+        while True:
+            pocket = None
+            if mt_pocket:
+                torch.set_rng_state(self._torch_state)
+                pocket = torch.tensor([[torch.rand(1).item() for _ in range(n)]], dtype=torch.float32, device=self.device)
+            pb = edage.generate_paths(1, R, map_size, self.Clearance, seed=rng.seed(), first_path_id=self._path_id,
+                                      device=self.device, draws=self._draws, pocket_draws=pocket, debug=True,
+                                      force_straight=force)
+            torch.cuda.synchronize(self.device)
+            if pocket is None:
+                return pb
             used = int(pb.pocket_draws_used[0])
-            torch.set_rng_state(self._torch_state)
-            for _ in range(used):
-                torch.rand(1)
+            if used <= n and not (int(pb.flags[0]) & L.FLAG_POCKET_DRAWS):
+                break
+            if n >= 3 * L.POCKET_TRY_CAP * L.MAX_ISLES:           # cannot happen: the kernel's own caps bound the draws
+                raise RuntimeError("set_obstacles consumed more torch.rand draws than the kernel's caps allow")
+            n = 3 * L.POCKET_TRY_CAP * L.MAX_ISLES                # every isle at its try cap: the most the kernel can use
+        torch.set_rng_state(self._torch_state)
+        for _ in range(used):
+            torch.rand(1)
         return pb
 
     # ------------------------------------------------------------------ reference API

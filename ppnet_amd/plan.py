@@ -54,16 +54,17 @@ def extract_paths(heat_u8, init_state, end_state, down_sample_rate=2, max_wp=L.M
     return ok.bool(), full, torch.where(ok.bool(), wp_n + 2, torch.zeros_like(wp_n))
 
 
-def collision_segments(s, e, prob, obs, obs_off, clearance):
+def collision_segments(s, e, prob, obs, obs_off, clearance, bound=224.0):
     """collision_check_circle_edge for n segments (device f32 [n,2] each); prob [n] i32 problem index;
-    obs [m,3] f32 rows (ox, oy, size); obs_off [P+1] i32 CSR offsets. Returns hit [n] bool."""
+    obs [m,3] f32 rows (ox, oy, size); obs_off [P+1] i32 CSR offsets. Returns hit [n] bool.
+    bound: the map's resolution for the out-of-map test (224 = the reference's constant, process_map.py:384-387)."""
     n = s.shape[0]
     hit = torch.empty(n, dtype=torch.uint8, device=s.device)
     with torch.cuda.device(s.device):
-        rc = L.lib.ppn_collision_segments(_ptr(s.contiguous()), _ptr(e.contiguous()), _ptr(prob.contiguous()), n,
-                                          _ptr(obs.contiguous()), _ptr(obs_off.contiguous()), float(clearance), _ptr(hit),
-                                          _sp(s.device))
-    L.check(rc, "ppn_collision_segments")
+        rc = L.lib.ppn_collision_segments_bound(_ptr(s.contiguous()), _ptr(e.contiguous()), _ptr(prob.contiguous()), n,
+                                                _ptr(obs.contiguous()), _ptr(obs_off.contiguous()), float(clearance),
+                                                float(bound), _ptr(hit), _sp(s.device))
+    L.check(rc, "ppn_collision_segments_bound")
     return hit.bool()
 
 

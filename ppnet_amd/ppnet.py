@@ -83,12 +83,22 @@ class PPNet(torch.nn.Module):
         return normalize_heatmap_u8(y)
 
     @torch.no_grad()
-    def plan(self, grid_u8, init, end, obstacles, n_obstacles, clearance, down_sample_rate=2):
+    def plan(self, grid_u8, init, end, obstacles, n_obstacles, clearance=None, down_sample_rate=2):
         """Full pipeline for B problems. init/end [B,2] f64 (row, col); obstacles [B,S,3] f64 rows [col,row,r] with
-        n_obstacles [B] valid. Returns dict(ok, waypoints, counts, collision, success)."""
-        B = grid_u8.shape[0]
-        dev = grid_u8.device
+        n_obstacles [B] valid. clearance in pixels: default 1/50 * resolution, the reference's call site
+        (process_map.py:491-495: `1/50*224` on its 224-pixel maps) at this model's resolution; the out-of-map test uses
+        the resolution as well.  Returns dict(ok, waypoints, counts, collision, success)."""
         heat = self.heatmap(self.segment(grid_u8) if os.environ.get("PPNET_NO_FUSED_TAIL") else self.segment_u8(grid_u8))
+        return self.plan_tail(heat, init, end, obstacles, n_obstacles, clearance, down_sample_rate)
+
+    @torch.no_grad()
+    def plan_tail(self, heat, init, end, obstacles, n_obstacles, clearance=None, down_sample_rate=2):
+        """extract_path + collision_check_circle_edge over the consecutive waypoints (process_map.py:486-503) for B
+        8-bit heat maps [B,R,R]."""
+        B = heat.shape[0]
+        dev = heat.device
+        if clearance is None:
+            clearance = 1 / 50 * self.resolution
         ok, wp, cnt = plan.extract_paths(heat, init, end, down_sample_rate)
         # consecutive-waypoint segments of every problem -> one collision launch (process_map.py:491-495)
         M = wp.shape[1]
@@ -102,6 +112,6 @@ class PPNet(torch.nn.Module):
         # only the first n_obstacles rows of each problem are real: give the rest zero size far away
         pad = (torch.arange(S, device=dev)[None, :] >= n_obstacles[:, None].to(torch.int64)).reshape(-1)
         obs = torch.where(pad[:, None], torch.tensor([-1e6, -1e6, 0.0], device=dev), obs)
-        hit = plan.collision_segments(s, e, prob, obs, off, clearance)
+        hit = plan.collision_segments(s, e, prob, obs, off, clearance, bound=self.resolution)
         collision = (hit & seg_valid).reshape(B, M - 1).any(dim=1)
         return dict(ok=ok, waypoints=wp, counts=cnt, collision=collision, success=ok & ~collision)

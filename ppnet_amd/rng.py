@@ -3,6 +3,8 @@
 "mt19937" (default): the host replays the reference's own global streams — `np.random.random` for path
     samples / placements / obstacles and `torch.rand` for pocket obstacles — in the reference's order and
     feeds the draws to the kernels, so `np.random.seed(s); torch.manual_seed(s)` scripts keep their meaning.
+    The torch stream also advances by the one draw torchvision 0.12's `RandomRotation` takes per path
+    (Path.py:160-161) and per placed map (MapGenerate.py:103-104).
     One deviation: pocket obstacles consume `torch.rand` isle by isle in the hull's canonical vertex order
     (lexicographically smallest vertex first); Qhull's start vertex is implementation-defined.
 "philox": every draw is Philox4x32-10 keyed by (seed, stream, instance id, index) and generated on the

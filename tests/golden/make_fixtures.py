@@ -7,7 +7,9 @@ script.  Absent third-party modules are replaced by `sys.modules` stubs:
 
   cv2, imgviz            -> empty modules (imported, never called on the recorded paths)
   torchvision            -> ToTensor = u8 HWC / PIL -> f32 CHW / 255 ; RandomRotation and
-                            functional.affine = identity ; utils.save_image = no-op ;
+                            functional.affine = identity on the raster — but RandomRotation still draws its
+                            angle as torchvision 0.12 does (`torch.empty(1).uniform_(lo, hi)`), so the global
+                            torch stream advances exactly as in the reference ; utils.save_image = no-op ;
                             Resize / ToPILImage = identity
 
 so every *non-raster* quantity recorded here is a genuine reference result; the rotated /
@@ -61,12 +63,24 @@ def _install_stubs():
         def __call__(self, x):
             return x
 
+    class RandomRotation:
+        """Raster identity, but with torchvision 0.12's draw: RandomRotation.forward -> get_params(degrees) ->
+        `torch.empty(1).uniform_(lo, hi)`, one draw from the global torch generator even when lo == hi
+        (Path.py:160-161, MapGenerate.py:103-104)."""
+
+        def __init__(self, degrees, *a, **k):
+            self.degrees = [float(np.ravel(d)[0]) for d in degrees]
+
+        def __call__(self, x):
+            torch.empty(1).uniform_(self.degrees[0], self.degrees[1])
+            return x
+
     tv = types.ModuleType("torchvision")
     tvt = types.ModuleType("torchvision.transforms")
     tvf = types.ModuleType("torchvision.transforms.functional")
     tvu = types.ModuleType("torchvision.utils")
     tvt.ToTensor = ToTensor
-    tvt.RandomRotation = Identity
+    tvt.RandomRotation = RandomRotation
     tvt.Resize = Identity
     tvt.ToPILImage = Identity
     tvt.CenterCrop = Identity
@@ -211,10 +225,12 @@ def run_path(PathMod, seed, R, clearance, is_straight, map_size=50, tseed=None):
         rec["hull_raw"] = _f64(hull_pts.numpy())
         tstate = torch.get_rng_state()
         ok = p.path_obstacles(resolution=R, map_size=map_size, map_offset=R / 2)
-        # torch draws consumed by set_obstacles: replay a generous prefix
+        # torch draws consumed by path_obstacles: replay a generous prefix.  The first n_rotation_draws of them
+        # belong to space_normalization's RandomRotation (Path.py:160-161), the rest to set_obstacles
         tstate2 = torch.get_rng_state()
         torch.set_rng_state(tstate)
         rec["torch_draws"] = np.array([torch.rand(1).item() for _ in range(600)], dtype=np.float32)
+        rec["n_rotation_draws"] = np.array([1])
         torch.set_rng_state(tstate2)
     rec["ok"] = np.array([int(bool(ok))])
     rec["rotation"] = _f64(p.Rotation).reshape(-1)
@@ -351,6 +367,8 @@ def fixture_mapgenerate(MapGenMod):
     out["problem_end"] = _f64([p["End"] for p in problems])
     # final numpy RNG position: lets the oracle prove it consumed exactly the same stream
     out["np_next_draws"] = np.random.random(4)
+    # and the torch one: 10 + 100 RandomRotation draws (Path.py:160, MapGenerate.py:103) + set_obstacles' torch.rand
+    out["torch_next_draws"] = np.array([torch.rand(1).item() for _ in range(4)], dtype=np.float32)
     np.savez_compressed(os.path.join(OUT, "g10_config1_R64.npz"), **out)
 
 
@@ -431,12 +449,13 @@ def fixture_gen_path(PM):
 # ----------------------------------------------------------------------------- G13 AE-ViT
 def fixture_aevit():
     """GenNet AEViT(1,1,R,24) (GenNet/networks/ae_vit.py:12-76, the model predict.py:46 builds) with seeded
-    random weights in eval mode: weights (as plain arrays), {0,1} inputs and outputs at R = 64 and 224."""
+    random weights in eval mode: weights (as plain arrays), {0,1} inputs and outputs at R = 64, 224, 256 (config 3,
+    what bench.py runs) and 512 (config 5: down_time = 4, one stage deeper, ae_vit.py:23)."""
     gen = "/root/reference/GenNet"
     sys.path.insert(0, gen)
     from networks.ae_vit import AEViT
     out = {}
-    for R, B in ((64, 3), (224, 2)):
+    for R, B in ((64, 3), (224, 2), (256, 2), (512, 1)):
         torch.manual_seed(100 + R)
         m = AEViT(1, 1, R, 24).eval()
         # make BatchNorm statistics non-trivial so eval-mode folding is exercised

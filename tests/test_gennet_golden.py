@@ -19,11 +19,13 @@ def _model_and_data(golden_dir, R):
     return m, torch.tensor(g[f"R{R}/x"]).float(), g[f"R{R}/y"]
 
 
-@pytest.mark.parametrize("R", [64, 224])
+@pytest.mark.parametrize("R", [64, 224, 256, 512])
 def test_aevit_cpu_matches_reference(golden_dir, R):
+    """R = 256 is what bench.py runs (config 3); R = 512 (config 5) has down_time = 4: one conv / deconv stage more."""
     m, x, y = _model_and_data(golden_dir, R)
     if R == 224:
         assert len(m.state_dict()) == 87 and sum(p.numel() for p in m.parameters()) == 53713
+    assert len(m.enc_conv) == len(m.dec_conv) == {64: 1, 224: 3, 256: 3, 512: 4}[R]
     with torch.no_grad():
         got = m(x).numpy()
     assert got.shape == y.shape
@@ -31,7 +33,7 @@ def test_aevit_cpu_matches_reference(golden_dir, R):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("R", [64, 224])
+@pytest.mark.parametrize("R", [64, 224, 256, 512])
 def test_aevit_gpu_matches_reference(golden_dir, R):
     assert torch.cuda.is_available()
     m, x, y = _model_and_data(golden_dir, R)
@@ -42,7 +44,7 @@ def test_aevit_gpu_matches_reference(golden_dir, R):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("R", [64, 224])
+@pytest.mark.parametrize("R", [64, 224, 256, 512])
 def test_aevit_prepared_gpu_matches_reference(golden_dir, R):
     """prepare_inference(): BN folded, bias + LeakyReLU and the ViT LayerNorms on the HIP kernels."""
     m, x, y = _model_and_data(golden_dir, R)

@@ -57,7 +57,8 @@ def test_paths_fed_draws_vs_reference_golden(dev, golden_dir, name):
     c = int(name.split("_c")[1].split("_")[0])
     st = name.endswith("st1")
     draws = torch.tensor(fixed_layout(G("draws"), st)[None, :], dtype=torch.float64, device=dev)
-    pocket = torch.tensor(G("torch_draws")[None, :], dtype=torch.float32, device=dev)
+    # the recorded torch stream starts at path_obstacles: its first draw is RandomRotation's (Path.py:160-161)
+    pocket = torch.tensor(G("torch_draws")[None, int(G("n_rotation_draws")[0]):], dtype=torch.float32, device=dev)
     pb = edage.generate_paths(1, R, 50, c, draws=draws, pocket_draws=pocket, device=dev, debug=True)
     torch.cuda.synchronize()
     assert int(pb.straight[0]) == int(st)

@@ -38,6 +38,41 @@ def test_collision_segments_vs_reference_golden(dev, golden_dir):
     assert hit.cpu().numpy().astype(np.int8).tolist() == g["hit"].tolist()              # bit-exact mask
 
 
+def test_collision_bound_follows_resolution(dev):
+    """The reference's 224 is its map size (process_map.py:384-387): at R=256 a waypoint beyond column 224 with no obstacle
+    near it is free with bound=R and a hit with the reference's constant; random segments agree with the oracle at bound=R."""
+    import torch
+    from ppnet_amd import plan
+    s = torch.tensor([[100.0, 230.0], [10.0, 10.0]], device=dev)
+    e = torch.tensor([[120.0, 250.0], [20.0, 30.0]], device=dev)
+    prob = torch.zeros(2, dtype=torch.int32, device=dev)
+    obs = torch.tensor([[30.0, 200.0, 4.0]], device=dev)
+    off = torch.tensor([0, 1], dtype=torch.int32, device=dev)
+    assert plan.collision_segments(s, e, prob, obs, off, 256 / 50, bound=256).cpu().tolist() == [False, False]
+    assert plan.collision_segments(s, e, prob, obs, off, 256 / 50).cpu().tolist() == [True, False]
+    rng = np.random.RandomState(3)
+    n, P, R = 600, 12, 256
+    sv = (rng.random_sample((n, 2)) * (R + 20) - 10).astype(np.float32)
+    ev = (sv + rng.standard_normal((n, 2)) * 25).astype(np.float32)
+    pr = rng.randint(0, P, n).astype(np.int32)
+    cnt = rng.randint(0, 30, P)
+    offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    ob = np.concatenate([rng.random_sample((offs[-1], 2)) * R, rng.random_sample((offs[-1], 1)) * 12], axis=1).astype(np.float32)
+    hit = plan.collision_segments(torch.tensor(sv, device=dev), torch.tensor(ev, device=dev), torch.tensor(pr, device=dev),
+                                  torch.tensor(ob, device=dev), torch.tensor(offs, device=dev), R / 50, bound=R).cpu().numpy()
+    want = [PN.collision_check_circle_edge(sv[i], ev[i], ob[offs[pr[i]]:offs[pr[i] + 1]], R / 50, bound=R) for i in range(n)]
+    assert hit.tolist() == want
+
+
+def test_extract_paths_rejects_non_square(dev):
+    import torch
+    from ppnet_amd import _lib, plan
+    heat = torch.zeros(1, 64, 96, dtype=torch.uint8, device=dev)
+    z = torch.zeros(1, 2, dtype=torch.float64, device=dev)
+    with pytest.raises(_lib.PpnError):
+        plan.extract_paths(heat, z, z, down_sample_rate=2)
+
+
 def test_resize_matches_pillow(dev):
     import torch
     from PIL import Image

@@ -163,7 +163,8 @@ def test_path_chain(golden_dir, name, mode):
             isles, fl = E.search_isle(nrm["pathpoint_image"], nrm["hull"], R, 50, c)
             assert fl == 0
             assert [list(i) for i in isles] == G("isle_bounds").tolist()    # exact slice bounds
-            feed = E._FloatFeed(G("torch_draws"))
+            feed = E._FloatFeed(G("torch_draws"), rotation_draws=int(G("n_rotation_draws")[0]))
+            feed.rotation_draw()                                          # Path.py:160-161, ahead of set_obstacles
             obs, fl = E.set_obstacles(nrm["pathpoint_image"], isles, R, 50, c, feed)
             assert fl == 0
             _close(obs, G("obstacles"), 1e-10)
@@ -217,6 +218,7 @@ def test_config1_mt_stream_replay(golden_dir):
     _close([m["init"] for m in maps], g["problem_init"], 1e-10)
     _close([m["end"] for m in maps], g["problem_end"], 1e-10)
     assert np.array_equal(np.random.random(4), g["np_next_draws"])          # stream position
+    assert np.array_equal(np.array([torch.rand(1).item() for _ in range(4)], np.float32), g["torch_next_draws"])   # and torch's
     for m in maps:
         assert m["grid"].shape == (64, 64) and set(np.unique(m["grid"])) <= {0, 128, 255}
 
