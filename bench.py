@@ -46,64 +46,189 @@ def measured_traffic():
         return None
 
 
-def cpu_baseline():
-    """The CPU oracle (a NumPy port of the reference's algorithm) on a bounded sample of the same
-    workload, one host core: 20 target paths x 100 placements at R=256, K=20 (~15 s).  Reported, not a target."""
+def _cpu_sample(args):
+    """One worker's share of the CPU baseline: `n_paths` target paths from `first_path` and their placements (oracle)."""
+    first_path, n_paths, placements = args
     from oracle import edage_np as E
-    n_paths, placements = 20, 100
     src = E.PhiloxSource(SEED)
     t0 = time.perf_counter()
-    precs = E.generate_paths(src, n_paths, R, MAP_SIZE, CLEARANCE)
+    precs = E.generate_paths(src, n_paths, R, MAP_SIZE, CLEARANCE, first_path_id=first_path)
     t1 = time.perf_counter()
-    maps = E.generate_maps(src, precs, R, MAP_SIZE, OBST_SIZE, K, CLEARANCE, placements)
+    maps = E.generate_maps(src, precs, R, MAP_SIZE, OBST_SIZE, K, CLEARANCE, placements, first_map_id=first_path * placements)
     t2 = time.perf_counter()
+    return t1 - t0, t2 - t1, n_paths, len(maps)
+
+
+def cpu_baseline():
+    """The CPU oracle (a NumPy port of the reference's algorithm) on a bounded sample of the same workload:
+    (a) one host core: 20 target paths x 100 placements at R=256, K=20 (~15 s); (b) all host cores: one worker process
+    per core (at most 32), 2 target paths x 100 placements each, wall-clock over the pool.  Reported, not a target."""
+    import multiprocessing as mp
+    n_paths, placements = 20, 100
+    ta, tb, _, n_maps = _cpu_sample((0, n_paths, placements))
     # same amortisation as the GPU step: stage A once per PLACEMENTS maps
-    per_inst = (t1 - t0) / n_paths / PLACEMENTS + (t2 - t1) / len(maps)
-    return {"value": round(1.0 / per_inst, 3), "unit": "instances/s", "cores": 1, "kind": "port",
-            "sample": f"oracle/edage_np.py: {n_paths} paths ({(t1 - t0) / n_paths * 1e3:.0f} ms each) + {len(maps)} maps "
-                      f"({(t2 - t1) / len(maps) * 1e3:.1f} ms each) at R={R}, K={K}; stage A amortised over {PLACEMENTS} placements",
+    per_inst = ta / n_paths / PLACEMENTS + tb / n_maps
+    out = {"value": round(1.0 / per_inst, 3), "unit": "instances/s", "cores": 1, "kind": "port",
+           "sample": f"oracle/edage_np.py: {n_paths} paths ({ta / n_paths * 1e3:.0f} ms each) + {n_maps} maps "
+                     f"({tb / n_maps * 1e3:.1f} ms each) at R={R}, K={K}; stage A amortised over {PLACEMENTS} placements",
+           "host_cores": os.cpu_count()}
+    try:
+        from concurrent.futures import ProcessPoolExecutor
+        workers = max(1, min(32, os.cpu_count() or 1))
+        # spawn: the parent holds a HIP context and must never be forked; an executor (not mp.Pool) so that a worker that
+        # dies raises instead of being respawned for ever; 2 paths per 200 maps = the GPU step's 1 path per PLACEMENTS maps
+        with ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) as ex:
+            list(ex.map(_cpu_sample, [(1000 + w, 0, 1) for w in range(workers)], timeout=120))   # start-up outside the clock
+            t0 = time.perf_counter()
+            parts = list(ex.map(_cpu_sample, [(100 + 2 * w, 2, placements) for w in range(workers)], timeout=240))
+            wall = time.perf_counter() - t0
+        inst = sum(p[3] for p in parts)
+        out["all_cores"] = {"value": round(inst / wall, 2), "unit": "instances/s", "cores": workers,
+                            "sample": f"{workers} worker processes x (2 paths + {2 * placements} maps), {wall:.1f} s wall"}
+    except Exception as e:                               # a reported extra: never fail the bench line over it
+        out["all_cores"] = {"value": None, "error": repr(e)[:200]}
+    return out
+
+
+MFMA_PEAK_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+
+
+def ppnet_flops_per_plan(R):
+    """FLOPs (2 per multiply-add) of one PPNet problem AS EXECUTED at resolution R — SURVEY.md 8(d)'s count for DiNAT-B +
+    SETR-UP (x4 stages) + AE-ViT, with the two places where the build does less work than the reference's graph:
+    dilated layers are virtually padded (the qkv projection, LayerNorm and the attention's queries cover the real tokens
+    only, so the unpadded figure is the executed one), and the 1x1 classifier runs before the last x2 up-sampling (2 output
+    channels at R/4 instead of 512 channels at R/2)."""
+    from ppnet_amd.segnet import DINAT_BASE
+    b, h = DINAT_BASE["backbone"], DINAT_BASE["decode_head"]
+    C0 = b["embed_dim"]
+    fl = 2 * (3 * 9 * (C0 // 2)) * (R // 2) ** 2 + 2 * ((C0 // 2) * 9 * C0) * (R // 4) ** 2         # tokenizer
+    side = R // 4
+    for li, depth in enumerate(b["depths"]):
+        C, T = C0 * 2 ** li, side * side
+        hidden = int(C * b["mlp_ratio"])
+        fl += depth * T * (2 * C * 3 * C + 2 * C * C + 2 * 2 * C * hidden + 2 * 2 * 49 * C)          # qkv, proj, fc1+fc2, QK+AV
+        if li + 1 < len(b["depths"]):
+            side //= 2
+            fl += 2 * (C * 9 * 2 * C) * side * side                                                  # downsampler
+    cin, hw = h["in_channels"], side
+    for _ in range(h["num_convs"]):
+        fl += 2 * cin * 9 * h["channels"] * hw * hw
+        cin, hw = h["channels"], hw * 2
+    fl += 2 * h["channels"] * h["num_classes"] * (hw // 2) ** 2                                      # classifier at the low resolution
+    seg = fl
+    n_down = 0
+    while (R // 28) >> (n_down + 1):
+        n_down += 1                                                                                   # int(log2(R // 28)), ae_vit.py:23
+    dim, N = 24, (R >> n_down) ** 2
+    gen = 2 * 9 * dim * R * R * 2                                                                     # conv_first + conv_final
+    for k in range(n_down):
+        gen += 2 * 2 * 9 * dim * dim * (R >> (k + 1)) ** 2                                            # stride-2 conv + its mirrored deconv
+    gen += 3 * (N * (2 * dim * 3 * dim + 2 * dim * dim + 2 * 2 * dim * 4 * dim) + 2 * 2 * N * N * dim)
+    return seg, gen
+
+
+def ppnet_cpu_baseline(torch, grids_u8, heat_ridge, init, end, obs, n_obs, R_):
+    """Loop B's CPU leg on the host cores (seeded random weights of the same architectures), a bounded sample: the reference's SegNet
+    as the float32 PyTorch-CPU composition of its sources (oracle/segnet_ref.py; its NATTEN op has no CPU build here, so
+    the attention is the definition oracle's gather) on 2 problems, the reference-architecture AE-ViT (PyTorch-CPU float32)
+    on a batch of 8, and the NumPy port of extract_path + collision_check_circle_edge on 8 problems."""
+    import numpy as np
+    from oracle import plan_np as PN
+    from oracle import segnet_ref as SR
+    from ppnet_amd import edage
+    from ppnet_amd.gennet import AEViT
+    from ppnet_amd.segnet import DINAT_BASE, SegNet, normalize_images
+    torch.manual_seed(0)
+    seg = SegNet().eval()
+    img = normalize_images(edage.grid_to_rgb(grids_u8[:2]) * 255.0).cpu()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        SR.segnet_logits_fp64(seg, DINAT_BASE, img, dtype=torch.float32)
+        t_seg = (time.perf_counter() - t0) / 2
+        gen = AEViT(1, 1, R_, 24).eval()
+        x = torch.rand(8, 1, R_, R_).round()
+        gen(x)
+        t0 = time.perf_counter()
+        gen(x)
+        t_gen = (time.perf_counter() - t0) / 8
+    hh, ih, eh = heat_ridge[:8].cpu().numpy(), init[:8].cpu().numpy(), end[:8].cpu().numpy()
+    oh, nh = obs[:8].cpu().numpy().astype(np.float32), n_obs[:8].cpu().numpy()
+    t0 = time.perf_counter()
+    for i in range(8):
+        ok, path = PN.extract_path(hh[i], ih[i], eh[i], down_sample_rate=2)
+        if ok:
+            p32 = path.astype(np.float32)
+            for j in range(len(path) - 1):
+                if PN.collision_check_circle_edge(p32[j], p32[j + 1], oh[i, :nh[i]], R_ / 50, bound=R_):
+                    break
+    t_tail = (time.perf_counter() - t0) / 8
+    per = t_seg + t_gen + t_tail
+    return {"value": round(1.0 / per, 3), "unit": "plans/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"SegNet (oracle/segnet_ref.py, float32 PyTorch-CPU composition, 2 problems): {t_seg:.2f} s each; AE-ViT "
+                      f"(PyTorch-CPU float32, batch 8): {t_gen * 1e3:.0f} ms each; extract_path + collision (oracle/plan_np.py, "
+                      f"1 core, 8 problems on ridge heat maps): {t_tail * 1e3:.0f} ms each",
             "host_cores": os.cpu_count()}
 
 
-def ppnet_leg(torch, dev, mb, batch, steps, world):
+def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg):
     """BASELINE config 3: PPNet inference (SegNet DiNAT-B + SETR-UP -> GenNet AE-ViT -> waypoint extraction ->
     collision check), batch of 256 problems over the 256x256 maps stage B just produced, per GPU.  Weights are
-    seeded random initialisations of the reference architectures (no trained weights ship with the reference)."""
+    seeded random initialisations of the reference architectures (no trained weights ship with the reference), so the
+    heat map the networks emit is noise and a walk over it ends after a few steps.  The timed batch therefore runs both
+    networks on the grids and the planner tail on RIDGE heat maps along the label paths (evaluate.label_heatmaps: GenNet's
+    training target blurred — what a trained GenNet is fitted to emit), built once outside the timed region; the tail's
+    success rate and path-length ratio (config 5's criterion) are reported with it.  Ends with the end-of-batch gather of
+    the fixed-size plan records (RCCL, own stream) when N > 1."""
     import torch.distributed as dist
+    from ppnet_amd import evaluate, na, shard
     from ppnet_amd.ppnet import PPNet
     torch.manual_seed(0)
     model = PPNet(resolution=R).to(dev).eval()
     g = mb.grid[:batch]
     init, end = mb.segpoint[:batch, 0].contiguous(), mb.segpoint[:batch, 10].contiguous()
     obs, n_obs = mb.obstacles[:batch], mb.n_obstacles[:batch, 0].contiguous()
-    clearance = 1 / 50 * 224                                                  # process_map.py:491-495 call site
+    ridge = evaluate.label_heatmaps(pb, mb, PLACEMENTS)[:batch].contiguous()
+    target_px = (pb.length.repeat_interleave(PLACEMENTS) * R / MAP_SIZE)[:batch]
+    s_comm = torch.cuda.Stream(dev) if world > 1 else None
+    gathered = torch.empty(world * batch, shard.PLAN_RECORD_WIDTH, dtype=torch.float64, device=dev) if world > 1 else None
 
-    def one():
-        return model.plan(g, init, end, obs, n_obs, clearance)
+    def one(timers=None):
+        if timers: timers[0].record()
+        mask = model.segment_u8(g)
+        if timers: timers[1].record()
+        heat = model.heatmap(mask)
+        if timers: timers[2].record()
+        res = model.plan_tail(ridge, init, end, obs, n_obs)
+        if timers: timers[3].record()
+        if world > 1:                                                         # end-of-batch gather of the plan records
+            rec = shard.pack_plan_records(res, evaluate.plan_lengths(res["waypoints"], res["counts"]))
+            ev = torch.cuda.Event(); ev.record()
+            with torch.cuda.stream(s_comm):
+                s_comm.wait_event(ev)
+                shard.gather_records(rec, world, out=gathered)
+                rec.record_stream(s_comm)
+        return res, heat
     for _ in range(2):
-        r = one()
+        res, heat = one()
     torch.cuda.synchronize()
-    t_seg = t_gen = t_tail = 0.0
+    # per-stage split and the attention kernel's own time: one extra, untimed batch with events
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    one(ev)
+    na.TIMING = []
+    model.segment_u8(g)
+    torch.cuda.synchronize()
+    na_ms = sum(a.elapsed_time(b) for a, b, _, _, _ in na.TIMING)
+    na_bytes = sum(4 * tok * ch * esz for _, _, tok, ch, esz in na.TIMING)        # q, k, v read + out written, once each
+    na_launches = len(na.TIMING)
+    na.TIMING = None
+    t_seg, t_gen, t_tail = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        ev[0].record(); mask = model.segment_u8(g)
-        ev[1].record(); heat = model.heatmap(mask)
-        ev[2].record(); r = one() if False else None
-        from ppnet_amd import plan as _plan
-        ok, wp, cnt = _plan.extract_paths(heat, init, end, 2)
-        ev[3].record()
-        torch.cuda.synchronize()
-        t_seg += ev[0].elapsed_time(ev[1]); t_gen += ev[1].elapsed_time(ev[2]); t_tail += ev[2].elapsed_time(ev[3])
-    torch.cuda.synchronize()
-    # the timed figure is the full plan() call (segment + heatmap + extract + collision)
-    torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(steps):
-        r = one()
+        res, heat = one()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -112,12 +237,32 @@ def ppnet_leg(torch, dev, mb, batch, steps, world):
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    return {"metric": "ppnet_plans_per_sec", "value": round(world * batch * steps / el, 1), "unit": "plans/s",
-            "batch_per_gpu": batch, "steps": steps, "ms_per_batch": round(el / steps * 1e3, 2), "dtype": "bf16 (fp32 accumulate)",
-            "workload": "PPNet inference batch=256 over 256x256 maps: DiNAT-B + SETR-UP -> AE-ViT -> extract_path -> collision check",
-            "ms_segnet": round(t_seg / steps, 2), "ms_gennet": round(t_gen / steps, 2), "ms_extract": round(t_tail / steps, 2),
-            "weights": "seeded random init (no trained weights in the reference)",
-            "extract_ok_rate": round(float(r["ok"].float().mean().item()), 4)}
+    if rank != 0:
+        return None
+    ms = el / steps * 1e3
+    seg_fl, gen_fl = ppnet_flops_per_plan(R)
+    tflops = (seg_fl + gen_fl) * batch / (ms * 1e-3) / 1e12
+    ev_tail = evaluate.evaluate_plans(res, target_px)
+    net_tail = model.plan_tail(heat, init, end, obs, n_obs)
+    out = {"metric": "ppnet_plans_per_sec", "value": round(world * batch * steps / el, 1), "unit": "plans/s",
+           "batch_per_gpu": batch, "steps": steps, "ms_per_batch": round(ms, 2), "dtype": "bf16 (fp32 accumulate)",
+           "workload": "PPNet inference batch=256 over 256x256 maps: DiNAT-B + SETR-UP -> AE-ViT -> extract_path -> collision check"
+                       + (" -> all-gather of plan records" if world > 1 else ""),
+           "ms_segnet": round(t_seg, 2), "ms_gennet": round(t_gen, 2), "ms_tail": round(t_tail, 2),
+           "weights": "seeded random init (no trained weights in the reference)",
+           "tail_input": "ridge heat maps along the label paths (GenNet's training target, blurred); the networks' own output is noise",
+           "tail": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ev_tail.items()},
+           "extract_ok_rate_network_output": round(float(net_tail["ok"].float().mean().item()), 4),
+           "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tflops / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "gflop_per_plan": round((seg_fl + gen_fl) / 1e9, 2), "gflop_segnet": round(seg_fl / 1e9, 2),
+                        "gflop_gennet": round(gen_fl / 1e9, 3), "counting": "as executed: virtual padding, classifier before the last upsample",
+                        "na_kernel": {"bound": "hbm", "ms": round(na_ms, 3), "launches": na_launches,
+                                      "algorithmic_bytes": na_bytes, "achieved": round(na_bytes / (na_ms * 1e-3) / 1e9, 1),
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(na_bytes / (na_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}}
+    if cpu_leg:
+        out["cpu_baseline"] = ppnet_cpu_baseline(torch, g, ridge, init, end, obs, n_obs, R)
+    return out
 
 
 def main():
@@ -151,7 +296,7 @@ def main():
     # its own HIP streams: while stage B of batch i writes its maps, stage A of batches i+1 .. i+DEPTH is in flight.
     # DEPTH+1 path buffers, events for the hand-off.  Every step launches exactly one stage-A and one stage-B kernel.
     DEPTH = int(os.environ.get("BENCH_DEPTH", "2"))
-    TIMED_EVERY = 4
+    TIMED_EVERY = 2          # every 2nd launch carries a start marker: >= 10 launches averaged at the default --steps 20
     NPB = DEPTH + 1
     pbs = [edage.PathsBatch(PATHS, R, MAP_SIZE, CLEARANCE, dev) for _ in range(NPB)]
     # N > 1: the end-of-batch all-gather of the fixed-size records runs on its own stream beside the next batch, so the
@@ -244,7 +389,8 @@ def main():
 
     ppnet = None
     if not args.no_ppnet:
-        ppnet = ppnet_leg(torch, dev, mb, args.ppnet_batch, args.ppnet_steps, world)
+        ppnet = ppnet_leg(torch, dev, pbs[(args.warmup + args.steps - 1) % NPB], mb, args.ppnet_batch, args.ppnet_steps, world, rank,
+                          cpu_leg=(world == 1 and not args.no_cpu_baseline))
     if rank == 0:
         bytes_per_launch = algorithmic_bytes_per_map(k_tot, k_pocket) * n_local
         achieved = bytes_per_launch / (maps_kernel_ms * 1e-3) / 1e9

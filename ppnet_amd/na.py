@@ -9,6 +9,10 @@ import torch.nn.functional as F
 
 from . import _lib as L
 
+# Measurement hook (bench.py): a list here makes every kernel launch record (start event, end event, real tokens, channels)
+# on its stream, so the kernel's own duration — and with 8*C bytes per token its HBM fraction — can be read live.
+TIMING = None
+
 
 def na2d_forward(qkv, rpb, heads, dilation, scale, real_hw=None, pad_kv=None, padded_hw=None):
     """qkv: [B,H,W,3*C] contiguous CUDA tensor (float32 or bfloat16) straight from the qkv Linear;
@@ -29,6 +33,19 @@ def na2d_forward(qkv, rpb, heads, dilation, scale, real_hw=None, pad_kv=None, pa
     qkv = qkv.contiguous()
     if rpb.dtype != torch.float32 or not rpb.is_contiguous():
         rpb = rpb.detach().to(torch.float32).contiguous()
+    if TIMING is None:
+        return _launch(qkv, rpb, heads, dilation, scale, real_hw, pad_kv, padded_hw, dtype)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    out = _launch(qkv, rpb, heads, dilation, scale, real_hw, pad_kv, padded_hw, dtype)
+    ev1.record()
+    TIMING.append((ev0, ev1, out.numel() // ch, ch, qkv.element_size()))
+    return out
+
+
+def _launch(qkv, rpb, heads, dilation, scale, real_hw, pad_kv, padded_hw, dtype):
+    B, H, W, C3 = qkv.shape
+    ch = C3 // 3
     stream = ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)
     if pad_kv is not None:
         Hp, Wp = padded_hw

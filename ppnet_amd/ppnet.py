@@ -92,14 +92,14 @@ class PPNet(torch.nn.Module):
         return self.plan_tail(heat, init, end, obstacles, n_obstacles, clearance, down_sample_rate)
 
     @torch.no_grad()
-    def plan_tail(self, heat, init, end, obstacles, n_obstacles, clearance=None, down_sample_rate=2):
+    def plan_tail(self, heat, init, end, obstacles, n_obstacles, clearance=None, down_sample_rate=2, max_wp=L.MAX_WAYPOINTS):
         """extract_path + collision_check_circle_edge over the consecutive waypoints (process_map.py:486-503) for B
-        8-bit heat maps [B,R,R]."""
+        8-bit heat maps [B,R,R].  max_wp: the walk's step cap (stands in for the reference's 1 s timeout)."""
         B = heat.shape[0]
         dev = heat.device
         if clearance is None:
             clearance = 1 / 50 * self.resolution
-        ok, wp, cnt = plan.extract_paths(heat, init, end, down_sample_rate)
+        ok, wp, cnt = plan.extract_paths(heat, init, end, down_sample_rate, max_wp)
         # consecutive-waypoint segments of every problem -> one collision launch (process_map.py:491-495)
         M = wp.shape[1]
         s = wp[:, :-1].reshape(-1, 2).to(torch.float32)

@@ -35,10 +35,35 @@ def pack_records(angle, flags, translation, segpoint, out=None):
     return rec
 
 
-def gather_records(rec, world, sizes=None, group=None, out=None):
+PLAN_WAYPOINTS = 32    # waypoints carried in a plan record (the reference's result lists are of this order)
+PLAN_RECORD_WIDTH = 4 + 2 * PLAN_WAYPOINTS
+
+
+def pack_plan_records(result, lengths, out=None):
+    """Loop B's end-of-batch record, one row per problem (the batched analogue of the result list the reference collects
+    on rank 0, SegNet/mmseg/apis/test.py:232-235): ok, collision, waypoint count, plan length, then the first
+    PLAN_WAYPOINTS waypoints (row, col) — when a plan has more, every k-th one so that start and goal are kept."""
+    ok, coll, cnt, wp = result["ok"], result["collision"], result["counts"], result["waypoints"]
+    B = ok.shape[0]
+    rec = out if out is not None else torch.empty(B, PLAN_RECORD_WIDTH, dtype=torch.float64, device=ok.device)
+    rec[:, 0] = ok.to(torch.float64)
+    rec[:, 1] = coll.to(torch.float64)
+    rec[:, 2] = cnt.to(torch.float64)
+    rec[:, 3] = lengths
+    last = (cnt.to(torch.int64) - 1).clamp(min=0)
+    t = torch.arange(PLAN_WAYPOINTS, device=ok.device, dtype=torch.float64) / (PLAN_WAYPOINTS - 1)
+    idx = torch.where(last[:, None] < PLAN_WAYPOINTS, torch.arange(PLAN_WAYPOINTS, device=ok.device)[None, :].clamp(max=wp.shape[1] - 1).expand(B, -1),
+                      (t[None, :] * last[:, None].to(torch.float64)).round().to(torch.int64))
+    idx = torch.minimum(idx, last[:, None])
+    rec[:, 4:] = torch.gather(wp, 1, idx[:, :, None].expand(-1, -1, 2)).reshape(B, 2 * PLAN_WAYPOINTS)
+    return rec
+
+
+def gather_records(rec, world, sizes=None, group=None, out=None, always_collective=False):
     """All-gather of per-instance records; `sizes` = rows per rank when shards are uneven; `out` = a preallocated
-    [world * rows, width] buffer for the even case (a steady-state loop should not allocate on a side stream)."""
-    if world == 1:
+    [world * rows, width] buffer for the even case (a steady-state loop should not allocate on a side stream).
+    always_collective: issue the collective even for a group of one (rehearses the RCCL path on a single GPU)."""
+    if world == 1 and not always_collective:
         return rec
     if sizes is None or len(set(sizes)) == 1:
         if out is None:

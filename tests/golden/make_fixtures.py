@@ -446,6 +446,49 @@ def fixture_gen_path(PM):
     np.savez_compressed(os.path.join(OUT, "g14_gen_path.npz"), pathpoint=pts, mask=masks.astype(np.uint8))
 
 
+# ----------------------------------------------------------------------------- G15 obstacle raster (A13)
+def fixture_plot_obstacles(PathMod):
+    """The reference's obstacle raster, Path.plot_obstacles (Path.py:36-49): matplotlib circles on the default 6.4 x 4.8 in
+    figure at dpi 90 -> ./map.jpg -> PIL '1' -> 'RGB' -> ToTensor -> crop [53:383, 73:517] -> T.Resize(R, R), run here with
+    the real matplotlib / libjpeg / Pillow and two stand-ins for torchvision: ToTensor (u8 HWC -> f32 CHW / 255) and Resize =
+    torch's bilinear interpolate without antialiasing (what torchvision 0.12 does to a tensor).  Recorded: the obstacle
+    lists of 20 config-1 maps (scaled to R = 64, 224, 256) and the binarised raster (obstacle = value < 0.5), bit-packed.
+    This MEASURES the deviation of the build's explicit rule (pixel centre in the closed disc); it does not pin it: the
+    stand-in Resize and the JPEG decoder make the result environment-dependent by a pixel at the rims."""
+    import torchvision
+
+    class _Resize:
+        def __init__(self, size):
+            self.size = tuple(size)
+
+        def __call__(self, img):
+            return torch.nn.functional.interpolate(img[None], size=self.size, mode="bilinear", align_corners=False)[0]
+    torchvision.transforms.Resize = _Resize
+    PathMod.T.Resize = _Resize
+    g = np.load(os.path.join(OUT, "g10_config1_R64.npz"))
+    off = np.concatenate([[0], np.cumsum(g["n_obs"])])
+    out = {}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        n = 0
+        for R in (64, 224, 256):
+            for m in range(0, 100, 15):                       # 7 maps per resolution
+                obs = g["obstacles"][off[m]:off[m + 1]] * (R / 64.0)
+                with quiet():
+                    img = PathMod.plot_obstacles((R, R), [list(o) for o in obs], resolution=(R, R))
+                occ = (img[0].numpy() < 0.5)
+                out[f"c{n}_R"] = np.array([R])
+                out[f"c{n}_obs"] = _f64(obs)
+                out[f"c{n}_occ"] = np.packbits(occ)
+                n += 1
+        out["ncase"] = np.array([n])
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, "g15_plot_obstacles.npz"), **out)
+
+
 # ----------------------------------------------------------------------------- G13 AE-ViT
 def fixture_aevit():
     """GenNet AEViT(1,1,R,24) (GenNet/networks/ae_vit.py:12-76, the model predict.py:46 builds) with seeded
@@ -482,6 +525,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "aevit":
         fixture_aevit()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "plot_obstacles":
+        sys.path.insert(0, REF)
+        import Path as PathMod
+        fixture_plot_obstacles(PathMod)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "gen_path":
         sys.path.insert(0, REF)
         import process_map as PM
@@ -502,6 +550,7 @@ def main():
     import process_map as PM
     fixture_plan_tail(PM)
     fixture_gen_path(PM)
+    fixture_plot_obstacles(PathMod)
     sys.path.remove(REF)
     for mod in ("utils",):
         sys.modules.pop(mod, None)

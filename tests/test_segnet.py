@@ -300,3 +300,24 @@ def test_nat_upernet_end_to_end_and_bn_folding():
         _, logits_f = f(img, return_logits=True)
     assert pred.shape == (2, 224, 224) and logits.shape == (2, 2, 224, 224) and torch.isfinite(logits).all()
     assert (logits - logits_f).abs().max() < 1e-3 * max(1.0, float(logits.abs().max()))
+
+
+@pytest.mark.gpu
+def test_nat_upernet_vs_fp64_composition():
+    """NAT-Base + UPerHead (the reference's default SegNet config) against the float64 op-by-op
+    composition of uper_head.py:76-127 + psp_head.py:48-60 + nat.py (oracle/segnet_ref.py), unprepared and prepared
+    (BN folded, levels folded).  Attention semantics: the definition oracle (parity unpinned)."""
+    import copy
+    from oracle import segnet_ref as SR
+    from ppnet_amd.segnet import NAT_BASE_UPER, SegNet, normalize_images
+    torch.manual_seed(2)
+    m = SR.randomize(SegNet(**NAT_BASE_UPER).eval(), seed=3).cuda()
+    img = normalize_images(torch.randint(0, 256, (2, 128, 128, 3), dtype=torch.uint8, device="cuda"))
+    with torch.no_grad():
+        want = SR.segnet_logits_fp64(m, NAT_BASE_UPER, img, head="uper")
+        got = m.encode_decode(img).double()
+        got_f = copy.deepcopy(m).prepare_inference().encode_decode(img).double()
+    scale = max(1.0, float(want.abs().max()))
+    assert want.shape == (2, 2, 128, 128) and float(want.std()) > 1e-3
+    assert float((got - want).abs().max()) < 2e-3 * scale
+    assert float((got_f - want).abs().max()) < 2e-3 * scale

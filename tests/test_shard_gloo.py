@@ -71,3 +71,47 @@ def test_two_ranks_gloo_equal_single_process(tmp_path):
     even = torch.cat([whole[:6], whole[n0:n0 + 6]])
     for r in range(2):
         assert torch.equal(torch.load(os.path.join(tmp_path, f"even{r}.pt"), weights_only=True), even)
+
+
+def test_plan_records_layout():
+    """Loop B's fixed-size result record: flags, count, length, then <= 32 waypoints with start and goal kept."""
+    wp = torch.zeros(3, 50, 2, dtype=torch.float64)
+    wp[0, :5] = torch.arange(10, dtype=torch.float64).reshape(5, 2)
+    wp[1, :40] = torch.arange(80, dtype=torch.float64).reshape(40, 2)
+    res = dict(ok=torch.tensor([True, True, False]), collision=torch.tensor([False, True, False]),
+               counts=torch.tensor([5, 40, 0], dtype=torch.int32), waypoints=wp)
+    rec = shard.pack_plan_records(res, torch.tensor([12.5, 99.0, 0.0], dtype=torch.float64))
+    assert rec.shape == (3, shard.PLAN_RECORD_WIDTH)
+    assert rec[:, :4].tolist() == [[1, 0, 5, 12.5], [1, 1, 40, 99.0], [0, 0, 0, 0.0]]
+    w0 = rec[0, 4:].reshape(-1, 2)
+    assert torch.equal(w0[:5], wp[0, :5]) and torch.equal(w0[5:], wp[0, 4].expand(27, 2))     # short plan: padded with the goal
+    w1 = rec[1, 4:].reshape(-1, 2)
+    assert torch.equal(w1[0], wp[1, 0]) and torch.equal(w1[-1], wp[1, 39])                      # long plan: subsampled, ends kept
+    assert bool((w1[1:, 0] >= w1[:-1, 0]).all())
+
+
+def _plan_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    B = 4
+    cnt = torch.randint(0, 60, (B,), generator=g, dtype=torch.int32)
+    res = dict(ok=cnt > 0, collision=torch.rand(B, generator=g) > 0.5, counts=cnt,
+               waypoints=torch.rand(B, 64, 2, generator=g, dtype=torch.float64))
+    rec = shard.pack_plan_records(res, torch.rand(B, generator=g, dtype=torch.float64))
+    out = torch.empty(world * B, shard.PLAN_RECORD_WIDTH, dtype=torch.float64)
+    shard.gather_records(rec, world, out=out)
+    torch.save((rec, out), os.path.join(out_dir, f"plan{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_plan_records_gather_two_ranks_gloo(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_plan_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, o0 = torch.load(os.path.join(tmp_path, "plan0.pt"), weights_only=True)
+    r1, o1 = torch.load(os.path.join(tmp_path, "plan1.pt"), weights_only=True)
+    assert torch.equal(o0, torch.cat([r0, r1])) and torch.equal(o1, o0)
