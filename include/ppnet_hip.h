@@ -302,6 +302,29 @@ int ppn_conv3x3_c1_nhwc(const void* x, const float* w, const float* bias, void* 
 int ppn_conv3x3_to1_nhwc(const void* x, const float* w, float bias, void* y, int32_t B, int32_t H, int32_t W, int32_t Cin,
                          int32_t dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * bf16 MFMA kernels (v_mfma_f32_16x16x32_bf16, float32 accumulation; ppnet_amd/csrc/mfma_gemm.h).
+ *
+ * 3x3 convolution, padding 1, stride 1 or 2, as an implicit GEMM on NHWC bfloat16: x [B][H][W][Cin] -> y [B][Ho][Wo][Cout],
+ * y = act(conv(x, w) + bias), act = ReLU when relu != 0.  w is [Cout][3][3][Cin] (the torch weight [Cout][Cin][3][3]
+ * permuted to (0, 2, 3, 1)); bias [Cout] float32 (zeros for a bias-free convolution).  Cin % 64 == 0, Cout % 8 == 0.
+ * Replaces mmcv's ConvModule conv -> (folded) BatchNorm -> ReLU of the SETR-UP head (setr_up_head.py:53-66) and the bias-free
+ * stride-2 convolution of NAT's ConvDownsampler (SegNet/nat.py:48-59). */
+int ppn_conv3x3_mfma_bf16(const void* x, const void* w, const float* bias, void* y, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                          int32_t Cout, int32_t stride, int32_t relu, void* stream);
+/* The head's last stage in one kernel (setr_up_head.py:78-80 with the 1x1 classifier commuted in front of the last
+ * up-sampling): logits[m][c] += sum_n max(conv(x, w)[m][n] + bias[n], 0) * w2[c][n] for the B*H*W pixels m and c = 0, 1.
+ * logits [B*H*W][2] float32 must hold the classifier's bias on entry; w2 [2][Cout] float32.  The 512-channel activation is
+ * never written. */
+int ppn_conv3x3_relu_classify2_bf16(const void* x, const void* w, const float* bias, const float* w2, float* logits, int32_t B, int32_t H,
+                                    int32_t W, int32_t Cin, int32_t Cout, void* stream);
+/* Dense projection c[M][N] = epilogue(a[M][K] . w[N][K]^T) on bfloat16 (torch.nn.Linear layout; SegNet/nat.py:62-85,111-120).
+ * epilogue: 0 = + bias[n]; 1 = gelu(+ bias[n]) (erf form); 2 = c += (the residual stream accumulates, bias unused).
+ * K % 64 == 0, K >= 128, N % 8 == 0.  persistent_blocks: 0 = one tile per workgroup; else the number of workgroups (a multiple
+ * of 8, normally the CU count) that walk the tiles with the LDS-DMA stream running across tile boundaries (M, N % 256 == 0). */
+int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int32_t N, int32_t K, int32_t epilogue,
+                  int32_t persistent_blocks, void* stream);
+
 /* PIL.Image.resize(size, BILINEAR) for 8-bit single-channel images, bit-exact: Pillow's ImagingResample
  * (support = max(scale,1), 22-bit fixed-point coefficients, horizontal pass then vertical pass, each rounded
  * to 8 bits).  Used by extract_path's down-sampling (process_map.py:301).  in [n][H][W], tmp [n][H][outW],

@@ -420,6 +420,41 @@ int ppn_conv3x3_to1_nhwc(const void* x, const float* w, float bias, void* y, int
     return PPN_OK;
 }
 
+int ppn_conv3x3_mfma_bf16(const void* x, const void* w, const float* bias, void* y, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                          int32_t Cout, int32_t stride, int32_t relu, void* stream) {
+    if (!x || !w || !bias || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 64) != 0 || Cout <= 0 || (Cout % 8) != 0 ||
+        (stride != 1 && stride != 2))
+        return PPN_E_INVALID;
+    // 32-bit byte offsets inside the kernel: the image and the weights must stay below 4 GiB
+    if ((long long)B * H * W * Cin * 2 >= (1LL << 32) || (long long)Cout * 9 * Cin * 2 >= (1LL << 32) || (long long)B * H * W >= (1LL << 31))
+        return PPN_E_UNSUPPORTED;
+    const int e = ppn::conv3x3_mfma_launch(x, w, bias, y, B, H, W, Cin, Cout, stride, relu, nullptr, nullptr, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
+int ppn_conv3x3_relu_classify2_bf16(const void* x, const void* w, const float* bias, const float* w2, float* logits, int32_t B, int32_t H,
+                                    int32_t W, int32_t Cin, int32_t Cout, void* stream) {
+    if (!x || !w || !bias || !w2 || !logits || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 64) != 0 || Cout <= 0 || (Cout % 8) != 0)
+        return PPN_E_INVALID;
+    if ((long long)B * H * W * Cin * 2 >= (1LL << 32) || (long long)Cout * 9 * Cin * 2 >= (1LL << 32) || (long long)B * H * W >= (1LL << 31))
+        return PPN_E_UNSUPPORTED;
+    const int e = ppn::conv3x3_mfma_launch(x, w, bias, nullptr, B, H, W, Cin, Cout, 1, 1, w2, logits, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
+int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int32_t N, int32_t K, int32_t epilogue,
+                  int32_t persistent_blocks, void* stream) {
+    if (!a || !w || !c || M <= 0 || M >= (1LL << 31) || N <= 0 || (N % 8) != 0 || K < 128 || (K % 64) != 0 || epilogue < 0 || epilogue > 2 ||
+        (epilogue != 2 && !bias) || persistent_blocks < 0 || (persistent_blocks % 8) != 0)
+        return PPN_E_INVALID;
+    if (M * K * 2 >= (1LL << 32) || (long long)N * K * 2 >= (1LL << 32)) return PPN_E_UNSUPPORTED;
+    const int e = ppn::gemm_mfma_launch(a, w, bias, c, M, N, K, epilogue, persistent_blocks, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_resize_bilinear_u8(const uint8_t* in, int32_t n, int32_t H, int32_t W, int32_t outH, int32_t outW, uint8_t* tmp,
                            uint8_t* out, void* stream) {
     if (!in || n < 0 || H <= 0 || W <= 0 || outH <= 0 || outW <= 0 || !tmp || !out) return PPN_E_INVALID;

@@ -1,0 +1,393 @@
+// mfma_gemm.h — bf16 MFMA GEMM core for gfx950 (CDNA4), shared by the dense projections of SegNet's NAT layers
+// (reference SegNet/nat.py:62-85,111-120: qkv / proj / fc1 / fc2) and the implicit-GEMM 3x3 convolutions of the SETR-UP head
+// (reference SegNet/mmseg/decode_heads/setr_up_head.py:53-66).
+//
+//   C[m][n] = epilogue( sum_k A[m][k] * B[n][k] )       A: activations, K contiguous;  B: weights [N][K] (torch Linear layout)
+//
+// Block tile 256 x 256 x 64, 512 threads = 8 waves as 2 (M) x 4 (N), each wave a 128 x 64 output in 32 accumulators of
+// v_mfma_f32_16x16x32_bf16 (weights as the MFMA's A operand, activations as its B operand, so a lane holds 4 consecutive
+// n of one row m).  Both operand tiles go global -> LDS by 16-byte LDS-DMA (global_load_lds_dwordx4): the LDS image is
+// lane-linear per wave-instruction (8 rows x 128 B), the XOR swizzle chunk ^= (row >> 1) & 7 is applied on the SOURCE
+// address and again on the fragment read (conflict-free ds_read_b128 for the 16x16x32 operand maps).  Double-buffered
+// LDS (2 x 64 KiB); the K loop runs 4 phases per K-tile (one 64 x 32 output quadrant of every wave each), one
+// quarter-tile is issued per phase and only counted vmcnt waits leave four of them in flight across the barriers; the
+// two waves of a SIMD run staggered by one barrier (cdna_hip_programming.md, "The 256^2 8-phase template").
+//
+// A modes:  DENSE   A is [M][lda] row-major;
+//           CONV3   A is an NHWC image [B][H][W][Cin]; row m = output pixel (stride 1 or 2, padding 1), k = (ky*3 + kx)*Cin + ci;
+//                   out-of-image taps read a zero line.  Cin % 64 == 0.  B is then [N][9*Cin] with the same k order.
+// Epilogues: see Epi.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ppn {
+namespace gemm {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int BM = 256, BN = 256, BK = 64, NTHREADS = 512;
+constexpr int TILE_BYTES = 256 * 128;          // one operand tile: 256 rows x 64 bf16
+constexpr int BUF_BYTES = 2 * TILE_BYTES;      // A + B of one K-tile
+constexpr int LDS_BYTES = 2 * BUF_BYTES;       // 128 KiB: double buffer
+
+enum AMode { DENSE = 0, CONV3 = 1 };
+enum Epi {
+    EPI_BIAS = 0,        // C = acc + bias[n]
+    EPI_BIAS_GELU = 1,   // C = gelu(acc + bias[n])              (erf form, torch.nn.GELU default)
+    EPI_ACCUM = 2,       // C = C + acc                           (residual stream update, bias carried outside)
+    EPI_BIAS_RELU = 3,   // C = max(acc + bias[n], 0)             (conv + folded BatchNorm + ReLU)
+    EPI_RELU_DOT2 = 4    // logits[m][c] += sum_n max(acc + bias[n], 0) * w2[c][n], c = 0, 1  (the 1x1 classifier on top)
+};
+
+struct Params {
+    const __bf16* A;
+    const __bf16* B;
+    __bf16* C;
+    const float* bias;     // [N] float32 (may be null for EPI_ACCUM)
+    int M, N, K;
+    int lda, ldc;          // elements
+    // CONV3: input image [B][H][W][Cin], output pixels [B][Ho][Wo] (row m), stride 1 or 2, padding 1
+    int H, W, Cin, Ho, Wo, stride;
+    const __bf16* zero;    // >= 128 bytes of zeros
+    // EPI_RELU_DOT2
+    const float* w2;       // [2][N]
+    float* logits;         // [M][2], pre-filled with the classifier's bias
+};
+
+__device__ __forceinline__ void glds16(const void* g, unsigned char* lds_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
+}
+
+// erf-form GELU (torch.nn.GELU default).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of
+// the result): one v_exp, one v_rcp and six FMAs instead of libm's ~40-instruction erff — the epilogue holds 128 values per lane.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * __expf(-z * z);                     // erf(|x| / sqrt 2)
+    return 0.5f * x + 0.5f * fabsf(x) * e;                            // 0.5 x (1 + sign(x) e)
+}
+
+// What one output tile needs from this lane: source pointers of its 16-byte pieces of the four quarter-tiles.
+struct TileSrc {
+    uint32_t a[2][2];           // [unit][pass]: BYTE offset from p.A at k-tile 0 (CONV3: the centre tap of the pixel); < 2^32
+    uint32_t b[2][2];           // byte offset from p.B
+    uint32_t valid[2];          // CONV3: 9-bit masks of in-image taps, [unit], pass 0 in bits 0-8, pass 1 in bits 16-24
+    int m0, n0;
+};
+
+// Persistent form: `gridDim.x` blocks (one per CU) walk the tiles v = blockIdx.x, blockIdx.x + gridDim.x, ... and the
+// LDS-DMA stream runs across tile boundaries — the first two k-tiles of the next tile are in flight while the current
+// tile's epilogue stores go out, so neither the cold first loads nor the store tail idle the matrix pipe.  The epilogue's
+// stores sit in the same in-order vmcnt queue as the DMA: the three counted waits that follow it are widened by the number
+// of store instructions (EPI_STORES), which requires every lane's stores to issue — launch with gridDim.x == number of
+// tiles (one tile per block, nothing follows an epilogue) when M or N is not a multiple of 256.
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int nblk = tiles_m * tiles_n;
+    const int nk = p.K / BK;
+
+    // ---- staging geometry: a quarter-tile ("unit") = 128 rows of one operand = 16 row-blocks of 8 rows, 2 passes x 8 waves.
+    // A unit u = the rows every wave row reads as its part u (rows with bit 6 == u); B unit u = the columns every wave column
+    // reads as its part u (cols with bit 5 == u).  Lane l of a wave-instruction fills LDS bytes [16 l, 16 l + 16) of its
+    // row-block: row l >> 3, physical chunk l & 7, which holds logical chunk (l & 7) ^ ((row >> 1) & 7).
+    const int srow = lane >> 3;
+    auto a_block = [&](int u, int j) { return j * 16 + u * 8 + wave; };                       // A row-block: bit 3 == u
+    auto b_block = [&](int u, int j) { const int x4 = j * 8 + wave; return (x4 >> 2) * 8 + u * 4 + (x4 & 3); };   // bit 2 == u
+    // tile v of the launch order -> (m0, n0), XCD-aware: virtual ids v and v + 8 run on one XCD (gridDim.x % 8 == 0 or one tile
+    // per block); each XCD gets a contiguous run of tiles, n-tiles of one m-tile adjacent (A panel and weights from its L2)
+    auto tile_src = [&](int v, TileSrc& t) {
+        const int q = nblk >> 3, r = nblk & 7, x = v & 7;
+        const int id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (v >> 3);
+        t.m0 = (id / tiles_n) * BM;
+        t.n0 = (id % tiles_n) * BN;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            t.valid[u] = 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ra = a_block(u, j) * 8 + srow;
+                const int ca = ((lane & 7) ^ ((ra >> 1) & 7)) * 8;
+                int gm = t.m0 + ra;
+                if (gm >= p.M) gm = p.M - 1;                       // clamp: rows past M are computed and never stored
+                if (AMODE == DENSE) {
+                    t.a[u][j] = ((uint32_t)gm * (uint32_t)p.lda + ca) * 2u;
+                } else {
+                    const int xo = gm % p.Wo, yo = (gm / p.Wo) % p.Ho, img = gm / (p.Wo * p.Ho);
+                    const int x0 = xo * p.stride, y0 = yo * p.stride;                    // centre tap in the input image
+                    t.a[u][j] = ((uint32_t)((img * p.H + y0) * p.W + x0) * (uint32_t)p.Cin + ca) * 2u;
+                    uint32_t vm = 0;
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) {
+                        const int yy = y0 + tp / 3 - 1, xx = x0 + tp % 3 - 1;
+                        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) vm |= 1u << tp;
+                    }
+                    t.valid[u] |= vm << (16 * j);
+                }
+                const int rb = b_block(u, j) * 8 + srow;
+                const int cb = ((lane & 7) ^ ((rb >> 1) & 7)) * 8;
+                int gn = t.n0 + rb;
+                if (gn >= p.N) gn = p.N - 1;
+                t.b[u][j] = ((uint32_t)gn * (uint32_t)p.K + cb) * 2u;
+            }
+        }
+    };
+    const __bf16* zero_src = (AMODE == CONV3) ? p.zero + (lane & 7) * 8 : nullptr;
+    const int k_per_tap = (AMODE == CONV3) ? p.Cin / BK : 1;
+
+    // op: 0 = A, 1 = B.  Issues the two LDS-DMA instructions of unit `u` of k-tile `kt` of tile `t` into buffer `par`.
+    const char* baseA = reinterpret_cast<const char*>(p.A);
+    const char* baseB = reinterpret_cast<const char*>(p.B);
+    auto stage = [&](int op, int u, const TileSrc& t, int kt, int par) {
+        unsigned char* buf = lds + par * BUF_BYTES;
+        if (op == 0) {
+            if (AMODE == DENSE) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) glds16(baseA + (t.a[u][j] + (uint32_t)(kt * BK * 2)), buf + a_block(u, j) * 1024);
+            } else {
+                const int tap = kt / k_per_tap, c0 = (kt - tap * k_per_tap) * BK;
+                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                const int off = ((dy * p.W + dx) * p.Cin + c0) * 2;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const void* src = ((t.valid[u] >> (16 * j + tap)) & 1u) ? (const void*)(baseA + (t.a[u][j] + (uint32_t)off)) : (const void*)zero_src;
+                    glds16(src, buf + a_block(u, j) * 1024);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(baseB + (t.b[u][j] + (uint32_t)(kt * BK * 2)), buf + TILE_BYTES + b_block(u, j) * 1024);
+        }
+    };
+
+    // ---- fragment read addresses (bytes within a buffer), one per k-substep kk; part / tile offsets are immediates
+    const int frow = lane & 15, fq = lane >> 4, fswz = frow >> 1;
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int ch = ((kk * 4 + fq) ^ fswz) << 4;
+        a_rd[kk] = (wr * 128 + frow) * 128 + ch;
+        b_rd[kk] = TILE_BYTES + (wc * 64 + frow) * 128 + ch;
+    }
+
+    f32x4 acc[2][4][2][2];       // [A part][m tile][B part][n tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[i][a][j][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];       // A part in use [m tile][kk]; B parts [n tile][kk]
+
+    auto load_a = [&](const unsigned char* buf, int part) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                fa[mt][kk] = *reinterpret_cast<const bf16x8*>(buf + a_rd[kk] + (part * 64 + mt * 16) * 128);
+    };
+    auto load_b = [&](const unsigned char* buf, int part, bf16x8 (&fb)[2][2]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                fb[nt][kk] = *reinterpret_cast<const bf16x8*>(buf + b_rd[kk] + (part * 32 + nt * 16) * 128);
+    };
+    auto mma = [&](int ap, int bp, const bf16x8 (&fb)[2][2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[ap][mt][bp][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt][kk], fa[mt][kk], acc[ap][mt][bp][nt], 0, 0, 0);
+    };
+
+    // ---- K loop: 4 phases per k-tile, each {fragment reads + one quarter-tile of LDS-DMA + counted wait | barrier | 16 MFMA |
+    // barrier}.  Waves 4-7 (the second wave of every SIMD) run one barrier behind waves 0-3, so one group's MFMA segment
+    // covers the other group's read / DMA segment instead of both idling the matrix pipe together.
+    //   reads of k-tile g:  phase 1: A0, B0 (B0 stays in registers)   phase 2: B1   phase 3: A1   phase 4: none
+    //   DMA issue:          phase 1: B1(g+1)   phase 2: A1(g+1)   phase 3: A0(g+2)   phase 4: B0(g+2)
+    // (g runs over the k-tiles of all of this block's tiles.)  A unit is overwritten two or more phases after its last read
+    // (with the stagger, the other group's reads of it finish one barrier later), and it is waited for one phase before its
+    // first read: vmcnt(8) in phases 4, 1 and 2 leaves the four youngest quarter-tiles (8 DMA instructions per lane) in flight;
+    // the barrier of that phase publishes the rest.  After an epilogue the same three waits allow EPI_STORES more.
+    constexpr int EPI_STORES = (EPI == EPI_RELU_DOT2) ? 16 : 32;       // vector-memory instructions an epilogue leaves in the queue
+    const int G = gridDim.x;
+    const int my_tiles = (nblk - (int)blockIdx.x + G - 1) / G;
+    const int total = my_tiles * nk;                                    // k-tiles in this block's stream
+    TileSrc cur, nxt;
+    tile_src(blockIdx.x, cur);
+    nxt = cur;
+    if (my_tiles > 1) tile_src(blockIdx.x + G, nxt);
+    stage(0, 0, cur, 0, 0); stage(1, 0, cur, 0, 0); stage(1, 1, cur, 0, 0); stage(0, 1, cur, 0, 0);
+    stage(0, 0, cur, 1, 1); stage(1, 0, cur, 1, 1);                    // nk >= 2
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();           // the stagger: this group's barriers pair with the other's next ones
+
+#define PPN_GEMM_WAIT(full, wide) do {                                                          \
+        if (!(full)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
+        else if (wide) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + EPI_STORES) : "memory");  \
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                   \
+    } while (0)
+#define PPN_GEMM_MMA(ap, bp, fb) do {                          \
+        __builtin_amdgcn_s_barrier();                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_sched_barrier(0);                     \
+        __builtin_amdgcn_s_setprio(1);                         \
+        mma(ap, bp, fb);                                       \
+        __builtin_amdgcn_s_setprio(0);                         \
+        __builtin_amdgcn_s_barrier();                          \
+    } while (0)
+
+    int g = 0;
+    for (int it = 0; it < my_tiles; ++it) {
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            const unsigned char* buf = lds + (g & 1) * BUF_BYTES;
+            const bool wide = (kt == 0) && (it > 0);                    // an epilogue's stores are in the queue
+            const bool has1 = g + 1 < total, has2 = g + 2 < total;
+            // k-tile g + 1 / g + 2 of the stream: in this tile, or the head of the next one
+            const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
+            const int k1 = in1 ? kt + 1 : 0, k2 = in2 ? kt + 2 : kt + 2 - nk;
+            // phase 1
+            load_b(buf, 0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(buf, 0);
+            if (has1) { if (in1) stage(1, 1, cur, k1, (g + 1) & 1); else stage(1, 1, nxt, k1, (g + 1) & 1); }
+            PPN_GEMM_WAIT(has1, wide);
+            PPN_GEMM_MMA(0, 0, fb0);
+            // phase 2
+            load_b(buf, 1, fb1);
+            if (has1) { if (in1) stage(0, 1, cur, k1, (g + 1) & 1); else stage(0, 1, nxt, k1, (g + 1) & 1); }
+            PPN_GEMM_WAIT(has1, wide);
+            PPN_GEMM_MMA(0, 1, fb1);
+            // phase 3
+            load_a(buf, 1);
+            if (has2) { if (in2) stage(0, 0, cur, k2, g & 1); else stage(0, 0, nxt, k2, g & 1); }
+            PPN_GEMM_MMA(1, 1, fb1);
+            // phase 4: no fragment reads (A1 and B0 are in registers)
+            if (has2) { if (in2) stage(1, 0, cur, k2, g & 1); else stage(1, 0, nxt, k2, g & 1); }
+            PPN_GEMM_WAIT(has2, wide);
+            PPN_GEMM_MMA(1, 0, fb0);
+        }
+
+        // ---- epilogue of this tile, straight from the accumulators: a lane holds 4 consecutive n of one row m = 8 bytes of
+        // bf16; the four column tiles of a wave complete each row's 128-byte line (merged in L2).  Exactly EPI_STORES
+        // vector-memory instructions stay in the queue behind it.
+        const int m0 = cur.m0, n0 = cur.n0;
+        float4 bv[2][2], w0v[2][2], w1v[2][2];
+#pragma unroll
+        for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                int n = n0 + wc * 64 + bp * 32 + nt * 16 + fq * 4;
+                const bool in = n < p.N;                                          // N % 4 == 0: a group of 4 is in or out
+                if (n > p.N - 4) n = p.N - 4;
+                bv[bp][nt] = (EPI != EPI_ACCUM) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (EPI == EPI_RELU_DOT2) {
+                    w0v[bp][nt] = in ? *reinterpret_cast<const float4*>(p.w2 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    w1v[bp][nt] = in ? *reinterpret_cast<const float4*>(p.w2 + p.N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        if (EPI == EPI_ACCUM) {
+            // C += acc: all 32 reads of the old values first (they drain the queue once), then 32 stores
+            uint2 prev[2][4][2][2];
+#pragma unroll
+            for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const int m = m0 + wr * 128 + ap * 64 + mt * 16 + frow;
+                            const int n = n0 + wc * 64 + bp * 32 + nt * 16 + fq * 4;
+                            prev[ap][mt][bp][nt] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint2*>(p.C + (size_t)m * p.ldc + n) : make_uint2(0u, 0u);
+                        }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const bf16x4 s4 = __builtin_bit_cast(bf16x4, prev[ap][mt][bp][nt]);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[ap][mt][bp][nt][r] += (float)s4[r];
+                        }
+        }
+#pragma unroll
+        for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = m0 + wr * 128 + ap * 64 + mt * 16 + frow;
+                if (EPI == EPI_RELU_DOT2) {
+                    // max(acc + bias, 0) . w2[c] over this wave's 64 columns: reduce over the 4 lane quarters, then one float
+                    // atomic per (row, class) per wave (8 per row over the two column blocks' four wave columns)
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const f32x4 a4 = acc[ap][mt][bp][nt];
+                            const float4 b4 = bv[bp][nt], u4 = w0v[bp][nt], w4 = w1v[bp][nt];
+                            const float v0 = fmaxf(a4[0] + b4.x, 0.f), v1 = fmaxf(a4[1] + b4.y, 0.f), v2 = fmaxf(a4[2] + b4.z, 0.f), v3 = fmaxf(a4[3] + b4.w, 0.f);
+                            s0 += v0 * u4.x + v1 * u4.y + v2 * u4.z + v3 * u4.w;
+                            s1 += v0 * w4.x + v1 * w4.y + v2 * w4.z + v3 * w4.w;
+                        }
+                    s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
+                    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+                    if (fq == 0 && m < p.M) {
+                        atomicAdd(p.logits + (size_t)m * 2, s0);
+                        atomicAdd(p.logits + (size_t)m * 2 + 1, s1);
+                    }
+                } else {
+#pragma unroll
+                    for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const int n = n0 + wc * 64 + bp * 32 + nt * 16 + fq * 4;
+                            const f32x4 v = acc[ap][mt][bp][nt];
+                            const float4 b4 = bv[bp][nt];
+                            float o[4] = {v[0] + b4.x, v[1] + b4.y, v[2] + b4.z, v[3] + b4.w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                if (EPI == EPI_BIAS_GELU) o[r] = gelu_erf(o[r]);
+                                if (EPI == EPI_BIAS_RELU) o[r] = fmaxf(o[r], 0.f);
+                            }
+                            const bf16x4 w = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                            if (m < p.M && n < p.N) *reinterpret_cast<bf16x4*>(p.C + (size_t)m * p.ldc + n) = w;
+                        }
+                }
+#pragma unroll
+                for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[ap][mt][bp][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        // next tile
+        cur = nxt;
+        if (it + 2 < my_tiles) tile_src(blockIdx.x + (it + 2) * G, nxt);
+    }
+#undef PPN_GEMM_WAIT
+#undef PPN_GEMM_MMA
+    if (wr == 0) __builtin_amdgcn_s_barrier();           // rebalance the barrier count of the two groups
+}
+
+}  // namespace gemm
+}  // namespace ppn

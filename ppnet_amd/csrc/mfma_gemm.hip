@@ -1,0 +1,67 @@
+// mfma_gemm.hip — launchers of the bf16 MFMA GEMM core (mfma_gemm.h): the implicit-GEMM 3x3 convolutions of the SETR-UP head
+// and the NAT downsamplers (reference SegNet/mmseg/decode_heads/setr_up_head.py:53-66, SegNet/nat.py:48-59), and the dense
+// projection form (SegNet/nat.py:62-85,111-120).
+#include "ppn_kernels.h"
+#include "mfma_gemm.h"
+
+namespace ppn {
+
+namespace {
+template <int AMODE, int EPI>
+int launch(const gemm::Params& p, int persistent, hipStream_t stream) {
+    static std::atomic<int> attr{0};
+    if (!attr.load()) {
+        const hipError_t e = hipFuncSetAttribute((const void*)gemm::gemm_bf16_kernel<AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 gemm::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr.store(1);
+    }
+    const int tiles = ((p.M + gemm::BM - 1) / gemm::BM) * ((p.N + gemm::BN - 1) / gemm::BN);
+    int grid = tiles;
+    if (persistent > 0 && tiles > persistent && p.M % gemm::BM == 0 && p.N % gemm::BN == 0) grid = persistent;   // one block per CU
+    hipLaunchKernelGGL((gemm::gemm_bf16_kernel<AMODE, EPI>), dim3(grid), dim3(gemm::NTHREADS), gemm::LDS_BYTES, stream, p);
+    return (int)hipGetLastError();
+}
+
+const __bf16* zero_line() {
+    static std::atomic<void*> z{nullptr};
+    void* p = z.load();
+    if (!p) {
+        void* q = nullptr;
+        if (hipMalloc(&q, 256) != hipSuccess || hipMemset(q, 0, 256) != hipSuccess) return nullptr;
+        void* expect = nullptr;
+        if (!z.compare_exchange_strong(expect, q)) { (void)hipFree(q); q = expect; }
+        p = q;
+    }
+    return (const __bf16*)p;
+}
+}  // namespace
+
+int conv3x3_mfma_launch(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int stride,
+                        int relu, const float* w2, float* logits, hipStream_t stream) {
+    gemm::Params p{};
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    p.A = (const __bf16*)x; p.B = (const __bf16*)w; p.C = (__bf16*)y; p.bias = bias;
+    p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin; p.lda = Cin; p.ldc = Cout;
+    p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.stride = stride;
+    p.zero = zero_line();
+    if (!p.zero) return (int)hipErrorOutOfMemory;
+    p.w2 = w2; p.logits = logits;
+    if (logits) return launch<gemm::CONV3, gemm::EPI_RELU_DOT2>(p, 0, stream);
+    return relu ? launch<gemm::CONV3, gemm::EPI_BIAS_RELU>(p, 0, stream) : launch<gemm::CONV3, gemm::EPI_BIAS>(p, 0, stream);
+}
+
+int gemm_mfma_launch(const void* a, const void* w, const float* bias, void* c, long long M, int N, int K, int epi, int persistent,
+                     hipStream_t stream) {
+    gemm::Params p{};
+    p.A = (const __bf16*)a; p.B = (const __bf16*)w; p.C = (__bf16*)c; p.bias = bias;
+    p.M = (int)M; p.N = N; p.K = K; p.lda = K; p.ldc = N;
+    switch (epi) {
+        case 0: return launch<gemm::DENSE, gemm::EPI_BIAS>(p, persistent, stream);
+        case 1: return launch<gemm::DENSE, gemm::EPI_BIAS_GELU>(p, persistent, stream);
+        case 2: return launch<gemm::DENSE, gemm::EPI_ACCUM>(p, persistent, stream);
+        default: return -1;
+    }
+}
+
+}  // namespace ppn

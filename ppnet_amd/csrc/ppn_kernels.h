@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/ppnet_hip.h"
 
 #ifndef PPN_PATHS_THREADS
@@ -73,6 +74,11 @@ int conv3x3_to1_launch(const void* x, const float* w, float bias, void* y, int B
 int seg_labels_launch(const void* lo, uint8_t* labels, int B, int h, int w, int Ho, int Wo, int dtype, hipStream_t stream);
 int grid_image_launch(const uint8_t* grid, void* img, long long n, const float* mean, const float* stdv, int dtype, hipStream_t stream);
 int bias_act_launch(void* x, const void* bias, long long n, int C, float slope, int dtype, hipStream_t stream);
+
+int conv3x3_mfma_launch(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int stride,
+                        int relu, const float* w2, float* logits, hipStream_t stream);
+int gemm_mfma_launch(const void* a, const void* w, const float* bias, void* c, long long M, int N, int K, int epi, int persistent,
+                     hipStream_t stream);
 
 __global__ void label_masks_kernel(ppn_paths_t paths, ppn_maps_t maps, int placements, int R, int bound, uint8_t* mask_path,
                                    uint8_t* mask_space);

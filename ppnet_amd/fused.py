@@ -180,3 +180,61 @@ def grid_to_image(grid_u8, mean, std, dtype):
         rc = L.lib.ppn_grid_to_image(_p(g), _p(img), g.numel(), m3, s3, _DT[dtype], ctypes.c_void_p(torch.cuda.current_stream(g.device).cuda_stream))
     L.check(rc, "ppn_grid_to_image")
     return img.permute(0, 3, 1, 2)
+
+
+def conv3x3_mfma(x_nchw_cl, w_k, bias32, stride=1, relu=False):
+    """3x3 convolution (padding 1) of a channels_last bfloat16 [B,Cin,H,W] tensor on the MFMA implicit-GEMM kernel
+    (ppn_conv3x3_mfma_bf16).  w_k: the weight as [Cout,3,3,Cin] bfloat16 (weight.permute(0,2,3,1).contiguous()); bias32:
+    float32 [Cout].  Returns channels_last [B,Cout,Ho,Wo]."""
+    if not x_nchw_cl.is_cuda or x_nchw_cl.dtype != torch.bfloat16:
+        raise RuntimeError("ppnet_amd.fused.conv3x3_mfma: bfloat16 GPU tensors only")
+    x = x_nchw_cl.permute(0, 2, 3, 1)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, H, W, Cin = x.shape
+    Cout = w_k.shape[0]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    assert w_k.dtype == torch.bfloat16 and w_k.is_contiguous() and w_k.shape == (Cout, 3, 3, Cin)
+    assert bias32.dtype == torch.float32 and bias32.is_contiguous() and bias32.numel() == Cout
+    y = torch.empty(B, Ho, Wo, Cout, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = L.lib.ppn_conv3x3_mfma_bf16(_p(x), _p(w_k), _p(bias32), _p(y), B, H, W, Cin, Cout, stride, 1 if relu else 0,
+                                         ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    L.check(rc, "ppn_conv3x3_mfma_bf16")
+    return y.permute(0, 3, 1, 2)
+
+
+def conv3x3_relu_classify2(x_nchw_cl, w_k, bias32, w2_32, b2_32):
+    """relu(conv3x3(x) + bias) followed by a 2-class 1x1 classifier, without writing the Cout-channel activation
+    (ppn_conv3x3_relu_classify2_bf16).  w2_32 [2,Cout], b2_32 [2] float32.  Returns float32 logits [B,2,H,W]."""
+    if not x_nchw_cl.is_cuda or x_nchw_cl.dtype != torch.bfloat16:
+        raise RuntimeError("ppnet_amd.fused.conv3x3_relu_classify2: bfloat16 GPU tensors only")
+    x = x_nchw_cl.permute(0, 2, 3, 1)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, H, W, Cin = x.shape
+    Cout = w_k.shape[0]
+    logits = b2_32.to(torch.float32).repeat(B * H * W).view(B, H, W, 2).contiguous()
+    with torch.cuda.device(x.device):
+        rc = L.lib.ppn_conv3x3_relu_classify2_bf16(_p(x), _p(w_k), _p(bias32), _p(w2_32), _p(logits), B, H, W, Cin, Cout,
+                                                   ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    L.check(rc, "ppn_conv3x3_relu_classify2_bf16")
+    return logits.permute(0, 3, 1, 2)
+
+
+def gemm_bf16(a, w, bias32, epilogue="bias", out=None, persistent_blocks=0):
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T) on the MFMA kernel (ppn_gemm_bf16).  epilogue: "bias", "bias_gelu", or "accum"
+    (out += a @ w^T, bias unused)."""
+    epi = {"bias": 0, "bias_gelu": 1, "accum": 2}[epilogue]
+    M, K = a.shape
+    N = w.shape[0]
+    assert a.is_cuda and a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.is_contiguous() and w.is_contiguous()
+    if out is None:
+        assert epi != 2
+        out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    assert out.is_contiguous() and out.shape == (M, N)
+    with torch.cuda.device(a.device):
+        rc = L.lib.ppn_gemm_bf16(_p(a), _p(w), _p(bias32), _p(out), M, N, K, epi, persistent_blocks,
+                                 ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream))
+    L.check(rc, "ppn_gemm_bf16")
+    return out

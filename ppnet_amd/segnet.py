@@ -16,6 +16,22 @@ from . import fused
 from .na import NeighborhoodAttention2D
 
 
+def _use_mfma_conv(x, conv):
+    """The hand-written MFMA implicit-GEMM convolution (ppn_conv3x3_mfma_bf16) serves bfloat16 inference on the GPU for 3x3,
+    padding 1, Cin % 64 == 0, Cout % 256 == 0 (whole 256-wide output tiles); everything else stays on the library."""
+    import os
+    return (x.is_cuda and x.dtype == torch.bfloat16 and not conv.training and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 256 == 0
+            and conv.weight.dtype == torch.bfloat16 and not os.environ.get("PPNET_LIBRARY_CONV"))
+
+
+def _mfma_weights(conv):
+    """(weight as [Cout,3,3,Cin] bfloat16 — the k order of the implicit GEMM — and the bias as float32, zeros if none)."""
+    w = conv.weight.detach().permute(0, 2, 3, 1).contiguous()
+    b = conv.bias.detach().float().contiguous() if conv.bias is not None else torch.zeros(conv.out_channels, dtype=torch.float32, device=w.device)
+    return w, b
+
+
 class ConvTokenizer(nn.Module):
     def __init__(self, in_chans=3, embed_dim=96, norm_layer=None):
         super().__init__()
@@ -34,7 +50,14 @@ class ConvDownsampler(nn.Module):
         self.reduction = nn.Conv2d(dim, 2 * dim, 3, 2, 1, bias=False)
         self.norm = norm_layer(2 * dim)
 
+    _mfma = None          # (weight [2C,3,3,C] bf16, zero bias float32) for the MFMA implicit-GEMM kernel, built on first use
+
     def forward(self, x):                      # x [B,H,W,C] contiguous == a channels_last [B,C,H,W] view: no layout copies
+        if _use_mfma_conv(x, self.reduction):
+            if self._mfma is None or self._mfma[0].device != x.device:
+                self._mfma = _mfma_weights(self.reduction)
+            y = fused.conv3x3_mfma(x.permute(0, 3, 1, 2), self._mfma[0], self._mfma[1], stride=2, relu=False)
+            return fused.layer_norm(y.permute(0, 2, 3, 1), self.norm)
         return fused.layer_norm(self.reduction(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1), self.norm)
 
 
@@ -265,6 +288,9 @@ class SETRUPHead(nn.Module):
         x = inputs[self.in_index]
         # LayerNorm over channels (setr_up_head.py:73-76) on the NHWC view; stays channels_last for the convolutions
         x = fused.layer_norm(x.permute(0, 2, 3, 1), self.norm).permute(0, 3, 1, 2)
+        prepared = all(isinstance(up[0].bn, nn.Identity) and up[0].conv.bias is not None for up in self.up_convs)
+        if prepared and all(_use_mfma_conv(x, up[0].conv) for up in self.up_convs) and self.conv_seg.out_channels == 2:
+            return self._forward_mfma(x, lowres)
         for up in self.up_convs[:-1]:
             cm = up[0]
             if isinstance(cm.bn, nn.Identity) and cm.conv.bias is not None:  # prepared: the folded-BN bias rides in the upsample kernel
@@ -283,6 +309,24 @@ class SETRUPHead(nn.Module):
             y = conv(x)
         lo = self.conv_seg(y).contiguous()
         return lo if lowres else up(lo)                                      # 2 channels: the library bilinear kernel
+
+
+    _mfma = None
+
+    def _forward_mfma(self, x, lowres):
+        """Prepared bfloat16 inference on the hand-written MFMA kernels: every ConvModule is one implicit-GEMM launch with the
+        folded-BatchNorm bias and the ReLU in its epilogue, and the last one also applies the 1x1 classifier (commuted in front
+        of the last up-sampling, as in forward()) so the 512-channel activation at the highest resolution is never written."""
+        if self._mfma is None or self._mfma[0][0].device != x.device:
+            cs = self.conv_seg
+            self._mfma = [_mfma_weights(up[0].conv) for up in self.up_convs] + \
+                         [(cs.weight.detach().float().reshape(cs.out_channels, -1).contiguous(), cs.bias.detach().float().contiguous())]
+        for i, up in enumerate(self.up_convs[:-1]):
+            x = up[1](fused.conv3x3_mfma(x, self._mfma[i][0], self._mfma[i][1], stride=1, relu=True))
+        w2, b2 = self._mfma[-1]
+        n = len(self.up_convs) - 1
+        lo = fused.conv3x3_relu_classify2(x, self._mfma[n][0], self._mfma[n][1], w2, b2).to(x.dtype).contiguous()
+        return lo if lowres else self.up_convs[-1][1](lo)
 
 
 class UPerHead(nn.Module):
