@@ -318,6 +318,23 @@ int ppn_conv3x3_mfma_bf16(const void* x, const void* w, const float* bias, void*
  * never written. */
 int ppn_conv3x3_relu_classify2_bf16(const void* x, const void* w, const float* bias, const float* w2, float* logits, int32_t B, int32_t H,
                                     int32_t W, int32_t Cin, int32_t Cout, void* stream);
+/* GenNet's 24-channel stride-2 stages on MFMA, NHWC bfloat16, BatchNorm folded by the caller, bias + LeakyReLU fused:
+ *   transposed == 0 (ae_vit.py:24-36, Conv2d(24, 24, 3, 2, 1)): x [B][H][W][24] -> y [B][H/2][W/2][24];
+ *        w [32][224] bfloat16, row co (24..31 zero), column (ky*3+kx)*24 + ci (216..223 zero);
+ *   transposed != 0 (ae_vit.py:44-55, ConvTranspose2d(24, 24, 3, 2, 1, output_padding=1)): x [B][H][W][24] -> y [B][2H][2W][24];
+ *        w [4][32][96] bfloat16: output parity class (oy & 1) * 2 + (ox & 1), row co, column (dy*2+dx)*24 + ci over the 2x2
+ *        input block under the 2x2 output block, zero where the class has no tap (ppnet_amd/gennet.py packs both).
+ * bias [32] float32 (24..31 zero). */
+int ppn_gennet_conv_s2_bf16(const void* x, const void* w, const float* bias, void* y, int32_t B, int32_t H, int32_t W, float negative_slope,
+                            int32_t transposed, void* stream);
+/* The ViT blocks of GenNet's AE-ViT (ae_vit.py:38-42,68-70; vit.py:88-161: pre-LN attention + MLP residual blocks, dim 24, 3 heads,
+ * MLP x4, LayerNorm eps 1e-6, erf GELU) as one kernel: x, y [B][N][24] bfloat16 token rows (the NHWC feature map), N <= 1024,
+ * N % 8 == 0.  One workgroup per problem holds the residual stream in registers (float32) across all n_blocks blocks and the
+ * block's K / V in LDS.  params: [n_blocks][PPN_GENNET_BLOCK_PARAMS] float32, per block in this order:
+ *   norm1.weight[24] norm1.bias[24] attn.qkv.weight[72][24] attn.qkv.bias[72] attn.proj.weight[24][24] attn.proj.bias[24]
+ *   norm2.weight[24] norm2.bias[24] mlp.fc1.weight[96][24] mlp.fc1.bias[96] mlp.fc2.weight TRANSPOSED [96][24] mlp.fc2.bias[24] */
+#define PPN_GENNET_BLOCK_PARAMS 7224
+int ppn_gennet_trunk_bf16(const void* x, void* y, const float* params, int32_t B, int32_t N, int32_t n_blocks, void* stream);
 /* Dense projection c[M][N] = epilogue(a[M][K] . w[N][K]^T) on bfloat16 (torch.nn.Linear layout; SegNet/nat.py:62-85,111-120).
  * epilogue: 0 = + bias[n]; 1 = gelu(+ bias[n]) (erf form); 2 = c += (the residual stream accumulates, bias unused).
  * K % 64 == 0, K >= 128, N % 8 == 0.  persistent_blocks: 0 = one tile per workgroup; else the number of workgroups (a multiple

@@ -444,6 +444,23 @@ int ppn_conv3x3_relu_classify2_bf16(const void* x, const void* w, const float* b
     return PPN_OK;
 }
 
+int ppn_gennet_conv_s2_bf16(const void* x, const void* w, const float* bias, void* y, int32_t B, int32_t H, int32_t W, float negative_slope,
+                            int32_t transposed, void* stream) {
+    if (!x || !w || !bias || !y || B <= 0 || H <= 0 || W <= 0 || (!transposed && ((H | W) & 1))) return PPN_E_INVALID;
+    if ((long long)B * H * W * 4 >= (1LL << 40)) return PPN_E_UNSUPPORTED;
+    const int e = transposed ? ppn::gennet_dec_conv_launch(x, w, bias, y, B, H, W, negative_slope, (hipStream_t)stream)
+                             : ppn::gennet_enc_conv_launch(x, w, bias, y, B, H, W, negative_slope, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
+int ppn_gennet_trunk_bf16(const void* x, void* y, const float* params, int32_t B, int32_t N, int32_t n_blocks, void* stream) {
+    if (!x || !y || !params || B <= 0 || N <= 0 || N > 1024 || (N % 8) != 0 || n_blocks <= 0) return PPN_E_INVALID;
+    const int e = ppn::gennet_trunk_launch(x, y, params, B, N, n_blocks, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int32_t N, int32_t K, int32_t epilogue,
                   int32_t persistent_blocks, void* stream) {
     if (!a || !w || !c || M <= 0 || M >= (1LL << 31) || N <= 0 || (N % 8) != 0 || K < 128 || (K % 64) != 0 || epilogue < 0 || epilogue > 2 ||

@@ -1,0 +1,260 @@
+// gennet_trunk.hip — the three ViT blocks of GenNet's AE-ViT as ONE kernel (reference GenNet/networks/ae_vit.py:38-42,68-70 and
+// vit.py:88-111 Attention.forward, :127-133 Mlp.forward, :158-161 Block.forward; dim 24, 3 heads of 8, MLP x4, LayerNorm eps
+// 1e-6, erf GELU, pre-norm residual blocks).
+//
+// The whole token set of a planning problem is N <= 1024 tokens x 24 channels: one 512-thread workgroup per problem keeps the
+// residual stream in registers (float32, two tokens per thread) for all three blocks, K and V of the block in LDS (bfloat16;
+// 96 KiB), and touches HBM twice: the 48-byte token rows in, the 48-byte token rows out.  Replaces, per batch, 3 library
+// attention launches, 12 projection GEMMs, 6 LayerNorm launches and the residual adds between them.
+//   LN1 -> qkv (weights are wave-uniform: scalar loads) -> K rows / V key-pairs to LDS, q packed in registers
+//   attention per head: every K / V read is a broadcast (all lanes the same key) serving both of a thread's queries;
+//       q.k on v_dot2_f32_bf16 over channel pairs, online softmax in base 2 (q carries scale * log2 e), rescale only when a
+//       chunk of 8 keys raises a running maximum in the wave, P rounded to bfloat16 pairs, P.V on v_dot2 over key pairs
+//   proj + residual, LN2, fc1 -> GELU -> fc2 streamed one hidden unit at a time, residual
+#include <hip/hip_runtime.h>
+#include "ppn_device.h"
+#include "ppn_kernels.h"
+
+namespace ppn {
+
+namespace {
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+constexpr int TC = 24, TH = 3, THD = 8, THID = 96;
+// float32 parameter block of one ViT block, in this order
+constexpr int O_LN1W = 0, O_LN1B = O_LN1W + TC, O_WQKV = O_LN1B + TC, O_BQKV = O_WQKV + 3 * TC * TC, O_WPROJ = O_BQKV + 3 * TC,
+              O_BPROJ = O_WPROJ + TC * TC, O_LN2W = O_BPROJ + TC, O_LN2B = O_LN2W + TC, O_W1 = O_LN2B + TC, O_B1 = O_W1 + THID * TC,
+              O_W2T = O_B1 + THID, O_B2 = O_W2T + THID * TC, BLOCK_PARAMS = O_B2 + TC;
+static_assert(BLOCK_PARAMS == PPN_GENNET_BLOCK_PARAMS, "parameter block layout");
+
+__device__ __forceinline__ float gelu_fast(float x) {                     // erf GELU, A&S 7.1.26 (|err| <= 1.5e-7), see mfma_gemm.h
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x + 0.5f * fabsf(x) * e;
+}
+
+__device__ __forceinline__ void layer_norm24(const float (&x)[TC], const float* __restrict__ w, const float* __restrict__ b, float (&y)[TC]) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < TC; ++c) s += x[c];
+    const float mean = s * (1.0f / TC);
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < TC; ++c) { const float d = x[c] - mean; v += d * d; }
+    const float rstd = rsqrtf(v * (1.0f / TC) + 1e-6f);
+#pragma unroll
+    for (int c = 0; c < TC; ++c) y[c] = (x[c] - mean) * rstd * w[c] + b[c];
+}
+}  // namespace
+
+// x, y: [B][N][24] bfloat16 (NHWC feature map = token rows).  params: [n_blocks][BLOCK_PARAMS] float32.
+__global__ __launch_bounds__(512) void gennet_trunk_kernel(const __bf16* __restrict__ xin, __bf16* __restrict__ yout,
+                                                           const float* __restrict__ params, int N, int n_blocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tl[];
+    // K rows: [N][24] bf16 (48 B per key, head h at +16 h);  V: [head][N/2 key pairs][8 channels] dwords {v[2j][c], v[2j+1][c]}
+    unsigned char* Kl = tl;
+    uint32_t* Vl = reinterpret_cast<uint32_t*>(tl + (size_t)N * 48);
+    const int tid = threadIdx.x;
+    const int prob = blockIdx.x;
+    const int tok[2] = {tid, tid + 512};
+    const bool live[2] = {tok[0] < N, tok[1] < N};
+    const int half_n = N >> 1;
+
+    float x[2][TC];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (live[s]) {
+            const __bf16* src = xin + ((size_t)prob * N + tok[s]) * TC;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + 8 * p);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[s][8 * p + e] = (float)v[e];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < TC; ++c) x[s][c] = 0.f;
+        }
+    }
+
+    const float qscale = 0.35355339059327373f * 1.4426950408889634f;      // head_dim^-0.5 * log2(e)
+    for (int blk = 0; blk < n_blocks; ++blk) {
+        const float* P = params + (size_t)blk * BLOCK_PARAMS;
+        float y[2][TC];
+        uint32_t qp[2][TH][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) layer_norm24(x[s], P + O_LN1W, P + O_LN1B, y[s]);
+        if (blk > 0) __syncthreads();                                     // everyone is done reading the previous block's K / V
+        // ---- qkv: 9 groups of 8 outputs (part, head); weights are uniform -> scalar loads
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+#pragma unroll
+            for (int h = 0; h < TH; ++h) {
+                float o8[2][THD];
+#pragma unroll
+                for (int c = 0; c < THD; ++c) {
+                    const int row = part * TC + h * THD + c;
+                    const float* wr = P + O_WQKV + row * TC;
+                    float a0 = P[O_BQKV + row], a1 = a0;
+#pragma unroll
+                    for (int i = 0; i < TC; ++i) { a0 += wr[i] * y[0][i]; a1 += wr[i] * y[1][i]; }
+                    o8[0][c] = a0; o8[1][c] = a1;
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (part == 0) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) qp[s][h][c] = pack_bf16x2(o8[s][2 * c] * qscale, o8[s][2 * c + 1] * qscale);
+                    } else if (live[s]) {
+                        if (part == 1) {
+                            *reinterpret_cast<uint4*>(Kl + (size_t)tok[s] * 48 + h * 16) =
+                                make_uint4(pack_bf16x2(o8[s][0], o8[s][1]), pack_bf16x2(o8[s][2], o8[s][3]), pack_bf16x2(o8[s][4], o8[s][5]),
+                                           pack_bf16x2(o8[s][6], o8[s][7]));
+                        } else {
+                            uint16_t* vp = reinterpret_cast<uint16_t*>(Vl + ((size_t)h * half_n + (tok[s] >> 1)) * THD) + (tok[s] & 1);
+#pragma unroll
+                            for (int c = 0; c < THD; ++c) vp[2 * c] = (uint16_t)(pack_bf16x2(o8[s][c], 0.f) & 0xffffu);
+                        }
+                    }
+                }
+            }
+        __syncthreads();
+
+        // ---- attention: each thread's two queries against all N keys, head by head
+        float att[2][TC];
+#pragma unroll
+        for (int h = 0; h < TH; ++h) {
+            float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f}, o[2][THD];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int c = 0; c < THD; ++c) o[s][c] = 0.f;
+            const unsigned char* kh = Kl + h * 16;
+            const uint32_t* vh = Vl + (size_t)h * half_n * THD;
+            for (int k0 = 0; k0 < N; k0 += 8) {
+                // all 16 reads of the chunk are issued before the first use (broadcast reads: every lane the same key)
+                uint4 kv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) kv[i] = *reinterpret_cast<const uint4*>(kh + (size_t)(k0 + i) * 48);
+                uint4 va[4], vb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t* vrow = vh + (size_t)((k0 >> 1) + j) * THD;
+                    va[j] = *reinterpret_cast<const uint4*>(vrow); vb[j] = *reinterpret_cast<const uint4*>(vrow + 4);
+                }
+                float sc[2][8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        float a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, qp[s][h][0]), __builtin_bit_cast(bf2, kv[i].x), 0.f, false);
+                        a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, qp[s][h][1]), __builtin_bit_cast(bf2, kv[i].y), a, false);
+                        a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, qp[s][h][2]), __builtin_bit_cast(bf2, kv[i].z), a, false);
+                        sc[s][i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, qp[s][h][3]), __builtin_bit_cast(bf2, kv[i].w), a, false);
+                    }
+                }
+                bool grow = false;
+                float cm[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    cm[s] = fmaxf(fmaxf(fmaxf(sc[s][0], sc[s][1]), fmaxf(sc[s][2], sc[s][3])), fmaxf(fmaxf(sc[s][4], sc[s][5]), fmaxf(sc[s][6], sc[s][7])));
+                    grow = grow || cm[s] > m[s];
+                }
+                if (__any(grow)) {                                         // wave-uniform: rare after the first chunks
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const float mn = fmaxf(m[s], cm[s]);
+                        const float corr = __builtin_amdgcn_exp2f(m[s] - mn);
+                        m[s] = mn;
+                        l[s] *= corr;
+#pragma unroll
+                        for (int c = 0; c < THD; ++c) o[s][c] *= corr;
+                    }
+                }
+                uint32_t pp[2][4];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float pe[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { pe[i] = __builtin_amdgcn_exp2f(sc[s][i] - m[s]); l[s] += pe[i]; }     // raw v_exp_f32: arguments <= 0
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pp[s][j] = pack_bf16x2(pe[2 * j], pe[2 * j + 1]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t vv[8] = {va[j].x, va[j].y, va[j].z, va[j].w, vb[j].x, vb[j].y, vb[j].z, vb[j].w};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int c = 0; c < THD; ++c)
+                            o[s][c] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pp[s][j]), __builtin_bit_cast(bf2, vv[c]), o[s][c], false);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float inv = 1.0f / l[s];
+#pragma unroll
+                for (int c = 0; c < THD; ++c) att[s][h * THD + c] = o[s][c] * inv;
+            }
+        }
+
+        // ---- proj + residual
+#pragma unroll
+        for (int oc = 0; oc < TC; ++oc) {
+            const float* wr = P + O_WPROJ + oc * TC;
+            float a0 = P[O_BPROJ + oc], a1 = a0;
+#pragma unroll
+            for (int i = 0; i < TC; ++i) { a0 += wr[i] * att[0][i]; a1 += wr[i] * att[1][i]; }
+            x[0][oc] += a0; x[1][oc] += a1;
+        }
+        // ---- MLP: one hidden unit at a time, never materialised
+#pragma unroll
+        for (int s = 0; s < 2; ++s) layer_norm24(x[s], P + O_LN2W, P + O_LN2B, y[s]);
+        float acc[2][TC];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < TC; ++c) acc[s][c] = P[O_B2 + c];
+        for (int j = 0; j < THID; ++j) {
+            const float* w1 = P + O_W1 + j * TC;
+            const float* w2 = P + O_W2T + j * TC;
+            float h0 = P[O_B1 + j], h1 = h0;
+#pragma unroll
+            for (int i = 0; i < TC; ++i) { h0 += w1[i] * y[0][i]; h1 += w1[i] * y[1][i]; }
+            h0 = gelu_fast(h0); h1 = gelu_fast(h1);
+#pragma unroll
+            for (int c = 0; c < TC; ++c) { acc[0][c] += h0 * w2[c]; acc[1][c] += h1 * w2[c]; }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < TC; ++c) x[s][c] += acc[s][c];
+    }
+
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (!live[s]) continue;
+        __bf16* dst = yout + ((size_t)prob * N + tok[s]) * TC;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint4*>(dst + 8 * p) = make_uint4(pack_bf16x2(x[s][8 * p], x[s][8 * p + 1]), pack_bf16x2(x[s][8 * p + 2], x[s][8 * p + 3]),
+                                                                pack_bf16x2(x[s][8 * p + 4], x[s][8 * p + 5]), pack_bf16x2(x[s][8 * p + 6], x[s][8 * p + 7]));
+    }
+}
+
+int gennet_trunk_launch(const void* x, void* y, const float* params, int B, int N, int n_blocks, hipStream_t stream) {
+    const size_t lds = (size_t)N * 48 + (size_t)3 * (N / 2) * 8 * 4;
+    static std::atomic<int> attr{0};
+    if (!attr.load()) {
+        const hipError_t e = hipFuncSetAttribute((const void*)gennet_trunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr.store(1);
+    }
+    hipLaunchKernelGGL(gennet_trunk_kernel, dim3(B), dim3(512), lds, stream, (const __bf16*)x, (__bf16*)y, params, N, n_blocks);
+    return (int)hipGetLastError();
+}
+
+}  // namespace ppn

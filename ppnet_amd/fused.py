@@ -238,3 +238,40 @@ def gemm_bf16(a, w, bias32, epilogue="bias", out=None, persistent_blocks=0):
                                  ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream))
     L.check(rc, "ppn_gemm_bf16")
     return out
+
+
+def gennet_conv_s2(x_nchw_cl, w_packed, bias32, negative_slope, transposed):
+    """GenNet's 24-channel stride-2 conv (transposed=False) / transposed conv (True) + bias + LeakyReLU on MFMA
+    (ppn_gennet_conv_s2_bf16).  x: channels_last bfloat16 [B,24,H,W]; w_packed / bias32 from gennet.pack_s2_weights."""
+    if not x_nchw_cl.is_cuda or x_nchw_cl.dtype != torch.bfloat16:
+        raise RuntimeError("ppnet_amd.fused.gennet_conv_s2: bfloat16 GPU tensors only")
+    x = x_nchw_cl.permute(0, 2, 3, 1)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, H, W, C = x.shape
+    assert C == 24
+    Ho, Wo = (2 * H, 2 * W) if transposed else (H // 2, W // 2)
+    y = torch.empty(B, Ho, Wo, C, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = L.lib.ppn_gennet_conv_s2_bf16(_p(x), _p(w_packed), _p(bias32), _p(y), B, H, W, float(negative_slope), 1 if transposed else 0,
+                                           ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    L.check(rc, "ppn_gennet_conv_s2_bf16")
+    return y.permute(0, 3, 1, 2)
+
+
+def gennet_trunk(x_nchw_cl, params32, n_blocks):
+    """GenNet's ViT blocks as one kernel (ppn_gennet_trunk_bf16): channels_last bfloat16 [B,24,H,W] in and out; params32 from
+    gennet.pack_trunk_params."""
+    if not x_nchw_cl.is_cuda or x_nchw_cl.dtype != torch.bfloat16:
+        raise RuntimeError("ppnet_amd.fused.gennet_trunk: bfloat16 GPU tensors only")
+    x = x_nchw_cl.permute(0, 2, 3, 1)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, H, W, C = x.shape
+    assert C == 24 and params32.dtype == torch.float32 and params32.is_contiguous() and params32.numel() == n_blocks * 7224
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = L.lib.ppn_gennet_trunk_bf16(_p(x), _p(y), _p(params32), B, H * W, n_blocks,
+                                         ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    L.check(rc, "ppn_gennet_trunk_bf16")
+    return y.permute(0, 3, 1, 2)

@@ -58,6 +58,49 @@ def _stage(conv):
     return nn.Sequential(conv, nn.BatchNorm2d(conv.out_channels), nn.LeakyReLU())
 
 
+def pack_trunk_params(blocks):
+    """The float32 parameter blocks ppn_gennet_trunk_bf16 reads (include/ppnet_hip.h), from the ViT blocks' modules."""
+    out = []
+    for b in blocks:
+        f = lambda t: t.detach().float().reshape(-1)
+        out += [f(b.norm1.weight), f(b.norm1.bias), f(b.attn.qkv.weight), f(b.attn.qkv.bias), f(b.attn.proj.weight), f(b.attn.proj.bias),
+                f(b.norm2.weight), f(b.norm2.bias), f(b.mlp.fc1.weight), f(b.mlp.fc1.bias), f(b.mlp.fc2.weight.detach().float().t().contiguous()),
+                f(b.mlp.fc2.bias)]
+    return torch.cat(out).contiguous()
+
+
+def pack_s2_weights(conv):
+    """(weights, bias) in the layout ppn_gennet_conv_s2_bf16 reads, from a 24 -> 24 3x3 stride-2 Conv2d / ConvTranspose2d
+    (padding 1, output_padding 1) whose BatchNorm is already folded."""
+    C = 24
+    w = conv.weight.detach().float()
+    dev = w.device
+    bias = torch.zeros(32, dtype=torch.float32, device=dev)
+    if conv.bias is not None:
+        bias[:C] = conv.bias.detach().float()
+    if isinstance(conv, nn.ConvTranspose2d):                   # weight [ci][co][ky][kx]; out(2iy+a) <- in(iy+dy) through tap ky
+        tap = lambda a, d: (1 if d == 0 else None) if a == 0 else (2 if d == 0 else 0)
+        wt = torch.zeros(4, 32, 96, dtype=torch.float32, device=dev)
+        for a in range(2):
+            for b in range(2):
+                for dy in range(2):
+                    for dx in range(2):
+                        ky, kx = tap(a, dy), tap(b, dx)
+                        if ky is None or kx is None:
+                            continue
+                        p = dy * 2 + dx
+                        wt[a * 2 + b, :C, p * C:(p + 1) * C] = w[:, :, ky, kx].t()
+        return wt.to(torch.bfloat16).contiguous(), bias
+    wk = torch.zeros(32, 224, dtype=torch.float32, device=dev)  # weight [co][ci][ky][kx] -> [co][(ky*3+kx)*24 + ci]
+    wk[:C, :216] = w.permute(0, 2, 3, 1).reshape(C, 216)
+    return wk.to(torch.bfloat16).contiguous(), bias
+
+
+def _is_s2_stage(c):
+    return (c.in_channels == 24 and c.out_channels == 24 and c.kernel_size == (3, 3) and c.stride == (2, 2) and c.padding == (1, 1)
+            and c.dilation == (1, 1) and c.groups == 1 and (not isinstance(c, nn.ConvTranspose2d) or c.output_padding == (1, 1)))
+
+
 class _FusedStage(nn.Module):
     """A conv stage after prepare_inference(): the (transposed) convolution with the BatchNorm folded in runs WITHOUT its
     bias on the library, and bias + LeakyReLU are one in-place pass of the HIP kernel (ppn_bias_act_nhwc) instead of the
@@ -67,6 +110,7 @@ class _FusedStage(nn.Module):
         super().__init__()
         self.conv, self.slope = conv, slope
         self._f32 = None                                  # (device, weight, bias) as float32 for the direct 1-channel kernel
+        self._s2 = None                                   # (device, packed weight, bias) for the MFMA stride-2 kernels
 
     def forward(self, x):
         c = self.conv
@@ -79,6 +123,13 @@ class _FusedStage(nn.Module):
             if self._f32 is None or self._f32[0] != x.device:
                 self._f32 = (x.device, c.weight.detach().float().contiguous(), c.bias.detach().float().contiguous())
             return fused.conv3x3_c1(x, self._f32[1], self._f32[2], self.slope)
+        import os
+        if x.dtype == torch.bfloat16 and _is_s2_stage(c) and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0 and not os.environ.get("PPNET_LIBRARY_CONV"):
+            # the 24-channel stride-2 stages: MFMA kernel with the weights in registers, bias + LeakyReLU in its epilogue
+            from . import fused
+            if self._s2 is None or self._s2[0] != x.device:
+                self._s2 = (x.device,) + pack_s2_weights(c)
+            return fused.gennet_conv_s2(x, self._s2[1], self._s2[2], self.slope, isinstance(c, nn.ConvTranspose2d))
         if isinstance(c, nn.ConvTranspose2d):
             y = F.conv_transpose2d(x, c.weight, None, c.stride, c.padding, c.output_padding, c.groups, c.dilation)
         else:
@@ -104,6 +155,7 @@ class AEViT(nn.Module):
         self.dec_conv = nn.ModuleList(_stage(nn.ConvTranspose2d(dim, dim, 3, 2, 1, output_padding=1)) for _ in range(n_down))
         self.conv_final = nn.Conv2d(dim, out_channels, 3, 1, 1)
         self._final_f32 = None                            # set by prepare_inference(): (device, float32 weight, float bias)
+        self._trunk = None                                # float32 parameter blocks of the fused ViT-trunk kernel (built on first use)
 
     def prepare_inference(self):
         """After the checkpoint is loaded: fold every eval-mode BatchNorm into the (transposed) convolution in front of
@@ -130,8 +182,17 @@ class AEViT(nn.Module):
         for blk in self.enc_conv:
             x = blk(x)
         B, C, H, W = x.shape
-        t = self.vit_blocks(x.flatten(2).transpose(1, 2))                    # feature2token / token2feature, base.py:43-52
-        x = t.transpose(1, 2).reshape(B, C, H, W)
+        import os
+        if (x.is_cuda and x.dtype == torch.bfloat16 and self._final_f32 is not None and C == 24 and H * W <= 1024 and (H * W) % 8 == 0
+                and self.vit_blocks[0].attn.num_heads == 3 and not os.environ.get("PPNET_LIBRARY_TRUNK")):
+            # prepared bfloat16 inference: the three ViT blocks are one kernel (residual stream in registers, K / V in LDS)
+            from . import fused
+            if self._trunk is None or self._trunk.device != x.device:
+                self._trunk = pack_trunk_params(self.vit_blocks).to(x.device)
+            x = fused.gennet_trunk(x.contiguous(memory_format=torch.channels_last), self._trunk, len(self.vit_blocks))
+        else:
+            t = self.vit_blocks(x.flatten(2).transpose(1, 2))                # feature2token / token2feature, base.py:43-52
+            x = t.transpose(1, 2).reshape(B, C, H, W)
         for blk in self.dec_conv:
             x = blk(x)
         c = self.conv_final

@@ -71,3 +71,49 @@ def test_gemm_bf16_epilogues_vs_torch(M, N, K, persistent):
     out = fused.gemm_bf16(a, w, None, "accum", out=c, persistent_blocks=persistent)
     assert out is c
     _close(c, c0.float() + lin)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 8, 8), (3, 32, 32), (5, 64, 48), (4, 256, 256)])
+def test_gennet_stride2_stages_vs_torch(B, H, W):
+    """ppn_gennet_conv_s2_bf16 (encoder Conv2d(24,24,3,2,1) and decoder ConvTranspose2d(24,24,3,2,1,output_padding=1), bias +
+    LeakyReLU fused) against float32 torch on the same bf16 operands."""
+    import torch.nn as nn
+    from ppnet_amd import fused
+    from ppnet_amd.gennet import pack_s2_weights
+    torch.manual_seed(B + H)
+    for transposed in (False, True):
+        conv = (nn.ConvTranspose2d(24, 24, 3, 2, 1, output_padding=1) if transposed else nn.Conv2d(24, 24, 3, 2, 1)).cuda()
+        with torch.no_grad():
+            conv.weight.copy_(conv.weight.to(BF).float())
+        x = torch.randn(B, 24, H, W, device="cuda").to(BF).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            want = F.leaky_relu(conv(x.float()), 0.01)
+        wp, bp = pack_s2_weights(conv)
+        got = fused.gennet_conv_s2(x, wp, bp, 0.01, transposed)
+        assert got.shape == want.shape and got.dtype == BF
+        _close(got, want)
+
+
+@pytest.mark.parametrize("B,side", [(3, 32), (2, 28), (5, 8)])
+def test_gennet_trunk_vs_torch_blocks(B, side):
+    """ppn_gennet_trunk_bf16 (three pre-LN ViT blocks in one kernel, vit.py:88-161) against the module's own float32 forward on
+    the same (bf16-representable) weights and input.  Inside the kernel q, k, v and the probabilities are bfloat16 (float32
+    accumulation), the residual stream float32: tolerance 2 % of the output scale."""
+    from ppnet_amd import fused
+    from ppnet_amd.gennet import _Block, pack_trunk_params
+    torch.manual_seed(side)
+    blocks = torch.nn.Sequential(*[_Block(24, 3, 4) for _ in range(3)]).cuda().eval()
+    with torch.no_grad():
+        for p in blocks.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.5, 0.5)
+            p.copy_(p.to(BF).float())
+        for b in blocks:
+            b.norm1.weight.uniform_(0.7, 1.3); b.norm2.weight.uniform_(0.7, 1.3)
+    x = torch.randn(B, 24, side, side, device="cuda").to(BF).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        t = blocks.cpu()(x.float().cpu().flatten(2).transpose(1, 2))          # CPU float32: plain torch ops, no HIP LayerNorm kernel
+        want = t.transpose(1, 2).reshape(B, 24, side, side)
+    got = fused.gennet_trunk(x, pack_trunk_params(blocks).cuda(), 3)
+    assert got.shape == want.shape and got.dtype == BF
+    _close(got.cpu(), want, rel=2e-2)
