@@ -310,6 +310,18 @@ int ppn_na2d_fwd(const void* qkv, const float* rpb, void* out, int32_t B, int32_
     return ppn_na2d_fwd_padded(qkv, rpb, out, B, H, W, H, W, heads, dilation, scale, dtype, stream);
 }
 
+int ppn_na2d_bwd(const void* qkv, const float* rpb, const void* dout, void* dqkv, float* drpb, float* workspace, int32_t B, int32_t H,
+                 int32_t W, int32_t heads, int32_t dilation, float scale, int32_t dtype, void* stream) {
+    if (!qkv || !rpb || !dout || !dqkv || !drpb || !workspace || B <= 0 || heads <= 0 || dilation < 1 || H < 7 * dilation || W < 7 * dilation ||
+        (dtype != 0 && dtype != 1))
+        return PPN_E_INVALID;
+    const long long n = (long long)B * heads * H * W * 49;
+    const int e = ppn::na2d_bwd_launch(qkv, rpb, dout, dqkv, drpb, workspace, workspace + n, B, H, W, heads, dilation, scale, dtype,
+                                       (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 static int na2d_checked(const void* qkv, const void* pad_kv, const float* rpb, void* out, int32_t B, int32_t H, int32_t W, int32_t Hr,
                         int32_t Wr, int32_t heads, int32_t dilation, float scale, int32_t dtype, void* stream) {
     if (!qkv || !rpb || !out || B <= 0 || heads <= 0 || dilation < 1 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;

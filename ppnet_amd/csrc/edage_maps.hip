@@ -277,7 +277,12 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
                     poddf[ci] = (float)rx; poddf[128 + ci] = (float)ry;
                 }
             }
+#ifdef PPN_NT_STORES
+            typedef double f64x2_t __attribute__((ext_vector_type(2)));
+            if (O.pathpoint) __builtin_nontemporal_store(f64x2_t{rx, ry}, reinterpret_cast<f64x2_t*>(O.pathpoint + ((size_t)m * PPN_PATH_POINTS + q) * 2));
+#else
             if (O.pathpoint) *reinterpret_cast<double2*>(O.pathpoint + ((size_t)m * PPN_PATH_POINTS + q) * 2) = make_double2(rx, ry);
+#endif
         }
         if (tid < PPN_SEGS + 1) {                                             // MapGenerate.py:70-74
             const double x = P.segpoint_image[((size_t)pj * 11 + tid) * 2] - half;
@@ -590,9 +595,17 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
                         q2 = (q2 & ~m2) | (m2 & 0x8080808080808080ull); q3 = (q3 & ~m3) | (m3 & 0x8080808080808080ull);
                     }
                 }
+#ifdef PPN_NT_STORES
+                // write-once output: non-temporal stores (A/B build, tools/r02_nt.sh)
+                typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                u32x4_t* dst = reinterpret_cast<u32x4_t*>(g + (size_t)w * 32);
+                __builtin_nontemporal_store(u32x4_t{(uint32_t)q0, (uint32_t)(q0 >> 32), (uint32_t)q1, (uint32_t)(q1 >> 32)}, dst);
+                __builtin_nontemporal_store(u32x4_t{(uint32_t)q2, (uint32_t)(q2 >> 32), (uint32_t)q3, (uint32_t)(q3 >> 32)}, dst + 1);
+#else
                 uint4* dst = reinterpret_cast<uint4*>(g + (size_t)w * 32);
                 dst[0] = make_uint4((uint32_t)q0, (uint32_t)(q0 >> 32), (uint32_t)q1, (uint32_t)(q1 >> 32));
                 dst[1] = make_uint4((uint32_t)q2, (uint32_t)(q2 >> 32), (uint32_t)q3, (uint32_t)(q3 >> 32));
+#endif
             }
         }
         PPN_STAMP(7);

@@ -6,6 +6,20 @@
 
 namespace ppn {
 
+// >= 256 bytes of zeros in device memory (the source of out-of-image taps / out-of-halo slots)
+const void* zero_line() {
+    static std::atomic<void*> z{nullptr};
+    void* p = z.load();
+    if (!p) {
+        void* q = nullptr;
+        if (hipMalloc(&q, 256) != hipSuccess || hipMemset(q, 0, 256) != hipSuccess) return nullptr;
+        void* expect = nullptr;
+        if (!z.compare_exchange_strong(expect, q)) { (void)hipFree(q); q = expect; }
+        p = q;
+    }
+    return p;
+}
+
 namespace {
 template <int AMODE, int EPI>
 int launch(const gemm::Params& p, int persistent, hipStream_t stream) {
@@ -23,18 +37,6 @@ int launch(const gemm::Params& p, int persistent, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-const __bf16* zero_line() {
-    static std::atomic<void*> z{nullptr};
-    void* p = z.load();
-    if (!p) {
-        void* q = nullptr;
-        if (hipMalloc(&q, 256) != hipSuccess || hipMemset(q, 0, 256) != hipSuccess) return nullptr;
-        void* expect = nullptr;
-        if (!z.compare_exchange_strong(expect, q)) { (void)hipFree(q); q = expect; }
-        p = q;
-    }
-    return (const __bf16*)p;
-}
 }  // namespace
 
 int conv3x3_mfma_launch(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int stride,
@@ -44,7 +46,7 @@ int conv3x3_mfma_launch(const void* x, const void* w, const float* bias, void* y
     p.A = (const __bf16*)x; p.B = (const __bf16*)w; p.C = (__bf16*)y; p.bias = bias;
     p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin; p.lda = Cin; p.ldc = Cout;
     p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.stride = stride;
-    p.zero = zero_line();
+    p.zero = (const __bf16*)zero_line();
     if (!p.zero) return (int)hipErrorOutOfMemory;
     p.w2 = w2; p.logits = logits;
     if (logits) return launch<gemm::CONV3, gemm::EPI_RELU_DOT2>(p, 0, stream);

@@ -20,6 +20,7 @@
 // accumulation): 1680 dot2 per query instead of 784 dot2 + 1.6 k unpack + 1.6 k FMA — 0.85 -> 0.69 ms on the 64x64
 // level at batch 256.  The float32 path keeps float32 probabilities and FMAs.
 #include <hip/hip_bf16.h>
+#include <cstdlib>
 #include "ppn_device.h"
 #include "ppn_kernels.h"
 
@@ -361,6 +362,18 @@ static int launch_typed(const void* qkv, const void* pad_kv, const float* rpb, v
 
 int na2d_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil, float scale,
                 int dtype, hipStream_t stream) {
+    // bfloat16 runs on the matrix cores (na2d_mfma.hip); PPNET_NA_VALU=1 keeps the v_dot2 kernel of this file (A/B runs)
+    static const bool valu = getenv("PPNET_NA_VALU") != nullptr;
+    const long long elems = (long long)B * (pad_kv ? Hr : H) * (pad_kv ? Wr : W) * 3 * heads * HD;       // 32-bit offsets inside
+    // The MFMA kernel takes the layers whose dilation groups fill 16 x 16 query regions (measured on MI355X, batch 256, tools/
+    // na_timing.py: 0.52 vs 0.66 ms at 64 x 64, 0.22 vs 0.26 at 32 x 32, 0.10 vs 0.11 at 16 x 16); on the 8 x 8 and 4 x 4 groups of
+    // the dilated layers this file's kernel is the faster one (it skips the padded keys; 0.23 vs 0.27, 0.056 vs 0.060 ms).
+    // PPNET_NA_MFMA=1 sends every bfloat16 launch to the MFMA kernel.
+    static const bool all_mfma = getenv("PPNET_NA_MFMA") != nullptr;
+    const int hq_ = (Hr + dil - 1) / dil, wq_ = (Wr + dil - 1) / dil;
+    auto util = [&](int t) { return (double)(hq_ * wq_) / ((double)((hq_ + t - 1) / t * t) * ((wq_ + t - 1) / t * t)); };
+    const bool region16 = !(util(8) > util(16) + 0.05) && !(util(4) > util(16) + 0.05);
+    if (dtype == 1 && !valu && elems < 0xffffffffLL && (region16 || all_mfma)) return na2d_mfma_launch(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
     return dtype == 0 ? launch_typed<float>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream)
                       : launch_typed<__hip_bfloat16>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
 }

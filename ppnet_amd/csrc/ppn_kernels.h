@@ -64,6 +64,12 @@ __global__ void philox_doubles_kernel(uint64_t seed, uint32_t stream_id, uint64_
 int na2d_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
                 float scale, int dtype, hipStream_t stream);
 
+const void* zero_line();
+int na2d_mfma_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
+                     float scale, hipStream_t stream);
+int na2d_bwd_launch(const void* qkv, const float* rpb, const void* dout, void* dqkv, float* drpb, float* attn_p, float* attn_ds, int B, int H, int W,
+                    int heads, int dil, float scale, int dtype, hipStream_t stream);
+
 int norm_launch(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,
                 long long rows, int C, float eps, int dtype, int Hr, int Wr, int Hp, int Wp, const void* xoff, hipStream_t stream);
 

@@ -68,6 +68,40 @@ def _launch(qkv, rpb, heads, dilation, scale, real_hw, pad_kv, padded_hw, dtype)
     return out
 
 
+class _NA2DFunction(torch.autograd.Function):
+    """qkv [B,H,W,3C] (H, W >= 7 * dilation), rpb [heads,13,13] float32 -> [B,H,W,C]; backward on ppn_na2d_bwd."""
+
+    @staticmethod
+    def forward(ctx, qkv, rpb, heads, dilation, scale):
+        qkv = qkv.contiguous()
+        rpb32 = rpb.detach().to(torch.float32).contiguous()
+        ctx.save_for_backward(qkv, rpb32)
+        ctx.meta = (heads, dilation, scale, rpb.dtype)
+        return na2d_forward(qkv.detach(), rpb32, heads, dilation, scale)
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, rpb32 = ctx.saved_tensors
+        heads, dilation, scale, rpb_dtype = ctx.meta
+        B, H, W, C3 = qkv.shape
+        dout = dout.to(qkv.dtype).contiguous()
+        dqkv = torch.empty_like(qkv)
+        drpb = torch.zeros_like(rpb32)
+        ws = torch.empty(2 * B * heads * H * W * 49, dtype=torch.float32, device=qkv.device)
+        dtype = {torch.float32: 0, torch.bfloat16: 1}[qkv.dtype]
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        with torch.cuda.device(qkv.device):
+            rc = L.lib.ppn_na2d_bwd(p(qkv), p(rpb32), p(dout), p(dqkv), p(drpb), p(ws), B, H, W, heads, dilation, float(scale), dtype,
+                                    ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream))
+        L.check(rc, "ppn_na2d_bwd")
+        return dqkv, drpb.to(rpb_dtype), None, None, None
+
+
+def na2d_autograd(qkv, rpb, heads, dilation, scale):
+    """Differentiable neighbourhood attention on qkv [B,H,W,3C] (the caller pads to 7 * dilation first, as NATTEN's module does)."""
+    return _NA2DFunction.apply(qkv, rpb, heads, dilation, scale)
+
+
 class NeighborhoodAttention2D(nn.Module):
     def __init__(self, dim, kernel_size, dilation=None, num_heads=1, qkv_bias=True, qk_scale=None, attn_drop=0.0,
                  proj_drop=0.0):
@@ -104,6 +138,14 @@ class NeighborhoodAttention2D(nn.Module):
         if real_hw is not None:
             o = na2d_forward(self.qkv(x), self.rpb, self.num_heads, self.dilation, self.scale, real_hw)
             return self.proj_drop(self.proj(o))
+        if torch.is_grad_enabled() and (x.requires_grad or self.rpb.requires_grad):
+            # training: NATTEN's module order — zero-pad bottom / right to kernel * dilation, qkv, NA over the padded grid
+            # (differentiable: ppn_na2d_bwd), crop, proj
+            B, H, W, _ = x.shape
+            pad = self.padded_hw(H, W)
+            xp = x if pad is None else F.pad(x, (0, 0, 0, pad[1] - W, 0, pad[0] - H))
+            o = na2d_autograd(self.qkv(xp), self.rpb, self.num_heads, self.dilation, self.scale)
+            return self.proj_drop(self.proj(o[:, :H, :W]))
         return self.proj_drop(self.proj(self.attend(x)))
 
     def _rpb_f32(self):

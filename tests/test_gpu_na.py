@@ -116,3 +116,58 @@ def test_virtual_padding_equals_materialised_padding(dev, H, W, Hr, Wr, d, heads
         assert (got.float() - want.float()).abs().max() < 2e-2
         ref = NA.na2d_from_qkv(full.float().cpu().numpy(), rpb.cpu().numpy(), heads, 7, d, 32 ** -0.5)[:, :Hr, :Wr]
         assert np.abs(got.float().cpu().numpy() - ref).max() < 3e-2
+
+
+@pytest.mark.parametrize("B,H,W,heads,d", [(2, 9, 11, 2, 1), (1, 16, 14, 2, 2), (2, 7, 7, 1, 1), (1, 21, 24, 1, 3)])
+def test_na2d_backward_vs_fp64_autograd(dev, B, H, W, heads, d):
+    """ppn_na2d_bwd (dQ, dK, dV, dRPB) against autograd through the float64 gather definition of the op (oracle/segnet_ref.py
+    na_fp64, itself checked against the brute-force oracle) — borders, dilation groups of unequal size, several heads."""
+    import torch
+    from oracle import segnet_ref as SR
+    from ppnet_amd.na import na2d_autograd
+    torch.manual_seed(H * W + d)
+    C = heads * 32
+    qkv = torch.randn(B, H, W, 3 * C, device=dev, dtype=torch.float32, requires_grad=True)
+    rpb = (torch.randn(heads, 13, 13, device=dev) * 0.5).requires_grad_(True)
+    gout = torch.randn(B, H, W, C, device=dev)
+    out = na2d_autograd(qkv, rpb, heads, d, 32 ** -0.5)
+    out.backward(gout)
+    # float64 definition: identity projections around the gather (x -> qkv is the identity on a 3C-wide "token")
+    q64 = qkv.detach().double().requires_grad_(True)
+    r64 = rpb.detach().double().requires_grad_(True)
+
+    def ref(qkv_, rpb_):
+        Hp, Wp = qkv_.shape[1], qkv_.shape[2]
+        ri, bi = SR._axis_tables(Hp, 7, d, qkv_.device)
+        cj, bj = SR._axis_tables(Wp, 7, d, qkv_.device)
+        bias = rpb_[:, bi[:, None, :, None], bj[None, :, None, :]]
+        outs = []
+        for b in range(qkv_.shape[0]):
+            t = qkv_[b].view(Hp, Wp, 3, heads, 32).permute(2, 3, 0, 1, 4)
+            q, kk, v = t[0] * 32 ** -0.5, t[1], t[2]
+            kg, vg = kk[:, ri][:, :, :, cj], v[:, ri][:, :, :, cj]
+            p = torch.softmax((torch.einsum("hijc,hiajbc->hijab", q, kg) + bias).reshape(heads, Hp, Wp, 49), dim=-1).view(heads, Hp, Wp, 7, 7)
+            outs.append(torch.einsum("hijab,hiajbc->hijc", p, vg).permute(1, 2, 0, 3).reshape(Hp, Wp, C))
+        return torch.stack(outs)
+    want = ref(q64, r64)
+    assert (out.detach().double() - want.detach()).abs().max() < 1e-4
+    want.backward(gout.double())
+    assert (qkv.grad.double() - q64.grad).abs().max() < 2e-4 * max(1.0, float(q64.grad.abs().max()))
+    assert (rpb.grad.double() - r64.grad).abs().max() < 2e-4 * max(1.0, float(r64.grad.abs().max()))
+
+
+def test_na_module_trains_through_padding(dev):
+    """The module's training path (pad -> qkv -> NA -> crop -> proj) is differentiable end to end on a padded dilated layer and
+    its forward equals the inference path (virtual padding)."""
+    import torch
+    from ppnet_amd.na import NeighborhoodAttention2D
+    torch.manual_seed(5)
+    m = NeighborhoodAttention2D(64, 7, dilation=2, num_heads=2).to(dev)
+    x = torch.randn(2, 9, 10, 64, device=dev, requires_grad=True)              # 9 x 10 < 14: padded to 14 x 14
+    y = m(x)
+    with torch.no_grad():
+        y_inf = m(x.detach())
+    assert (y.detach() - y_inf).abs().max() < 1e-4
+    y.square().mean().backward()
+    for t in (x.grad, m.rpb.grad, m.qkv.weight.grad, m.proj.weight.grad):
+        assert t is not None and torch.isfinite(t).all() and float(t.abs().max()) > 0
