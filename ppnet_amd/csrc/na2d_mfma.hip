@@ -45,7 +45,7 @@ template <int RT>
 __global__ __launch_bounds__(RT == 16 ? 512 : 256) void na2d_mfma_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pad_kv,
                                                            const float* __restrict__ rpb, __bf16* __restrict__ out, int B, int H, int W, int Hr,
                                                            int Wr, int heads, int dil, float scale, int tiles_y, int tiles_x, int total_tiles,
-                                                           const __bf16* __restrict__ zero, int dbg) {
+                                                           const __bf16* __restrict__ zero) {
     constexpr int NTHR = RT == 16 ? 512 : 256, NWAVES = NTHR / 64;
     constexpr int TPW = RT == 4 ? 4 : 1;                                   // tiles per workgroup
     constexpr int NT = NTHR / TPW;                                         // threads staging one tile
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(RT == 16 ? 512 : 256) void na2d_mfma_kernel(const _
 
     // ---- stage K and V: every piece has an address — its token's row, the padded token (virtual padding: k / v = the qkv
     // bias) or a line of zeros (slack columns, rows beyond the halo; V must stay finite) — so the loads are unconditional
-    if (tile_in && dbg != 2) {
+    if (tile_in) {
         const int chunk = tid & 3;
         uint4 kq[ITER], vq[ITER];
 #pragma unroll
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(RT == 16 ? 512 : 256) void na2d_mfma_kernel(const _
         }
     }
     __syncthreads();
-    if (!tile_in || dbg == 1) return;
+    if (!tile_in) return;
 
     const int q4 = j >> 2, p4 = j & 3;                                     // transposed read: this lane addresses row q4, columns 4 p4 ..
     const float NEG = -1.0e30f;
@@ -255,7 +255,7 @@ static int launch_rt(const void* qkv, const void* pad_kv, const float* rpb, void
     if (wgs >= (1LL << 31)) return -1;
     const dim3 grid((unsigned)wgs, 1, 1);
     hipLaunchKernelGGL(na2d_mfma_kernel<RT>, grid, dim3(RT == 16 ? 512 : 256), lds, stream, (const __bf16*)qkv, (const __bf16*)pad_kv, rpb, (__bf16*)out, B, H, W, Hr,
-                       Wr, heads, dil, scale, tiles_y, tiles_x, (int)total, zero, getenv("PPNET_NA_DBG") ? atoi(getenv("PPNET_NA_DBG")) : 0);
+                       Wr, heads, dil, scale, tiles_y, tiles_x, (int)total, zero);
     return (int)hipGetLastError();
 }
 

@@ -1,7 +1,9 @@
 #!/bin/bash
-# Round-end measurement set (run on the GPU box from the repo root): bench line, kernel stats, HBM traffic, SQ counters,
-# PPNet per-kernel breakdown.  Outputs land in gpurun_out/final/; copy the summaries to profiles/.
+# Round-end measurement set (run on the GPU box from the repo root): bench line, kernel stats, HBM traffic and SQ counters of the
+# maps kernel, PPNet per-kernel breakdown, matrix-pipe counters of the MFMA kernels, NA kernel counters.
+# Outputs land in gpurun_out/final/; copy the summaries to profiles/ (tools/final_profile.sh TAG names them).
 set -e
+TAG=${1:-r02}
 ROOT=$PWD; OUT=$ROOT/gpurun_out/final; mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py --steps 50 > $OUT/bench.json 2> $OUT/bench.err
@@ -10,10 +12,22 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 $ROOT
 cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ppnet > $OUT/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ppnet > $OUT/pw.log 2>&1
-cd $ROOT && python tools/collect_traffic.py /tmp/pmc_fetch /tmp/pmc_write r01 > $OUT/traffic.log && cp profiles/traffic_maps_kernel.json $OUT/ && cd /tmp
+cd $ROOT && python tools/collect_traffic.py /tmp/pmc_fetch /tmp/pmc_write $TAG > $OUT/traffic.log && cp profiles/traffic_maps_kernel.json $OUT/ && cd /tmp
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY --output-format csv -d /tmp/sq -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ppnet > $OUT/sq.log 2>&1
 python3 $ROOT/tools/pmc_avg.py /tmp/sq > $OUT/pmc_sq_counters.txt
+# PPNet: per-kernel time of one steady-state batch, then the matrix-pipe counters of the same run (separate PMC pass)
 rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -- python3 $ROOT/tools/profile_ppnet.py 256 > $OUT/pp.log 2>&1
-python3 $ROOT/tools/kernel_breakdown.py /tmp/pp extract_paths_kernel 2 30 > $OUT/ppnet_kernel_breakdown_b256.txt
+python3 $ROOT/tools/kernel_breakdown.py /tmp/pp extract_paths_kernel 2 45 > $OUT/ppnet_kernel_breakdown_b256.txt
 grep "ms per batch" $OUT/pp.log >> $OUT/ppnet_kernel_breakdown_b256.txt
-tail -c 600 $OUT/bench.json
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d /tmp/ppm -- python3 $ROOT/tools/profile_ppnet.py 256 > $OUT/ppm.log 2>&1
+python3 $ROOT/tools/pmc_avg.py /tmp/ppm | grep -i "gemm_bf16\|na2d\|gennet\|Cijk" > $OUT/ppnet_pmc_mfma.txt || true
+# NA kernels on every (level, dilation) shape + their counters
+python3 $ROOT/tools/na_timing.py > $OUT/na_timing.txt 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY --output-format csv -d /tmp/na_sq -- python3 $ROOT/tools/na_timing.py > $OUT/na_sq.log 2>&1
+python3 $ROOT/tools/pmc_avg.py /tmp/na_sq | grep na2d > $OUT/na_pmc_sq.txt || true
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/na_f -- python3 $ROOT/tools/na_timing.py > $OUT/na_f.log 2>&1
+python3 $ROOT/tools/pmc_avg.py /tmp/na_f | grep na2d > $OUT/na_pmc_fetch.txt || true
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/na_w -- python3 $ROOT/tools/na_timing.py > $OUT/na_w.log 2>&1
+python3 $ROOT/tools/pmc_avg.py /tmp/na_w | grep na2d > $OUT/na_pmc_write.txt || true
+tools/micro/gemm_bench > $OUT/gemm_bench.txt 2>&1 || true
+tail -c 900 $OUT/bench.json
