@@ -47,6 +47,8 @@ __device__ __forceinline__ float group_sum(float v, int lpr) {
 
 }  // namespace
 
+constexpr int NORM_ROW_ITERS = 8;     // row groups per wave: the per-channel vectors (w, b, offset: 5x the bytes of a bf16 row piece) are loaded once
+
 // PASSES = C / (8 * lpr): 1 for C <= 512, 2 for C = 1024.  RESID: fuse x' = x + gamma * a (gamma may be null = 1).
 template <typename T, int PASSES, bool RESID>
 __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ gamma,
@@ -56,78 +58,84 @@ __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, cons
     const int lane = threadIdx.x & 63;
     const int rows_per_wave = 64 / lpr;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long row = wave * rows_per_wave + lane / lpr;
     const int li = lane % lpr;
-    const bool live = row < rows;                                            // dead lanes still join the shuffles
-    float v[PASSES][8];
+    // per-channel vectors are the same for every row: loaded once per wave, NORM_ROW_ITERS row groups reuse them
+    float ov[PASSES][8], wv[PASSES][8], bv[PASSES][8], gv[PASSES][8];
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int c0 = (p * lpr + li) * 8;
-        if (live) {
-            Vec8<T>::load(x + row * C + c0, v[p]);
-            if (xoff) {                                                      // y = LN(x + xoff): a per-channel float32 offset carried outside x
-                float ov[8];
-                Vec8<float>::load(xoff + c0, ov);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[p][k] += ov[k];
-            }
-            if (RESID) {
-                float av[8];
-                Vec8<T>::load(a + row * C + c0, av);
-                if (gamma) {
-                    float gv[8];
-                    Vec8<T>::load(gamma + c0, gv);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[p][k] = fmaf(gv[k], av[k], v[p][k]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[p][k] += av[k];
-                }
-                Vec8<T>::store(x_out + row * C + c0, v[p]);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[p][k] = 0.0f;
-        }
+        if (xoff) Vec8<float>::load(xoff + c0, ov[p]);
+        if (RESID && gamma) Vec8<T>::load(gamma + c0, gv[p]);
+        if (y_out) { Vec8<T>::load(w + c0, wv[p]); Vec8<T>::load(b + c0, bv[p]); }
     }
-    if (!y_out) return;                                                      // residual only (last sub-layer of a level)
-    if (RESID && sizeof(T) == 2) {
-        // LN sees what the next op would read back: the rounded residual stream
+    for (int it = 0; it < NORM_ROW_ITERS; ++it) {
+        const long long row = (wave * NORM_ROW_ITERS + it) * rows_per_wave + lane / lpr;
+        if (__builtin_amdgcn_readfirstlane((int)((wave * NORM_ROW_ITERS + it) * rows_per_wave >= rows))) break;   // wave-uniform: nothing left
+        const bool live = row < rows;                                        // dead lanes still join the shuffles
+        float v[PASSES][8];
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int c0 = (p * lpr + li) * 8;
+            if (live) {
+                Vec8<T>::load(x + row * C + c0, v[p]);
+                if (xoff) {                                                  // y = LN(x + xoff): a per-channel float32 offset carried outside x
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[p][k] += ov[p][k];
+                }
+                if (RESID) {
+                    float av[8];
+                    Vec8<T>::load(a + row * C + c0, av);
+                    if (gamma) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[p][k] = fmaf(gv[p][k], av[k], v[p][k]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[p][k] += av[k];
+                    }
+                    Vec8<T>::store(x_out + row * C + c0, v[p]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[p][k] = 0.0f;
+            }
+        }
+        if (!y_out) continue;                                                // residual only (last sub-layer of a level)
+        if (RESID && sizeof(T) == 2) {
+            // LN sees what the next op would read back: the rounded residual stream
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    const uint32_t u = Vec8<__hip_bfloat16>::pack(v[p][k], v[p][k + 1]);
+                    v[p][k] = __uint_as_float(u << 16); v[p][k + 1] = __uint_as_float(u & 0xffff0000u);
+                }
+        }
+        float s = 0.0f;
 #pragma unroll
         for (int p = 0; p < PASSES; ++p)
 #pragma unroll
-            for (int k = 0; k < 8; k += 2) {
-                const uint32_t u = Vec8<__hip_bfloat16>::pack(v[p][k], v[p][k + 1]);
-                v[p][k] = __uint_as_float(u << 16); v[p][k + 1] = __uint_as_float(u & 0xffff0000u);
-            }
-    }
-    float s = 0.0f;
+            for (int k = 0; k < 8; ++k) s += v[p][k];
+        const float mean = group_sum(s, lpr) / (float)C;
+        float q = 0.0f;
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p)
+        for (int p = 0; p < PASSES; ++p)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += v[p][k];
-    const float mean = group_sum(s, lpr) / (float)C;
-    float q = 0.0f;
+            for (int k = 0; k < 8; ++k) { const float d = v[p][k] - mean; q = fmaf(d, d, q); }
+        const float rstd = rsqrtf(group_sum(q, lpr) / (float)C + eps);
+        if (!live) continue;
+        long long yrow = row;                                                // optional scatter into a zero-padded token grid
+        if (Hp) {
+            const long long hw = (long long)Hr * Wr, bi = row / hw, rem = row - bi * hw;
+            yrow = (bi * Hp + rem / Wr) * Wp + rem % Wr;
+        }
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p)
+        for (int p = 0; p < PASSES; ++p) {
+            const int c0 = (p * lpr + li) * 8;
+            float o[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const float d = v[p][k] - mean; q = fmaf(d, d, q); }
-    const float rstd = rsqrtf(group_sum(q, lpr) / (float)C + eps);
-    if (!live) return;
-    long long yrow = row;                                                    // optional scatter into a zero-padded token grid
-    if (Hp) {
-        const long long hw = (long long)Hr * Wr, bi = row / hw, rem = row - bi * hw;
-        yrow = (bi * Hp + rem / Wr) * Wp + rem % Wr;
-    }
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-        const int c0 = (p * lpr + li) * 8;
-        float wv[8], bv[8], o[8];
-        Vec8<T>::load(w + c0, wv);
-        Vec8<T>::load(b + c0, bv);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = fmaf((v[p][k] - mean) * rstd, wv[k], bv[k]);
-        Vec8<T>::store(y_out + yrow * C + c0, o);
+            for (int k = 0; k < 8; ++k) o[k] = fmaf((v[p][k] - mean) * rstd, wv[p][k], bv[p][k]);
+            Vec8<T>::store(y_out + yrow * C + c0, o);
+        }
     }
 }
 
@@ -380,7 +388,7 @@ static int launch_norm(const void* x, const void* a, const void* gamma, const vo
     int lpr = C / 8, passes = 1;
     if (lpr > 64) { passes = lpr / 64; lpr = 64; }
     if (passes > 2 || (lpr & (lpr - 1)) != 0 || lpr * 8 * passes != C) return -1;
-    const long long rows_per_block = 4LL * (64 / lpr);
+    const long long rows_per_block = 4LL * (64 / lpr) * NORM_ROW_ITERS;
     const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
     const bool resid = a != nullptr;
 #define PPN_NORM_LAUNCH(P, R) hipLaunchKernelGGL((norm_kernel<T, P, R>), grid, dim3(256), 0, stream, (const T*)x, (const T*)a, \
