@@ -216,6 +216,57 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
                     acc[ap][mt][bp][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt][kk], fa[mt][kk], acc[ap][mt][bp][nt], 0, 0, 0);
     };
 
+    // ---- per-quadrant epilogue.  A lane holds 4 consecutive n of row m in each of the quadrant's two 16-wide column tiles;
+    // v_permlane16_swap exchanges them between neighbouring lane rows so that a lane ends with 8 consecutive n of ONE tile
+    // (row g: tile g & 1, columns 8 (g >> 1) ..): half as many, 16-byte, stores — the store tail of a tile is issue-bound.
+    const int qcol = (fq & 1) * 16 + (fq >> 1) * 8;                      // this lane's 8 columns inside a quadrant's 32
+    auto swap_rows = [&](f32x4& x, f32x4& y) {                             // x: tile 0, y: tile 1 -> x: columns 0-3, y: columns 4-7 of this lane's 8
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[r]), __float_as_uint(y[r]), false, false);
+            x[r] = __uint_as_float(t[0]); y[r] = __uint_as_float(t[1]);
+        }
+    };
+    auto load_prev = [&](int ap, int bp, int m0, int n0, uint4 (&prev)[4]) {   // EPI_ACCUM: the old C values of a quadrant
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wr * 128 + ap * 64 + mt * 16 + frow, n = n0 + wc * 64 + bp * 32 + qcol;
+            prev[mt] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint4*>(p.C + (size_t)m * p.ldc + n) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto finish_quadrant = [&](int ap, int bp, int m0, int n0, const uint4 (&prev)[4]) {
+        int n = n0 + wc * 64 + bp * 32 + qcol;
+        const bool n_in = n < p.N;                                         // N % 8 == 0: a group of 8 is in or out
+        if (n > p.N - 8) n = p.N - 8;
+        float bq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bq[e] = 0.f;
+        if (EPI != EPI_ACCUM) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+            bq[0] = b0.x; bq[1] = b0.y; bq[2] = b0.z; bq[3] = b0.w; bq[4] = b1.x; bq[5] = b1.y; bq[6] = b1.z; bq[7] = b1.w;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x4 x = acc[ap][mt][bp][0], y = acc[ap][mt][bp][1];
+            swap_rows(x, y);
+            float o[8] = {x[0] + bq[0], x[1] + bq[1], x[2] + bq[2], x[3] + bq[3], y[0] + bq[4], y[1] + bq[5], y[2] + bq[6], y[3] + bq[7]};
+            if (EPI == EPI_ACCUM) {
+                const bf16x8 s8 = __builtin_bit_cast(bf16x8, prev[mt]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += (float)s8[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (EPI == EPI_BIAS_GELU) o[e] = gelu_erf(o[e]);
+                if (EPI == EPI_BIAS_RELU) o[e] = fmaxf(o[e], 0.f);
+            }
+            const bf16x8 w = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3], (__bf16)o[4], (__bf16)o[5], (__bf16)o[6], (__bf16)o[7]};
+            const int m = m0 + wr * 128 + ap * 64 + mt * 16 + frow;
+            if (m < p.M && n_in) *reinterpret_cast<bf16x8*>(p.C + (size_t)m * p.ldc + n) = w;
+            acc[ap][mt][bp][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ap][mt][bp][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
     // ---- K loop: 4 phases per k-tile, each {fragment reads + one quarter-tile of LDS-DMA + counted wait | barrier | 16 MFMA |
     // barrier}.  Waves 4-7 (the second wave of every SIMD) run one barrier behind waves 0-3, so one group's MFMA segment
     // covers the other group's read / DMA segment instead of both idling the matrix pipe together.
@@ -225,7 +276,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
     // (with the stagger, the other group's reads of it finish one barrier later), and it is waited for one phase before its
     // first read: vmcnt(8) in phases 4, 1 and 2 leaves the four youngest quarter-tiles (8 DMA instructions per lane) in flight;
     // the barrier of that phase publishes the rest.  After an epilogue the same three waits allow EPI_STORES more.
-    constexpr int EPI_STORES = (EPI == EPI_RELU_DOT2) ? 16 : 32;       // vector-memory instructions an epilogue leaves in the queue
+    constexpr int EPI_STORES = 16;                                      // vector-memory instructions an epilogue leaves in the queue
     const int G = gridDim.x;
     const int my_tiles = (nblk - (int)blockIdx.x + G - 1) / G;
     const int total = my_tiles * nk;                                    // k-tiles in this block's stream
@@ -254,9 +305,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
         __builtin_amdgcn_s_barrier();                          \
     } while (0)
 
+    // One tile per workgroup (the default launch): the tile's LAST k-tile is peeled and each quadrant is finished — converted,
+    // exchanged, stored — in the phase after its final MFMAs, in the segment where this wave group only reads and the other group
+    // owns the matrix pipe; three quarters of the store tail then overlap the remaining quadrants' MFMAs.
+    const bool overlap = (my_tiles == 1) && (EPI != EPI_RELU_DOT2);
     int g = 0;
     for (int it = 0; it < my_tiles; ++it) {
-        for (int kt = 0; kt < nk; ++kt, ++g) {
+        const int nk_loop = overlap ? nk - 1 : nk;
+        for (int kt = 0; kt < nk_loop; ++kt, ++g) {
             const unsigned char* buf = lds + (g & 1) * BUF_BYTES;
             const bool wide = (kt == 0) && (it > 0);                    // an epilogue's stores are in the queue
             const bool has1 = g + 1 < total, has2 = g + 2 < total;
@@ -285,61 +341,48 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
             PPN_GEMM_MMA(1, 0, fb0);
         }
 
-        // ---- epilogue of this tile, straight from the accumulators: a lane holds 4 consecutive n of one row m = 8 bytes of
-        // bf16; the four column tiles of a wave complete each row's 128-byte line (merged in L2).  Exactly EPI_STORES
-        // vector-memory instructions stay in the queue behind it.
         const int m0 = cur.m0, n0 = cur.n0;
-        float4 bv[2][2], w0v[2][2], w1v[2][2];
+        if (overlap) {
+            const unsigned char* buf = lds + (g & 1) * BUF_BYTES;           // the last k-tile; everything has landed (vmcnt(0) above)
+            uint4 pa[4] = {}, pb[4] = {};
+            load_b(buf, 0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(buf, 0);
+            if (EPI == EPI_ACCUM) load_prev(0, 0, m0, n0, pa);
+            PPN_GEMM_MMA(0, 0, fb0);
+            load_b(buf, 1, fb1);
+            finish_quadrant(0, 0, m0, n0, pa);
+            if (EPI == EPI_ACCUM) load_prev(0, 1, m0, n0, pb);
+            PPN_GEMM_MMA(0, 1, fb1);
+            load_a(buf, 1);
+            finish_quadrant(0, 1, m0, n0, pb);
+            if (EPI == EPI_ACCUM) load_prev(1, 1, m0, n0, pa);
+            PPN_GEMM_MMA(1, 1, fb1);
+            finish_quadrant(1, 1, m0, n0, pa);
+            if (EPI == EPI_ACCUM) load_prev(1, 0, m0, n0, pb);
+            PPN_GEMM_MMA(1, 0, fb0);
+            finish_quadrant(1, 0, m0, n0, pb);
+            ++g;
+        } else if (EPI == EPI_RELU_DOT2) {
+            // max(acc + bias, 0) . w2[c] over this wave's 64 columns: reduce over the 4 lane quarters, then one float atomic per
+            // (row, class) per wave (8 per row over the two column blocks' four wave columns): 16 atomic instructions
+            float4 bv[2][2], w0v[2][2], w1v[2][2];
 #pragma unroll
-        for (int bp = 0; bp < 2; ++bp)
+            for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                int n = n0 + wc * 64 + bp * 32 + nt * 16 + fq * 4;
-                const bool in = n < p.N;                                          // N % 4 == 0: a group of 4 is in or out
-                if (n > p.N - 4) n = p.N - 4;
-                bv[bp][nt] = (EPI != EPI_ACCUM) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (EPI == EPI_RELU_DOT2) {
+                for (int nt = 0; nt < 2; ++nt) {
+                    int n = n0 + wc * 64 + bp * 32 + nt * 16 + fq * 4;
+                    const bool in = n < p.N;                                      // N % 4 == 0: a group of 4 is in or out
+                    if (n > p.N - 4) n = p.N - 4;
+                    bv[bp][nt] = *reinterpret_cast<const float4*>(p.bias + n);
                     w0v[bp][nt] = in ? *reinterpret_cast<const float4*>(p.w2 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                     w1v[bp][nt] = in ? *reinterpret_cast<const float4*>(p.w2 + p.N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-            }
-        if (EPI == EPI_ACCUM) {
-            // C += acc: all 32 reads of the old values first (they drain the queue once), then 32 stores
-            uint2 prev[2][4][2][2];
 #pragma unroll
             for (int ap = 0; ap < 2; ++ap)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            const int m = m0 + wr * 128 + ap * 64 + mt * 16 + frow;
-                            const int n = n0 + wc * 64 + bp * 32 + nt * 16 + fq * 4;
-                            prev[ap][mt][bp][nt] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint2*>(p.C + (size_t)m * p.ldc + n) : make_uint2(0u, 0u);
-                        }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int ap = 0; ap < 2; ++ap)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            const bf16x4 s4 = __builtin_bit_cast(bf16x4, prev[ap][mt][bp][nt]);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) acc[ap][mt][bp][nt][r] += (float)s4[r];
-                        }
-        }
-#pragma unroll
-        for (int ap = 0; ap < 2; ++ap)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int m = m0 + wr * 128 + ap * 64 + mt * 16 + frow;
-                if (EPI == EPI_RELU_DOT2) {
-                    // max(acc + bias, 0) . w2[c] over this wave's 64 columns: reduce over the 4 lane quarters, then one float
-                    // atomic per (row, class) per wave (8 per row over the two column blocks' four wave columns)
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int m = m0 + wr * 128 + ap * 64 + mt * 16 + frow;
                     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                     for (int bp = 0; bp < 2; ++bp)
@@ -350,6 +393,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
                             const float v0 = fmaxf(a4[0] + b4.x, 0.f), v1 = fmaxf(a4[1] + b4.y, 0.f), v2 = fmaxf(a4[2] + b4.z, 0.f), v3 = fmaxf(a4[3] + b4.w, 0.f);
                             s0 += v0 * u4.x + v1 * u4.y + v2 * u4.z + v3 * u4.w;
                             s1 += v0 * w4.x + v1 * w4.y + v2 * w4.z + v3 * w4.w;
+                            acc[ap][mt][bp][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
                         }
                     s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
                     s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
@@ -357,29 +401,22 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
                         atomicAdd(p.logits + (size_t)m * 2, s0);
                         atomicAdd(p.logits + (size_t)m * 2 + 1, s1);
                     }
-                } else {
-#pragma unroll
-                    for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            const int n = n0 + wc * 64 + bp * 32 + nt * 16 + fq * 4;
-                            const f32x4 v = acc[ap][mt][bp][nt];
-                            const float4 b4 = bv[bp][nt];
-                            float o[4] = {v[0] + b4.x, v[1] + b4.y, v[2] + b4.z, v[3] + b4.w};
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                if (EPI == EPI_BIAS_GELU) o[r] = gelu_erf(o[r]);
-                                if (EPI == EPI_BIAS_RELU) o[r] = fmaxf(o[r], 0.f);
-                            }
-                            const bf16x4 w = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
-                            if (m < p.M && n < p.N) *reinterpret_cast<bf16x4*>(p.C + (size_t)m * p.ldc + n) = w;
-                        }
                 }
+        } else {
+            // persistent form: the whole tile is finished here; exactly EPI_STORES vector-memory instructions stay in the queue
+            if (EPI == EPI_ACCUM) {
+                uint4 pq[4][4];
 #pragma unroll
-                for (int bp = 0; bp < 2; ++bp)
+                for (int q = 0; q < 4; ++q) load_prev(q >> 1, q & 1, m0, n0, pq[q]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the 16 reads drain the queue once
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) acc[ap][mt][bp][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < 4; ++q) finish_quadrant(q >> 1, q & 1, m0, n0, pq[q]);
+            } else {
+                const uint4 none[4] = {};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) finish_quadrant(q >> 1, q & 1, m0, n0, none);
             }
+        }
         // next tile
         cur = nxt;
         if (it + 2 < my_tiles) tile_src(blockIdx.x + (it + 2) * G, nxt);

@@ -139,6 +139,9 @@ class _FusedStage(nn.Module):
 
 
 def _ln(x, ln):
+    # The CPU branches of this module (here and in _FusedStage) are not a product fallback: they let the CPU golden test
+    # (tests/test_gennet_golden.py) check the module's wiring against the reference's own outputs without a GPU.  PPNet, the
+    # drop-in classes and bench.py run on the GPU only, where every op below is a HIP kernel or a ROCm library call.
     if x.is_cuda:
         from . import fused
         return fused.layer_norm(x, ln)                                       # thread-per-row HIP kernel (C = 24)

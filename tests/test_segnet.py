@@ -264,24 +264,35 @@ def test_dinat_base_end_to_end_256():
 
 @pytest.mark.gpu
 def test_ppnet_pipeline_runs_at_512_and_224():
-    """BASELINE config 5 resolution (512) and the reference default (224): the whole plan() path on generator output."""
-    from ppnet_amd import edage
+    """BASELINE config 5 resolution (512: AE-ViT with down_time = 4, 128 x 128 SegNet tokens) and the reference default (224):
+    the whole plan() path on generator output, and config 5's PPNet column — success rate and plan length / target length
+    (process_map.py:496-503; updated_geometric_planner.py:260-277) — on ridge heat maps along the labels, where plans exist
+    (no trained weights ship with the reference: the networks' own heat map is noise)."""
+    from ppnet_amd import edage, evaluate
     from ppnet_amd.ppnet import PPNet
     dev = torch.device("cuda:0")
-    for R, bound_ok in ((512, True), (224, True)):
-        pb = edage.generate_paths(2, R, 50, 3, seed=3, device=dev)
-        mb = edage.generate_maps(pb, 2, 5, 20, seed=3)
+    for R in (512, 224):
+        pb = edage.generate_paths(4, R, 50, 3, seed=3, device=dev)
+        mb = edage.generate_maps(pb, 4, 5, 20, seed=3)
         torch.manual_seed(0)
         model = PPNet(R).to(dev).eval()
-        out = model.plan(mb.grid, mb.segpoint[:, 0].contiguous(), mb.segpoint[:, 10].contiguous(), mb.obstacles,
-                         mb.n_obstacles[:, 0].contiguous(), 1 / 50 * 224)
+        init, end = mb.segpoint[:, 0].contiguous(), mb.segpoint[:, 10].contiguous()
+        out = model.plan(mb.grid, init, end, mb.obstacles, mb.n_obstacles[:, 0].contiguous())
         torch.cuda.synchronize()
-        assert out["ok"].shape == (4,) and out["waypoints"].shape[0] == 4 and out["collision"].dtype == torch.bool
+        assert out["ok"].shape == (16,) and out["waypoints"].shape[0] == 16 and out["collision"].dtype == torch.bool
         mask = model.segment(mb.grid)
-        assert mask.shape == (4, R, R)
+        assert mask.shape == (16, R, R)
         heat = model.heatmap(mask)
-        assert heat.shape == (4, R, R) and heat.dtype == torch.uint8
-        assert int(heat.reshape(4, -1).max(dim=1).values.min()) == 255          # per-sample min-max normalisation
+        assert heat.shape == (16, R, R) and heat.dtype == torch.uint8
+        assert int(heat.reshape(16, -1).max(dim=1).values.min()) == 255         # per-sample min-max normalisation
+        ridge = evaluate.label_heatmaps(pb, mb, 4, sigma=2.0 * R / 256)
+        res = model.plan_tail(ridge, init, end, mb.obstacles, mb.n_obstacles[:, 0].contiguous())
+        ev = evaluate.evaluate_plans(res, pb.length.repeat_interleave(4) * R / 50)
+        print(f"R={R}: {ev}")
+        assert ev["extract_ok"] >= 0.9 and ev["success"] >= 0.75 and 0.9 < ev["length_ratio"] < 1.3
+        # a waypoint beyond column 224 is not a collision on a larger map (the reference's constant is its map size)
+        if R == 512:
+            assert bool((res["waypoints"][res["ok"]][:, :, 1].max() > 224)) and bool(res["success"].any())
 
 
 @pytest.mark.gpu
