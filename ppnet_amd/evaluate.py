@@ -50,7 +50,12 @@ def label_heatmaps(paths, maps, placements, sigma=2.0, bound=None):
     t = torch.arange(-r, r + 1, device=x.device, dtype=torch.float32)
     k = torch.exp(-t * t / (2 * sigma * sigma))
     k = k / k.sum()
-    x = torch.nn.functional.conv2d(x, k.view(1, 1, 1, -1), padding=(0, r))
-    x = torch.nn.functional.conv2d(x, k.view(1, 1, -1, 1), padding=(r, 0))
+    # separable blur as sums of shifted slices (no library convolution: PPNet switches MIOpen's exhaustive search on, and a
+    # search over these one-off 1 x (2r+1) shapes can take minutes)
+    H, W = x.shape[-2:]
+    xp = torch.nn.functional.pad(x, (r, r, 0, 0))
+    x = sum(k[i] * xp[..., :, i:i + W] for i in range(2 * r + 1))
+    xp = torch.nn.functional.pad(x, (0, 0, r, r))
+    x = sum(k[i] * xp[..., i:i + H, :] for i in range(2 * r + 1))
     from .gennet import normalize_heatmap_u8
     return normalize_heatmap_u8(x)
