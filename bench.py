@@ -296,9 +296,16 @@ def main():
     # its own HIP streams: while stage B of batch i writes its maps, stage A of batches i+1 .. i+DEPTH is in flight.
     # DEPTH+1 path buffers, events for the hand-off.  Every step launches exactly one stage-A and one stage-B kernel.
     DEPTH = int(os.environ.get("BENCH_DEPTH", "2"))
+    # GROUP > 1: one stage-A launch produces the target paths of GROUP consecutive steps (GROUP x PATHS workgroups instead of
+    # PATHS: the latency chains fill the chip for a short while instead of trickling beside every stage-B launch); the steps
+    # consume views of that batch.  Work per step is unchanged; a timed region of K steps contains K / GROUP stage-A launches.
+    GROUP = int(os.environ.get("BENCH_PATH_GROUP", "1"))
+    if GROUP > 1 and (args.warmup % GROUP or args.steps % GROUP):
+        raise SystemExit(f"BENCH_PATH_GROUP={GROUP}: --warmup and --steps must be multiples of it (the timed region must hold whole groups)")
     TIMED_EVERY = 2          # every 2nd launch carries a start marker: >= 10 launches averaged at the default --steps 20
     NPB = DEPTH + 1
-    pbs = [edage.PathsBatch(PATHS, R, MAP_SIZE, CLEARANCE, dev) for _ in range(NPB)]
+    pbs = [edage.PathsBatch(PATHS * GROUP, R, MAP_SIZE, CLEARANCE, dev) for _ in range(NPB)]
+    pviews = [[pb.view(k * PATHS, PATHS) for k in range(GROUP)] for pb in pbs]
     # N > 1: the end-of-batch all-gather of the fixed-size records runs on its own stream beside the next batch, so the
     # maps are double-buffered (batch i+1 must not overwrite the labels batch i's records are packed from).
     exchange = world > 1 or bool(os.environ.get("BENCH_FORCE_EXCHANGE"))      # the env knob rehearses the stream logic on one GPU
@@ -316,13 +323,21 @@ def main():
     launched = [-1]               # newest batch whose stage A has been launched
 
     def launch_paths(it):
+        """Stage A of path group `it` (the paths of steps it*GROUP .. it*GROUP + GROUP - 1)."""
         b = it % NPB
         sp = s_paths[it % DEPTH]
-        first_path, _, _ = shard.local_ids(PATHS * world, PLACEMENTS, rank, world, batch_index=it)
         with torch.cuda.stream(sp):
             if consumed[b] is not None:
                 sp.wait_event(consumed[b])
-            edage.generate_paths(PATHS, R, MAP_SIZE, CLEARANCE, seed=SEED, first_path_id=first_path, device=dev, out=pbs[b])
+            if GROUP == 1:
+                first_path, _, _ = shard.local_ids(PATHS * world, PLACEMENTS, rank, world, batch_index=it)
+                edage.generate_paths(PATHS, R, MAP_SIZE, CLEARANCE, seed=SEED, first_path_id=first_path, device=dev, out=pbs[b])
+            else:
+                # path ids of this rank for GROUP consecutive batches are not contiguous across ranks: one launch per batch id
+                # range would defeat the grouping, so a group draws the ids [first(it*GROUP) .. ) of a world whose batch is
+                # GROUP times as large — same streams for any N, every id used once
+                first_path, _, _ = shard.local_ids(PATHS * GROUP * world, PLACEMENTS, rank, world, batch_index=it)
+                edage.generate_paths(PATHS * GROUP, R, MAP_SIZE, CLEARANCE, seed=SEED, first_path_id=first_path, device=dev, out=pbs[b])
             ready[b] = torch.cuda.Event()
             ready[b].record(sp)
         launched[0] = it
@@ -330,13 +345,19 @@ def main():
 
     def step(it):
         # a fresh batch every step: path / map ids advance so no two steps generate the same instances
-        b = it % NPB
-        _, _, first_map = shard.local_ids(PATHS * world, PLACEMENTS, rank, world, batch_index=it)
-        while launched[0] < it + DEPTH - 1:
-            launch_paths(launched[0] + 1)     # pipeline fill (first step only)
-        launch_paths(it + DEPTH)              # this step's stage A: the batch stage B will reach DEPTH steps from now
-        s_maps.wait_event(ready[b])
-        ready[b] = None
+        grp, sub = divmod(it, GROUP)
+        b = grp % NPB
+        if GROUP == 1:
+            _, _, first_map = shard.local_ids(PATHS * world, PLACEMENTS, rank, world, batch_index=it)
+        else:
+            fp, _, _ = shard.local_ids(PATHS * GROUP * world, PLACEMENTS, rank, world, batch_index=grp)
+            first_map = (fp + sub * PATHS) * PLACEMENTS
+        if sub == 0:
+            while launched[0] < grp + DEPTH - 1:
+                launch_paths(launched[0] + 1)     # pipeline fill (first step only)
+            launch_paths(grp + DEPTH)             # this group's stage A: the paths stage B will reach DEPTH groups from now
+            s_maps.wait_event(ready[b])
+            ready[b] = None
         # every event is a marker packet the queue has to drain before the next kernel starts (~5 us each on this
         # runtime), so the stream carries one per step (it doubles as the buffer hand-off) and a start marker only on
         # every TIMED_EVERY-th step: those launches are the sample the roofline's kernel duration is averaged over
@@ -347,10 +368,11 @@ def main():
         m = it % NMB
         if exchange and sent[m] is not None:
             s_maps.wait_event(sent[m])        # the records of batch it-2 have left this maps buffer
-        edage.generate_maps(pbs[b], PLACEMENTS, OBST_SIZE, K, seed=SEED, first_map_id=first_map, out=mbs[m])
+        edage.generate_maps(pviews[b][sub], PLACEMENTS, OBST_SIZE, K, seed=SEED, first_map_id=first_map, out=mbs[m])
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        consumed[b] = ev1
+        if sub == GROUP - 1:
+            consumed[b] = ev1                     # the last step of the group releases the path buffer
         if exchange:                          # end-of-batch gather of the fixed-size records (RCCL over xGMI), off the compute stream
             with torch.cuda.stream(s_comm):
                 s_comm.wait_event(ev1)
@@ -389,7 +411,8 @@ def main():
 
     ppnet = None
     if not args.no_ppnet:
-        ppnet = ppnet_leg(torch, dev, pbs[(args.warmup + args.steps - 1) % NPB], mb, args.ppnet_batch, args.ppnet_steps, world, rank,
+        last = args.warmup + args.steps - 1
+        ppnet = ppnet_leg(torch, dev, pviews[(last // GROUP) % NPB][last % GROUP], mb, args.ppnet_batch, args.ppnet_steps, world, rank,
                           cpu_leg=(world == 1 and not args.no_cpu_baseline))
     if rank == 0:
         bytes_per_launch = algorithmic_bytes_per_map(k_tot, k_pocket) * n_local

@@ -12,6 +12,7 @@
 //       chunk of 8 keys raises a running maximum in the wave, P rounded to bfloat16 pairs, P.V on v_dot2 over key pairs
 //   proj + residual, LN2, fc1 -> GELU -> fc2 streamed one hidden unit at a time, residual
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "ppn_device.h"
 #include "ppn_kernels.h"
 
@@ -245,7 +246,214 @@ __global__ __launch_bounds__(512) void gennet_trunk_kernel(const __bf16* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Matrix-core form of the same trunk.  v_dot2_f32_bf16 issues at a quarter of the VALU rate on gfx950, and the kernel above
+// spends 16 of them per (two queries, key): 1.56 ms per 256-problem batch.  Here the attention products run on
+// v_mfma_f32_16x16x32_bf16 with the head dimension (8) zero-padded to the instruction's K of 32 — lanes 16-63 hold zero
+// fragments — which wastes three quarters of a pipe that is otherwise idle:
+//   Q, K, V rows of the block in LDS (bf16, 48 B per token each; q carries scale * log2 e);
+//   per (head, 16-query tile) of a wave:  pass 1  S^T = K Q^T tile by tile, only the row maximum is kept (4 max per tile);
+//                                         pass 2  S^T again, p = 2^(s - max), P^T is the accumulator converted in place (k slot
+//                                                 8g+j <-> key 4g+(j&3) of tile 2kp+(j>>2)), O^T += V^T P^T with V^T read by
+//                                                 ds_read_b64_tr_b16 from the row-major V image (rows = channels h*8 .., 8 used)
+//   exact softmax (two passes over the logits instead of an online rescale: the second S^T costs MFMA time only);
+//   the attention output overwrites the tile's Q rows (bf16) for the per-token proj / MLP phase.
+typedef __attribute__((ext_vector_type(4))) short ts16x4;
+typedef __attribute__((ext_vector_type(8))) short ts16x8;
+typedef __attribute__((ext_vector_type(4))) float tf32x4;
+
+__global__ __launch_bounds__(512) void gennet_trunk_mfma_kernel(const __bf16* __restrict__ xin, __bf16* __restrict__ yout,
+                                                                const float* __restrict__ params, int N, int n_blocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tl[];
+    unsigned char* Ql = tl;                                                // [N][48 B]: q (scaled), later the attention output
+    unsigned char* Kl = tl + (size_t)N * 48;
+    unsigned char* Vl = tl + (size_t)N * 96;                               // + 64 B of slack behind it (transposed reads of head 2)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int prob = blockIdx.x;
+    const int tok[2] = {tid, tid + 512};
+    const bool live[2] = {tok[0] < N, tok[1] < N};
+    const int j = lane & 15, g = lane >> 4, q4 = j >> 2, p4 = j & 3;
+    const int ntile = N >> 4;
+
+    float x[2][TC];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (live[s]) {
+            const __bf16* src = xin + ((size_t)prob * N + tok[s]) * TC;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + 8 * p);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[s][8 * p + e] = (float)v[e];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < TC; ++c) x[s][c] = 0.f;
+        }
+    }
+    if (tid < 16) reinterpret_cast<uint32_t*>(Vl + (size_t)N * 48)[tid] = 0u;     // the slack stays finite
+
+    const float qscale = 0.35355339059327373f * 1.4426950408889634f;      // head_dim^-0.5 * log2(e)
+    for (int blk = 0; blk < n_blocks; ++blk) {
+        const float* P = params + (size_t)blk * BLOCK_PARAMS;
+        float y[2][TC];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) layer_norm24(x[s], P + O_LN1W, P + O_LN1B, y[s]);
+        // ---- qkv rows to LDS (the previous block's phase C read only this thread's own Q rows; K / V readers are past the
+        // barrier that closed the attention phase)
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+#pragma unroll
+            for (int h = 0; h < TH; ++h) {
+                float o8[2][THD];
+#pragma unroll
+                for (int c = 0; c < THD; ++c) {
+                    const int row = part * TC + h * THD + c;
+                    const float* wr = P + O_WQKV + row * TC;
+                    float a0 = P[O_BQKV + row], a1 = a0;
+#pragma unroll
+                    for (int i = 0; i < TC; ++i) { a0 += wr[i] * y[0][i]; a1 += wr[i] * y[1][i]; }
+                    o8[0][c] = a0; o8[1][c] = a1;
+                }
+                unsigned char* base = part == 0 ? Ql : (part == 1 ? Kl : Vl);
+                const float sc = part == 0 ? qscale : 1.0f;
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    if (live[s])
+                        *reinterpret_cast<uint4*>(base + (size_t)tok[s] * 48 + h * 16) =
+                            make_uint4(pack_bf16x2(o8[s][0] * sc, o8[s][1] * sc), pack_bf16x2(o8[s][2] * sc, o8[s][3] * sc),
+                                       pack_bf16x2(o8[s][4] * sc, o8[s][5] * sc), pack_bf16x2(o8[s][6] * sc, o8[s][7] * sc));
+            }
+        __syncthreads();
+
+        // ---- attention on the matrix cores: this wave's query tiles, head by head
+        const bf16x8 zf = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int qt = wave; qt < ntile; qt += 8) {
+#pragma unroll 1
+            for (int h = 0; h < TH; ++h) {
+                const unsigned char* kh = Kl + (size_t)j * 48 + h * 16;
+                bf16x8 qf = zf;
+                if (g == 0) qf = *reinterpret_cast<const bf16x8*>(Ql + (size_t)(qt * 16 + j) * 48 + h * 16);
+                // pass 1: the row maximum
+                float mx = -1.0e30f;
+                for (int kt = 0; kt < ntile; kt += 4) {
+                    bf16x8 kf[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { kf[u] = zf; if (g == 0) kf[u] = *reinterpret_cast<const bf16x8*>(kh + (size_t)(kt + u) * 16 * 48); }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const tf32x4 sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u], qf, tf32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        mx = fmaxf(mx, fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                // pass 2: probabilities and P V
+                float lsum = 0.f;
+                tf32x4 oacc = {0.f, 0.f, 0.f, 0.f};
+                const unsigned char* vb = Vl + (size_t)(4 * g + q4) * 48 + h * 16 + 8 * p4;
+                for (int kp = 0; kp < ntile; kp += 4) {                    // two k-steps of 32 keys per iteration
+                    bf16x8 kf[4];
+                    ts16x4 vt[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        kf[u] = zf; if (g == 0) kf[u] = *reinterpret_cast<const bf16x8*>(kh + (size_t)(kp + u) * 16 * 48);
+                        vt[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ts16x4*)(vb + (size_t)(kp + u) * 16 * 48));
+                    }
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        tf32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[2 * half], qf, tf32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        tf32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[2 * half + 1], qf, tf32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            s0[r] = __builtin_amdgcn_exp2f(s0[r] - mx); s1[r] = __builtin_amdgcn_exp2f(s1[r] - mx);
+                            lsum += s0[r] + s1[r];
+                        }
+                        const bf16x8 pf = {(__bf16)s0[0], (__bf16)s0[1], (__bf16)s0[2], (__bf16)s0[3], (__bf16)s1[0], (__bf16)s1[1], (__bf16)s1[2], (__bf16)s1[3]};
+                        const ts16x4 lo = vt[2 * half], hi = vt[2 * half + 1];
+                        const ts16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        oacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc, 0, 0, 0);
+                    }
+                }
+                lsum += __shfl_xor(lsum, 16, 64);
+                lsum += __shfl_xor(lsum, 32, 64);
+                const float inv = 1.0f / lsum;
+                // O^T rows = channels 4g + r of this head (g < 2), column = query j: 8 bytes over the query's own q row
+                if (g < 2)
+                    *reinterpret_cast<uint2*>(Ql + (size_t)(qt * 16 + j) * 48 + h * 16 + g * 8) =
+                        make_uint2(pack_bf16x2(oacc[0] * inv, oacc[1] * inv), pack_bf16x2(oacc[2] * inv, oacc[3] * inv));
+            }
+        }
+        __syncthreads();
+
+        // ---- proj + residual, from the attention rows in LDS
+        float att[2][TC];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const bf16x8 v = live[s] ? *reinterpret_cast<const bf16x8*>(Ql + (size_t)tok[s] * 48 + p * 16) : zf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) att[s][8 * p + e] = (float)v[e];
+            }
+#pragma unroll
+        for (int oc = 0; oc < TC; ++oc) {
+            const float* wr = P + O_WPROJ + oc * TC;
+            float a0 = P[O_BPROJ + oc], a1 = a0;
+#pragma unroll
+            for (int i = 0; i < TC; ++i) { a0 += wr[i] * att[0][i]; a1 += wr[i] * att[1][i]; }
+            x[0][oc] += a0; x[1][oc] += a1;
+        }
+        // ---- MLP: one hidden unit at a time, never materialised
+#pragma unroll
+        for (int s = 0; s < 2; ++s) layer_norm24(x[s], P + O_LN2W, P + O_LN2B, y[s]);
+        float acc[2][TC];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < TC; ++c) acc[s][c] = P[O_B2 + c];
+        for (int jh = 0; jh < THID; ++jh) {
+            const float* w1 = P + O_W1 + jh * TC;
+            const float* w2 = P + O_W2T + jh * TC;
+            float h0 = P[O_B1 + jh], h1 = h0;
+#pragma unroll
+            for (int i = 0; i < TC; ++i) { h0 += w1[i] * y[0][i]; h1 += w1[i] * y[1][i]; }
+            h0 = gelu_fast(h0); h1 = gelu_fast(h1);
+#pragma unroll
+            for (int c = 0; c < TC; ++c) { acc[0][c] += h0 * w2[c]; acc[1][c] += h1 * w2[c]; }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < TC; ++c) x[s][c] += acc[s][c];
+    }
+
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (!live[s]) continue;
+        __bf16* dst = yout + ((size_t)prob * N + tok[s]) * TC;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint4*>(dst + 8 * p) = make_uint4(pack_bf16x2(x[s][8 * p], x[s][8 * p + 1]), pack_bf16x2(x[s][8 * p + 2], x[s][8 * p + 3]),
+                                                                pack_bf16x2(x[s][8 * p + 4], x[s][8 * p + 5]), pack_bf16x2(x[s][8 * p + 6], x[s][8 * p + 7]));
+    }
+}
+
 int gennet_trunk_launch(const void* x, void* y, const float* params, int B, int N, int n_blocks, hipStream_t stream) {
+    // the matrix-core form needs whole groups of 4 key tiles (N % 64 == 0: 1024 tokens at R = 256 / 512 / 64); PPNET_TRUNK_VALU=1
+    // keeps the v_dot2 kernel (A/B runs), which also serves the other token counts (784 at R = 224)
+    static const bool valu = getenv("PPNET_TRUNK_VALU") != nullptr;
+    if (!valu && N % 64 == 0) {
+        const size_t lds_m = (size_t)N * 144 + 64;
+        static std::atomic<int> attr_m{0};
+        if (!attr_m.load()) {
+            const hipError_t e = hipFuncSetAttribute((const void*)gennet_trunk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
+            if (e != hipSuccess) return (int)e;
+            attr_m.store(1);
+        }
+        hipLaunchKernelGGL(gennet_trunk_mfma_kernel, dim3(B), dim3(512), lds_m, stream, (const __bf16*)x, (__bf16*)y, params, N, n_blocks);
+        return (int)hipGetLastError();
+    }
     const size_t lds = (size_t)N * 48 + (size_t)3 * (N / 2) * 8 * 4;
     static std::atomic<int> attr{0};
     if (!attr.load()) {

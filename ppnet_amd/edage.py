@@ -63,6 +63,17 @@ class PathsBatch:
         self.pocket_draws_used = z(n, **i32)
         self.struct = L.PathsStruct(**{name: _ptr(getattr(self, name)) for name, _ in L.PathsStruct._fields_})
 
+    def view(self, first, n):
+        """Paths [first, first + n) of this batch as a PathsBatch of their own (no copies: narrowed tensors, a new pointer
+        struct) — stage A can be launched for several stage-B batches at once and consumed batch by batch."""
+        v = object.__new__(PathsBatch)
+        v.n, v.R, v.map_size, v.clearance, v.device = n, self.R, self.map_size, self.clearance, self.device
+        for name, _ in L.PathsStruct._fields_:
+            t = getattr(self, name)
+            setattr(v, name, t.narrow(0, first, n) if t is not None else None)
+        v.struct = L.PathsStruct(**{name: _ptr(getattr(v, name)) for name, _ in L.PathsStruct._fields_})
+        return v
+
     def space_mask(self):
         """Path.Space as a bool tensor [n, R, R] (unpacked on the device)."""
         return _unpack_bits(self.space_bits, self.R, self.R)
