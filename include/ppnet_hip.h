@@ -343,6 +343,16 @@ int ppn_gennet_conv_s2_bf16(const void* x, const void* w, const float* bias, voi
  *   norm2.weight[24] norm2.bias[24] mlp.fc1.weight[96][24] mlp.fc1.bias[96] mlp.fc2.weight TRANSPOSED [96][24] mlp.fc2.bias[24] */
 #define PPN_GENNET_BLOCK_PARAMS 7224
 int ppn_gennet_trunk_bf16(const void* x, void* y, const float* params, int32_t B, int32_t N, int32_t n_blocks, void* stream);
+/* The dense half of a 128-channel NAT layer (DiNAT-B level 0) as two token-streaming kernels with the weights resident in LDS
+ * (SegNet/nat.py:101-153), bfloat16 token rows, float32 accumulation.  tokens % 16 == 0 (else PPN_E_UNSUPPORTED).
+ *   ppn_nat128_ln_qkv_bf16:  qkv[tokens][384] = LN(s + offset) . w[384][128]^T + bias     (norm1 -> attn.qkv; offset, bias may be NULL)
+ *   ppn_nat128_ln_mlp_bf16:  s[tokens][128] += GELU(LN(s + offset) . w1[256][128]^T + b1) . w2[128][256]^T   in place
+ *                            (norm2 -> mlp.fc1 -> erf GELU -> mlp.fc2 -> residual; fc2's bias is carried by the caller's offset)
+ * offset [128] float32 is the constant part of the residual stream carried outside the tensor (ppn_layernorm_offset). */
+int ppn_nat128_ln_qkv_bf16(const void* s, const float* offset, const void* ln_w, const void* ln_b, const void* w, const void* bias, void* qkv,
+                           int64_t tokens, float eps, void* stream);
+int ppn_nat128_ln_mlp_bf16(void* s, const float* offset, const void* ln_w, const void* ln_b, const void* w1, const void* b1, const void* w2,
+                           int64_t tokens, float eps, void* stream);
 /* Dense projection c[M][N] = epilogue(a[M][K] . w[N][K]^T) on bfloat16 (torch.nn.Linear layout; SegNet/nat.py:62-85,111-120).
  * epilogue: 0 = + bias[n]; 1 = gelu(+ bias[n]) (erf form); 2 = c += (the residual stream accumulates, bias unused).
  * K % 64 == 0, K >= 128, N % 8 == 0.  persistent_blocks: 0 = one tile per workgroup; else the number of workgroups (a multiple

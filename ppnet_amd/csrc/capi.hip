@@ -473,6 +473,24 @@ int ppn_gennet_trunk_bf16(const void* x, void* y, const float* params, int32_t B
     return PPN_OK;
 }
 
+int ppn_nat128_ln_qkv_bf16(const void* s, const float* offset, const void* ln_w, const void* ln_b, const void* w, const void* bias, void* qkv,
+                           int64_t tokens, float eps, void* stream) {
+    if (!s || !ln_w || !ln_b || !w || !qkv || tokens <= 0) return PPN_E_INVALID;
+    if (tokens % 16) return PPN_E_UNSUPPORTED;
+    const int e = ppn::nat128_ln_qkv_launch(s, offset, ln_w, ln_b, w, bias, qkv, tokens, eps, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
+int ppn_nat128_ln_mlp_bf16(void* s, const float* offset, const void* ln_w, const void* ln_b, const void* w1, const void* b1, const void* w2,
+                           int64_t tokens, float eps, void* stream) {
+    if (!s || !ln_w || !ln_b || !w1 || !b1 || !w2 || tokens <= 0) return PPN_E_INVALID;
+    if (tokens % 16) return PPN_E_UNSUPPORTED;
+    const int e = ppn::nat128_ln_mlp_launch(s, offset, ln_w, ln_b, w1, b1, w2, tokens, eps, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int32_t N, int32_t K, int32_t epilogue,
                   int32_t persistent_blocks, void* stream) {
     if (!a || !w || !c || M <= 0 || M >= (1LL << 31) || N <= 0 || (N % 8) != 0 || K < 128 || (K % 64) != 0 || epilogue < 0 || epilogue > 2 ||

@@ -259,6 +259,44 @@ def gennet_conv_s2(x_nchw_cl, w_packed, bias32, negative_slope, transposed):
     return y.permute(0, 3, 1, 2)
 
 
+def _nat128_args(s, offset, ln):
+    if not s.is_cuda or s.dtype != torch.bfloat16 or not s.is_contiguous() or s.shape[-1] != 128:
+        raise RuntimeError("ppnet_amd.fused.nat128: contiguous bfloat16 GPU token rows of 128 channels only")
+    assert offset is None or (offset.dtype == torch.float32 and offset.is_contiguous() and offset.device == s.device and offset.numel() == 128)
+    return ln.weight.detach().to(torch.bfloat16), ln.bias.detach().to(torch.bfloat16)
+
+
+def nat128_ln_qkv(s, offset, ln, qkv_linear):
+    """qkv = qkv_linear(ln(s + offset)) for 128-channel token rows s [...,128] in ONE kernel (ppn_nat128_ln_qkv_bf16): the
+    normalised tokens go from registers straight into the matrix pipe.  Returns [...,384] bfloat16."""
+    lw, lb = _nat128_args(s, offset, ln)
+    w = qkv_linear.weight.detach()
+    assert w.shape == (384, 128) and w.dtype == torch.bfloat16 and w.is_contiguous()
+    bias = qkv_linear.bias.detach() if qkv_linear.bias is not None else None
+    out = torch.empty(*s.shape[:-1], 384, dtype=s.dtype, device=s.device)
+    with torch.cuda.device(s.device):
+        rc = L.lib.ppn_nat128_ln_qkv_bf16(_p(s), _p(offset) if offset is not None else None, _p(lw), _p(lb), _p(w),
+                                          _p(bias) if bias is not None else None, _p(out), s.numel() // 128, float(ln.eps),
+                                          ctypes.c_void_p(torch.cuda.current_stream(s.device).cuda_stream))
+    L.check(rc, "ppn_nat128_ln_qkv_bf16")
+    return out
+
+
+def nat128_ln_mlp_(s, offset, ln, fc1, fc2):
+    """s += fc2.weight @ gelu(fc1(ln(s + offset))) in place, ONE kernel (ppn_nat128_ln_mlp_bf16): the hidden activations
+    never reach HBM.  fc2's bias is NOT added (the folded layer carries it in the next offset)."""
+    lw, lb = _nat128_args(s, offset, ln)
+    w1, w2 = fc1.weight.detach(), fc2.weight.detach()
+    assert w1.shape == (256, 128) and w2.shape == (128, 256) and w1.dtype == w2.dtype == torch.bfloat16
+    assert w1.is_contiguous() and w2.is_contiguous()
+    with torch.cuda.device(s.device):
+        rc = L.lib.ppn_nat128_ln_mlp_bf16(_p(s), _p(offset) if offset is not None else None, _p(lw), _p(lb), _p(w1), _p(fc1.bias.detach()),
+                                          _p(w2), s.numel() // 128, float(ln.eps),
+                                          ctypes.c_void_p(torch.cuda.current_stream(s.device).cuda_stream))
+    L.check(rc, "ppn_nat128_ln_mlp_bf16")
+    return s
+
+
 def gennet_trunk(x_nchw_cl, params32, n_blocks):
     """GenNet's ViT blocks as one kernel (ppn_gennet_trunk_bf16): channels_last bfloat16 [B,24,H,W] in and out; params32 from
     gennet.pack_trunk_params."""

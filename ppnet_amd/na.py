@@ -159,10 +159,12 @@ class NeighborhoodAttention2D(nn.Module):
             self._rpb32 = (key, r.detach().to(torch.float32).contiguous())
         return self._rpb32[1]
 
-    def attend(self, x):
-        """The attention output BEFORE the output projection ([B,H,W,C]) for an unpadded x (padding virtual)."""
+    def attend(self, x, qkv=None):
+        """The attention output BEFORE the output projection ([B,H,W,C]) for an unpadded x (padding virtual).  qkv: the
+        projection of x when the caller already holds it ([B,H,W,3C]; x is then only read for its shape)."""
         pad = self.padded_hw(x.shape[1], x.shape[2])
-        qkv = self.qkv(x)
+        if qkv is None:
+            qkv = self.qkv(x)
         if pad is None:
             o = na2d_forward(qkv, self._rpb_f32(), self.num_heads, self.dilation, self.scale)
         else:

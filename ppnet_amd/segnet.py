@@ -8,6 +8,8 @@ gamma1,gamma2}`, `backbone.levels.i.downsample.{reduction,norm}`, `backbone.norm
 The neighbourhood attention is the hand-written HIP kernel (ppnet_amd/na.py); tokenizer / downsampler / head
 convolutions and the linear projections run on the ROCm libraries through PyTorch.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -106,6 +108,12 @@ class NATLayer(nn.Module):
         """s: the residual stream minus the level's accumulated projection biases (see _fold_doc); y = norm1(s + c_in)."""
         C = s.shape[-1]
         c_in, c_mid, c_out = self.offsets(s.device)
+        if self._streams_c128(s):
+            # 128-channel level: LN -> qkv and LN -> MLP -> residual are one token-streaming kernel each (weights in LDS)
+            qkv = fused.nat128_ln_qkv(s, c_in, self.norm1, self.attn.qkv)
+            s.view(-1, C).addmm_(self.attn.attend(s, qkv=qkv).view(-1, C), self.attn.proj.weight.t())
+            fused.nat128_ln_mlp_(s, c_mid, self.norm2, self.mlp.fc1, self.mlp.fc2)
+            return s, (fused.layer_norm(s, next_norm, offset=c_out) if next_norm is not None else None)
         if y is None:
             y = fused.layer_norm(s, self.norm1, offset=c_in)
         s2 = s.view(-1, C)
@@ -113,6 +121,11 @@ class NATLayer(nn.Module):
         y2 = fused.layer_norm(s, self.norm2, offset=c_mid)
         s2.addmm_(self.mlp.hidden(y2), self.mlp.fc2.weight.t())                        # s += h W2'^T (bias in c_out)
         return s, (fused.layer_norm(s, next_norm, offset=c_out) if next_norm is not None else None)
+
+    def _streams_c128(self, s):
+        return (s.shape[-1] == 128 and s.is_cuda and s.dtype == torch.bfloat16 and (s.numel() // 128) % 16 == 0
+                and self.mlp.fc1.out_features == 256 and isinstance(self.mlp.act, nn.GELU) and self.mlp.act.approximate == "none"
+                and self.attn.qkv.weight.dtype == torch.bfloat16 and not os.environ.get("PPNET_LIBRARY_NAT128"))
 
     def offsets(self, device):
         """(c_in, c_mid, c_out) as float32 tensors on `device`: plain attributes, not buffers, so that module.to(bfloat16)
@@ -167,7 +180,8 @@ class NATBlock(nn.Module):
         hw = (x.shape[1], x.shape[2])
         for i, blk in enumerate(self.blocks):
             if i + 1 < n:
-                x, y = blk(x, y, self.blocks[i + 1].norm1, None)
+                nxt = self.blocks[i + 1]
+                x, y = blk(x, y, None if (nxt.folded and nxt._streams_c128(x)) else nxt.norm1, None)
             else:
                 x, y = blk(x, y, out_norm, None)
         if self.blocks[0].folded:                      # x is s = x_true - c: give the true stream back where it is read itself

@@ -117,3 +117,65 @@ def test_gennet_trunk_vs_torch_blocks(B, side):
     got = fused.gennet_trunk(x, pack_trunk_params(blocks).cuda(), 3)
     assert got.shape == want.shape and got.dtype == BF
     _close(got.cpu(), want, rel=2e-2)
+
+
+def _nat128_modules(seed):
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(seed)
+    ln = nn.LayerNorm(128, eps=1e-5)
+    qkv, fc1, fc2 = nn.Linear(128, 384), nn.Linear(128, 256), nn.Linear(256, 128)
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.2 * torch.randn(128, generator=g)); ln.bias.copy_(0.1 * torch.randn(128, generator=g))
+        for lin in (qkv, fc1, fc2):
+            lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) / lin.in_features ** 0.5)
+            lin.bias.copy_(0.3 * torch.randn(lin.bias.shape, generator=g))
+    return [m.cuda().to(torch.bfloat16) for m in (ln, qkv, fc1, fc2)]
+
+
+@pytest.mark.parametrize("tokens", [16, 4096 + 48, 1 << 20])
+def test_nat128_streaming_kernels_vs_float64(tokens):
+    """ppn_nat128_ln_qkv_bf16 / ppn_nat128_ln_mlp_bf16 (SegNet/nat.py:101-153 at C = 128) against the same algebra in
+    float64 on the SAME bfloat16 parameters and input: LN(s + offset) -> qkv, and s + fc2.W gelu(fc1(LN(s + offset))).
+    Tolerance: the kernel rounds the LayerNorm output and the hidden activations to bfloat16 once each (as the library path
+    does when it stores them), accumulates in float32 and rounds the result to bfloat16: errors are a few bf16 ulps of the
+    O(1..4) outputs — 0.06 absolute bounds the worst element, 6e-3 the mean."""
+    from ppnet_amd import fused
+    ln, qkv, fc1, fc2 = _nat128_modules(5)
+    g = torch.Generator().manual_seed(tokens)
+    s = (1.5 * torch.randn(tokens, 128, generator=g)).cuda().to(torch.bfloat16)
+    off = (0.5 * torch.randn(128, generator=g)).cuda()
+    d = lambda t: t.detach().double()
+    y = torch.nn.functional.layer_norm(d(s) + d(off), (128,), d(ln.weight), d(ln.bias), ln.eps)
+    want_qkv = y @ d(qkv.weight).t() + d(qkv.bias)
+    want_s = d(s) + torch.nn.functional.gelu(y @ d(fc1.weight).t() + d(fc1.bias)) @ d(fc2.weight).t()
+    got_qkv = fused.nat128_ln_qkv(s, off, ln, qkv)
+    s2 = s.clone()
+    fused.nat128_ln_mlp_(s2, off, ln, fc1, fc2)
+    torch.cuda.synchronize()
+    for got, want, name in ((got_qkv, want_qkv, "qkv"), (s2, want_s, "mlp")):
+        err = (got.double() - want).abs()
+        assert float(err.max()) < 0.06 and float(err.mean()) < 6e-3, (name, float(err.max()), float(err.mean()))
+    # no offset / no bias forms
+    got0 = fused.nat128_ln_qkv(s, None, ln, qkv)
+    y0 = torch.nn.functional.layer_norm(d(s), (128,), d(ln.weight), d(ln.bias), ln.eps)
+    assert float((got0.double() - (y0 @ d(qkv.weight).t() + d(qkv.bias))).abs().max()) < 0.06
+
+
+def test_nat128_layer_matches_library_form(monkeypatch):
+    """A folded 128-channel NAT layer through the streaming kernels against the same layer on the library GEMM path
+    (PPNET_LIBRARY_NAT128): both are bf16 pipelines with float32 accumulation, they differ by rounding only."""
+    from ppnet_amd.segnet import NATBlock
+    torch.manual_seed(3)
+    blk = NATBlock(128, 2, 4, 7, dilations=[1, 2], downsample=False, layer_scale=1e-1).cuda().to(torch.bfloat16).eval()
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() == 1 and p.numel() == 128:
+                p.add_(0.05 * torch.randn_like(p))
+    blk.fold()
+    x = torch.randn(2, 16, 16, 128, device="cuda").to(torch.bfloat16)
+    with torch.no_grad():
+        a, _ = blk(x)
+        monkeypatch.setenv("PPNET_LIBRARY_NAT128", "1")
+        b, _ = blk(x)
+    err = (a.float() - b.float()).abs()
+    assert float(err.max()) < 0.05 and float(err.mean()) < 4e-3, (float(err.max()), float(err.mean()))
