@@ -343,6 +343,12 @@ int ppn_gennet_conv_s2_bf16(const void* x, const void* w, const float* bias, voi
  *   norm2.weight[24] norm2.bias[24] mlp.fc1.weight[96][24] mlp.fc1.bias[96] mlp.fc2.weight TRANSPOSED [96][24] mlp.fc2.bias[24] */
 #define PPN_GENNET_BLOCK_PARAMS 7224
 int ppn_gennet_trunk_bf16(const void* x, void* y, const float* params, int32_t B, int32_t N, int32_t n_blocks, void* stream);
+/* SegNet's first tokenizer convolution (SegNet/nat.py:24-40, Conv2d(3, 64, 3, stride 2, padding 1)) straight from the occupancy
+ * codes grid [B][H][W] u8: the input image is a 3-colour palette (see ppn_grid_to_image), so the convolution is a 64 x 28 table
+ * times a one-hot column per output pixel.  lut [2][64][32] bfloat16: hi and lo halves of the float32 table
+ * L[co][3 * (ky * 3 + kx) + colour] = sum_ci w[co][ci][ky][kx] * image_ci(colour)  (colour 0 free, 1 marker, 2 other), column 27 =
+ * bias (hi half only), 28..31 zero.  out [B][H/2][W/2][64] bfloat16.  H even, W % 32 == 0 (else PPN_E_UNSUPPORTED). */
+int ppn_tokenizer_conv1_codes_bf16(const uint8_t* grid, const void* lut, void* out, int32_t B, int32_t H, int32_t W, void* stream);
 /* The dense half of a 128-channel NAT layer (DiNAT-B level 0) as two token-streaming kernels with the weights resident in LDS
  * (SegNet/nat.py:101-153), bfloat16 token rows, float32 accumulation.  tokens % 16 == 0 (else PPN_E_UNSUPPORTED).
  *   ppn_nat128_ln_qkv_bf16:  qkv[tokens][384] = LN(s + offset) . w[384][128]^T + bias     (norm1 -> attn.qkv; offset, bias may be NULL)

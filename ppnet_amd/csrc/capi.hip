@@ -473,6 +473,14 @@ int ppn_gennet_trunk_bf16(const void* x, void* y, const float* params, int32_t B
     return PPN_OK;
 }
 
+int ppn_tokenizer_conv1_codes_bf16(const uint8_t* grid, const void* lut, void* out, int32_t B, int32_t H, int32_t W, void* stream) {
+    if (!grid || !lut || !out || B <= 0 || H <= 0 || W <= 0) return PPN_E_INVALID;
+    if ((H & 1) || (W % 32)) return PPN_E_UNSUPPORTED;
+    const int e = ppn::tokenizer_codes_launch(grid, lut, out, B, H, W, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_nat128_ln_qkv_bf16(const void* s, const float* offset, const void* ln_w, const void* ln_b, const void* w, const void* bias, void* qkv,
                            int64_t tokens, float eps, void* stream) {
     if (!s || !ln_w || !ln_b || !w || !qkv || tokens <= 0) return PPN_E_INVALID;

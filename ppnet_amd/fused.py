@@ -182,6 +182,41 @@ def grid_to_image(grid_u8, mean, std, dtype):
     return img.permute(0, 3, 1, 2)
 
 
+def tokenizer_lut(conv, mean, std):
+    """The [2][64][32] bfloat16 table ppn_tokenizer_conv1_codes_bf16 reads, from the tokenizer's first convolution
+    (Conv2d(3, 64, 3, 2, 1), bfloat16 parameters) and the image normalisation: column 3 * (ky * 3 + kx) + colour holds
+    sum_ci w[co][ci][ky][kx] * image_ci(colour) with the image values rounded to bfloat16 as ppn_grid_to_image stores them
+    (colour 0 = free (255,255,255), 1 = marker (255,0,0), 2 = other (0,0,0)); column 27 the bias; hi + lo split."""
+    w = conv.weight.detach().double()                                                    # [64,3,3,3]
+    assert w.shape == (64, 3, 3, 3)
+    lo = torch.tensor([(0.0 - m) / s for m, s in zip(mean, std)], dtype=torch.float32).to(torch.bfloat16).double()
+    hi = torch.tensor([(255.0 - m) / s for m, s in zip(mean, std)], dtype=torch.float32).to(torch.bfloat16).double()
+    pal = torch.stack([hi, torch.stack([hi[0], lo[1], lo[2]]), lo]).to(w.device)         # [colour][ci]
+    table = torch.zeros(64, 32, dtype=torch.float64, device=w.device)
+    table[:, :27] = torch.einsum("oikl,ci->oklc", w, pal).reshape(64, 27)               # k = (ky * 3 + kx) * 3 + colour
+    if conv.bias is not None:
+        table[:, 27] = conv.bias.detach().double()
+    t_hi = table.to(torch.float32).to(torch.bfloat16)
+    t_lo = (table - t_hi.double()).to(torch.float32).to(torch.bfloat16)
+    t_lo[:, 27:] = 0
+    return torch.stack([t_hi, t_lo]).contiguous()
+
+
+def tokenizer_conv1_codes(grid_u8, lut):
+    """[B,R/2,R/2,64] bfloat16 = the tokenizer's first convolution applied to the palette image of the u8 occupancy codes
+    [B,R,R] (ppn_tokenizer_conv1_codes_bf16); lut from tokenizer_lut."""
+    if not grid_u8.is_cuda or grid_u8.dtype != torch.uint8:
+        raise RuntimeError("ppnet_amd.fused.tokenizer_conv1_codes: u8 GPU code grids only")
+    g = grid_u8.contiguous()
+    B, H, W = g.shape
+    assert lut.shape == (2, 64, 32) and lut.dtype == torch.bfloat16 and lut.is_contiguous() and lut.device == g.device
+    out = torch.empty(B, H // 2, W // 2, 64, dtype=torch.bfloat16, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = L.lib.ppn_tokenizer_conv1_codes_bf16(_p(g), _p(lut), _p(out), B, H, W, ctypes.c_void_p(torch.cuda.current_stream(g.device).cuda_stream))
+    L.check(rc, "ppn_tokenizer_conv1_codes_bf16")
+    return out
+
+
 def conv3x3_mfma(x_nchw_cl, w_k, bias32, stride=1, relu=False):
     """3x3 convolution (padding 1) of a channels_last bfloat16 [B,Cin,H,W] tensor on the MFMA implicit-GEMM kernel
     (ppn_conv3x3_mfma_bf16).  w_k: the weight as [Cout,3,3,Cin] bfloat16 (weight.permute(0,2,3,1).contiguous()); bias32:

@@ -70,6 +70,8 @@ class PPNet(torch.nn.Module):
         fused output tail (SegNet.labels_u8)."""
         from .segnet import IMG_MEAN, IMG_STD
         from . import fused
+        if self.amp_dtype is None and self.segnet.backbone.patch_embed.takes_codes(grid_u8):
+            return self.segnet.labels_u8(grid_u8)              # the tokenizer reads the codes themselves (palette convolution)
         x = fused.grid_to_image(grid_u8, IMG_MEAN, IMG_STD, self.weights_dtype or torch.float32)
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             return self.segnet.labels_u8(x)

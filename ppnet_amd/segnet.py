@@ -45,6 +45,28 @@ class ConvTokenizer(nn.Module):
         x = self.proj(x.contiguous(memory_format=torch.channels_last)).permute(0, 2, 3, 1)
         return fused.layer_norm(x, self.norm) if self.norm is not None else x
 
+    _codes = None         # (lut, second convolution's bias as float32) for forward_codes, built on first use
+
+    def takes_codes(self, grid_u8):
+        c0, c1 = self.proj[0], self.proj[1]
+        return (grid_u8.is_cuda and grid_u8.dtype == torch.uint8 and grid_u8.dim() == 3 and grid_u8.shape[1] % 2 == 0
+                and grid_u8.shape[2] % 32 == 0 and c0.weight.shape == (64, 3, 3, 3) and c0.weight.dtype == torch.bfloat16
+                and self.norm is not None and c1.bias is not None and not os.environ.get("PPNET_LIBRARY_TOKENIZER"))
+
+    def forward_codes(self, grid_u8):
+        """The tokens of the palette image of u8 occupancy codes [B,R,R] (what ppn_grid_to_image would render): the first
+        convolution is a table product on the matrix cores (ppn_tokenizer_conv1_codes_bf16), the second convolution runs
+        without its bias, which the LayerNorm kernel adds in registers — the normalised image and two bias passes are
+        never written."""
+        if self._codes is None or self._codes[0].device != grid_u8.device:
+            self._codes = (fused.tokenizer_lut(self.proj[0], IMG_MEAN, IMG_STD).to(grid_u8.device),
+                           self.proj[1].bias.detach().float().contiguous())
+        lut, b2 = self._codes
+        c1 = self.proj[1]
+        x = fused.tokenizer_conv1_codes(grid_u8, lut).permute(0, 3, 1, 2)
+        x = F.conv2d(x, c1.weight, None, c1.stride, c1.padding).permute(0, 2, 3, 1)
+        return fused.layer_norm(x, self.norm, offset=b2)
+
 
 class ConvDownsampler(nn.Module):
     def __init__(self, dim, norm_layer=nn.LayerNorm):
@@ -243,7 +265,8 @@ class NAT(nn.Module):
             self.load_state_dict(sd, strict=False)
 
     def forward(self, x):
-        x = self.patch_embed(x)
+        """x: the image [B,3,H,W], or (GPU inference) the u8 occupancy codes [B,H,W] it would be rendered from."""
+        x = self.patch_embed.forward_codes(x) if x.dtype == torch.uint8 else self.patch_embed(x)
         outs = []
         for idx, level in enumerate(self.levels):
             want = idx in self.compute_indices
@@ -437,7 +460,9 @@ class SegNet(nn.Module):
         head = self.decode_head
         if (img.is_cuda and isinstance(head, SETRUPHead) and head.conv_seg.out_channels == 2 and not self.align_corners
                 and not head.align_corners and head.up_convs[-1][1].scale_factor == 2.0):
-            return fused.seg_labels_2class(head(self.backbone(img), lowres=True), img.shape[2:])
+            return fused.seg_labels_2class(head(self.backbone(img), lowres=True), img.shape[-2:])
+        if img.dtype == torch.uint8:                   # occupancy codes: render the image for the generic path
+            img = fused.grid_to_image(img, IMG_MEAN, IMG_STD, next(self.parameters()).dtype)
         return self.forward(img).to(torch.uint8)
 
     def forward(self, img, return_logits=False):

@@ -179,3 +179,47 @@ def test_nat128_layer_matches_library_form(monkeypatch):
         b, _ = blk(x)
     err = (a.float() - b.float()).abs()
     assert float(err.max()) < 0.05 and float(err.mean()) < 4e-3, (float(err.max()), float(err.mean()))
+
+
+def _code_grids(B, R, seed):
+    g = torch.Generator().manual_seed(seed)
+    grid = torch.full((B, R, R), 255, dtype=torch.uint8)
+    grid[torch.rand(B, R, R, generator=g) < 0.3] = 0                      # obstacles
+    grid[torch.rand(B, R, R, generator=g) < 0.02] = 128                   # marker pixels
+    grid[torch.rand(B, R, R, generator=g) < 0.01] = 77                    # any other code renders black
+    grid[:, 0, :] = 0; grid[:, :, -1] = 128                               # borders exercise the zero padding
+    return grid.cuda()
+
+
+@pytest.mark.parametrize("B,R", [(1, 32), (3, 64), (2, 256)])
+def test_tokenizer_palette_conv_vs_float64(B, R):
+    """ppn_tokenizer_conv1_codes_bf16 (SegNet/nat.py:24-40 first convolution, from the occupancy codes) against
+    torch.nn.functional.conv2d in float64 on the rendered bfloat16 palette image (ppn_grid_to_image) with the same
+    bfloat16 weights.  The table is hi + lo bfloat16 (16 mantissa bits per entry) and the sum is float32: the result
+    differs from the float64 one by the final bfloat16 rounding only — half an ulp, 2^-9 relative, plus 1e-4."""
+    from ppnet_amd import fused
+    from ppnet_amd.segnet import IMG_MEAN, IMG_STD
+    torch.manual_seed(R)
+    conv = torch.nn.Conv2d(3, 64, 3, 2, 1).cuda().to(torch.bfloat16)
+    grid = _code_grids(B, R, R + B)
+    img = fused.grid_to_image(grid, IMG_MEAN, IMG_STD, torch.bfloat16)
+    want = torch.nn.functional.conv2d(img.double(), conv.weight.double(), conv.bias.double(), 2, 1).permute(0, 2, 3, 1)
+    got = fused.tokenizer_conv1_codes(grid, fused.tokenizer_lut(conv, IMG_MEAN, IMG_STD)).double()
+    assert got.shape == want.shape
+    assert bool(((got - want).abs() <= want.abs() * 2.0 ** -8 + 1e-4).all()), float((got - want).abs().max())
+
+
+def test_tokenizer_codes_path_matches_image_path():
+    """ConvTokenizer.forward_codes (palette convolution, bias-free second convolution, bias inside the LayerNorm) against
+    ConvTokenizer.forward on the rendered image: same tokens up to bfloat16 rounding of the intermediates."""
+    from ppnet_amd import fused
+    from ppnet_amd.segnet import ConvTokenizer, IMG_MEAN, IMG_STD
+    torch.manual_seed(9)
+    tok = ConvTokenizer(3, 128, torch.nn.LayerNorm).cuda().to(torch.bfloat16).eval()
+    grid = _code_grids(2, 64, 4)
+    assert tok.takes_codes(grid)
+    with torch.no_grad():
+        a = tok.forward_codes(grid).float()
+        b = tok(fused.grid_to_image(grid, IMG_MEAN, IMG_STD, torch.bfloat16)).float()
+    err = (a - b).abs()
+    assert a.shape == b.shape and float(err.max()) < 0.08 and float(err.mean()) < 6e-3, (float(err.max()), float(err.mean()))
