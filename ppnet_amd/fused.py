@@ -1,7 +1,12 @@
-"""Host side of the fused residual / LayerScale / LayerNorm kernel (ppn_residual_layernorm). GPU only."""
+"""Host side of the fused residual / LayerScale / LayerNorm kernel (ppn_residual_layernorm). GPU only.
+
+Inference runs the HIP kernels below.  When autograd is recording (a training step, ppnet_amd/train.py) the same functions
+compose differentiable torch ops instead — the fused kernels are forward-only; the one hand-written backward is the
+neighbourhood attention's (ppn_na2d_bwd)."""
 import ctypes
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib as L
 
@@ -52,10 +57,24 @@ def _y_for(x, pad_to):
     return _padded_buffer(B, pad_to[0], pad_to[1], C, x.dtype, x.device), (Hr, Wr, pad_to[0], pad_to[1])
 
 
+def recording(*tensors):
+    """True when autograd must see the op: grad mode on and an input / parameter requires grad."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _layer_norm_autograd(x, ln, pad_to, offset):
+    y = F.layer_norm(x if offset is None else x + offset.to(x.dtype), ln.normalized_shape, ln.weight, ln.bias, ln.eps)
+    if pad_to is not None:
+        y = F.pad(y, (0, 0, 0, pad_to[1] - x.shape[2], 0, pad_to[0] - x.shape[1]))
+    return y
+
+
 def layer_norm(x, ln, pad_to=None, offset=None):
     """y = ln(x) for a torch.nn.LayerNorm over the last dimension. pad_to=(Hp,Wp): x is [B,H,W,C] and y is the
     zero-padded (bottom/right) [B,Hp,Wp,C] grid the next neighbourhood attention wants.  offset [C]: y = ln(x + offset)
     (a residual stream whose constant part is carried outside the tensor, ppn_layernorm_offset)."""
+    if recording(x, ln.weight, ln.bias):
+        return _layer_norm_autograd(x, ln, pad_to, offset)
     x = x.contiguous()
     if offset is not None:
         assert pad_to is None
@@ -75,7 +94,11 @@ def layer_norm(x, ln, pad_to=None, offset=None):
 
 
 def residual_layer_norm(x, a, gamma, ln_next, pad_to=None):
-    """x' = x + gamma * a (gamma None = 1) in place of x; returns (x', ln_next(x')) — y is None when ln_next is None."""
+    """x' = x + gamma * a (gamma None = 1) in place of x; returns (x', ln_next(x')) — y is None when ln_next is None.
+    (Under autograd x' is a new tensor.)"""
+    if recording(x, a, gamma, *((ln_next.weight, ln_next.bias) if ln_next is not None else ())):
+        x2 = x + (a if gamma is None else gamma * a)
+        return x2, (_layer_norm_autograd(x2, ln_next, pad_to, None) if ln_next is not None else None)
     x = x.contiguous()
     a = a.to(x.dtype).contiguous()
     y, pad = _y_for(x, pad_to) if ln_next is not None else (None, None)
@@ -87,6 +110,9 @@ def upsample2x_nhwc(x_nchw_cl, relu=False, bias=None):
     """Bilinear x2 (align_corners=False) of a channels_last [B,C,H,W] tensor, optionally with a per-channel bias and a
     ReLU folded into the loads (conv -> folded BN -> ReLU -> Upsample with a bias-free library convolution).  Returns a
     channels_last [B,C,2H,2W] tensor (zero-copy views on both sides)."""
+    if recording(x_nchw_cl, bias):
+        t = x_nchw_cl if bias is None else x_nchw_cl + bias.view(1, -1, 1, 1)
+        return F.interpolate(F.relu(t) if relu else t, scale_factor=2.0, mode="bilinear", align_corners=False)
     if not x_nchw_cl.is_cuda:
         raise RuntimeError("ppnet_amd.fused: GPU tensors only (no CPU fallback)")
     x = x_nchw_cl.permute(0, 2, 3, 1)

@@ -42,16 +42,18 @@ class _Mlp(nn.Module):
 
 
 class _Block(nn.Module):
-    def __init__(self, dim, num_heads, mlp_ratio=4):
+    def __init__(self, dim, num_heads, mlp_ratio=4, drop_path=0.0):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim, eps=1e-6)
         self.attn = _Attention(dim, num_heads)
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.drop_path_rate = float(drop_path)    # stochastic depth, training only (vit.py:150,158-161)
 
-    def forward(self, x):                     # DropPath is the identity at inference (vit.py:158-161)
-        x = x + self.attn(_ln(x, self.norm1))
-        return x + self.mlp(_ln(x, self.norm2))
+    def forward(self, x):
+        from .segnet import drop_path
+        x = x + drop_path(self.attn(_ln(x, self.norm1)), self.drop_path_rate, self.training)
+        return x + drop_path(self.mlp(_ln(x, self.norm2)), self.drop_path_rate, self.training)
 
 
 def _stage(conv):
@@ -154,7 +156,8 @@ class AEViT(nn.Module):
         n_down = int(math.log2(img_resolution // 28))                       # ae_vit.py:23
         self.conv_first = _stage(nn.Conv2d(img_channels, dim, 3, 1, 1))
         self.enc_conv = nn.ModuleList(_stage(nn.Conv2d(dim, dim, 3, 2, 1)) for _ in range(n_down))
-        self.vit_blocks = nn.Sequential(*[_Block(dim, 3, 4) for _ in range(3)])
+        dpr = [float(v) for v in torch.linspace(0, 0.1, 3)]                   # ae_vit.py:35-36: drop_path_rate 0.1 over the depth
+        self.vit_blocks = nn.Sequential(*[_Block(dim, 3, 4, dpr[i]) for i in range(3)])
         self.dec_conv = nn.ModuleList(_stage(nn.ConvTranspose2d(dim, dim, 3, 2, 1, output_padding=1)) for _ in range(n_down))
         self.conv_final = nn.Conv2d(dim, out_channels, 3, 1, 1)
         self._final_f32 = None                            # set by prepare_inference(): (device, float32 weight, float bias)

@@ -18,10 +18,22 @@ from . import fused
 from .na import NeighborhoodAttention2D
 
 
+def drop_path(x, rate, training):
+    """Stochastic depth per sample (timm's DropPath as SegNet/nat.py:122,145-152 and GenNet/networks/vit.py:150-161 use it):
+    identity unless training with rate > 0."""
+    if not training or rate <= 0.0:
+        return x
+    keep = 1.0 - rate
+    mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+    return x * (mask / keep)
+
+
 def _use_mfma_conv(x, conv):
     """The hand-written MFMA implicit-GEMM convolution (ppn_conv3x3_mfma_bf16) serves bfloat16 inference on the GPU for 3x3,
     padding 1, Cin % 64 == 0, Cout % 256 == 0 (whole 256-wide output tiles); everything else stays on the library."""
     import os
+    if fused.recording(x, conv.weight):
+        return False                                   # training: the library convolution (differentiable)
     return (x.is_cuda and x.dtype == torch.bfloat16 and not conv.training and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 256 == 0
             and conv.weight.dtype == torch.bfloat16 and not os.environ.get("PPNET_LIBRARY_CONV"))
@@ -118,6 +130,7 @@ class NATLayer(nn.Module):
                                             qkv_bias=qkv_bias, qk_scale=qk_scale)
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio), act_layer=act_layer)
+        self.drop_path_rate = float(drop_path)                              # stochastic depth, training only (nat.py:122)
         self.layer_scale = layer_scale is not None and type(layer_scale) in (int, float)
         if self.layer_scale:
             self.gamma1 = nn.Parameter(layer_scale * torch.ones(dim))
@@ -168,8 +181,9 @@ class NATLayer(nn.Module):
         if y is None:
             y = fused.layer_norm(x, self.norm1)
         real = hw if (y.shape[1], y.shape[2]) != hw else None               # a materialised padded y still works
-        x, y2 = fused.residual_layer_norm(x, self.attn(y, real), self.gamma1 if self.layer_scale else None, self.norm2)
-        return fused.residual_layer_norm(x, self.mlp(y2), self.gamma2 if self.layer_scale else None, next_norm, next_pad)
+        dp = self.drop_path_rate if self.training else 0.0                  # x + drop_path(gamma * f(.)): the mask commutes with gamma
+        x, y2 = fused.residual_layer_norm(x, drop_path(self.attn(y, real), dp, self.training), self.gamma1 if self.layer_scale else None, self.norm2)
+        return fused.residual_layer_norm(x, drop_path(self.mlp(y2), dp, self.training), self.gamma2 if self.layer_scale else None, next_norm, next_pad)
 
 
 def _fold_doc():
@@ -188,7 +202,8 @@ class NATBlock(nn.Module):
         super().__init__()
         self.blocks = nn.ModuleList(
             NATLayer(dim, num_heads, kernel_size, None if dilations is None else dilations[i], mlp_ratio, qkv_bias,
-                     qk_scale, norm_layer=norm_layer, layer_scale=layer_scale) for i in range(depth))
+                     qk_scale, drop_path=drop_path[i] if isinstance(drop_path, (list, tuple)) else drop_path,
+                     norm_layer=norm_layer, layer_scale=layer_scale) for i in range(depth))
         self.downsample = ConvDownsampler(dim, norm_layer) if downsample else None
 
     def forward(self, x, out_norm=None, inplace=False):
@@ -246,10 +261,12 @@ class NAT(nn.Module):
         self.embed_dim = embed_dim
         self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_levels)]
         self.patch_embed = ConvTokenizer(in_chans, embed_dim, norm_layer)
+        dpr = [float(v) for v in torch.linspace(0, drop_path_rate, sum(depths))]      # nat.py:247
         self.levels = nn.ModuleList(
             NATBlock(int(embed_dim * 2 ** i), depths[i], num_heads[i], kernel_size,
                      None if dilations is None else dilations[i], downsample=(i < self.num_levels - 1),
-                     mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, norm_layer=norm_layer,
+                     mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                     drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])], norm_layer=norm_layer,
                      layer_scale=layer_scale) for i in range(self.num_levels))
         self.out_indices = out_indices
         self.compute_indices = tuple(out_indices)      # inference may narrow this to the levels the head reads
@@ -318,7 +335,8 @@ class SETRUPHead(nn.Module):
         for _ in range(num_convs):
             self.up_convs.append(nn.Sequential(_ConvModule(cin, channels, kernel_size), _Upsample(up_scale, align_corners)))
             cin = channels
-        self.conv_seg = nn.Conv2d(channels, num_classes, 1)                  # Dropout2d is the identity at inference
+        self.conv_seg = nn.Conv2d(channels, num_classes, 1)
+        self.dropout = nn.Dropout2d(dropout_ratio) if dropout_ratio > 0 else nn.Identity()   # decode_head.py cls_seg; identity in eval
 
     def forward(self, inputs, lowres=False):
         """lowres=True: the classifier's logits BEFORE the last x2 up-sampling (the caller fuses the rest of the tail)."""
@@ -344,6 +362,10 @@ class SETRUPHead(nn.Module):
             y = fused.bias_act_(F.conv2d(x, c.weight, None, c.stride, c.padding).contiguous(memory_format=torch.channels_last), c.bias, 0.0)
         else:
             y = conv(x)
+        if self.training:
+            # the reference's order (setr_up_head.py:78-80, decode_head.py:232-237): up-sample, channel dropout, classify —
+            # the dropout mask does not commute with the interpolation
+            return self.conv_seg(self.dropout(up(y)))
         lo = self.conv_seg(y).contiguous()
         return lo if lowres else up(lo)                                      # 2 channels: the library bilinear kernel
 

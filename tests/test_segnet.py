@@ -7,6 +7,14 @@ import pytest
 torch = pytest.importorskip("torch")
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """Everything in this file is inference: under autograd recording the fused host functions would step aside for
+    differentiable torch ops (ppnet_amd/fused.py recording()) and the HIP kernels would not be the thing tested."""
+    with torch.no_grad():
+        yield
+
+
 def test_dinat_base_checkpoint_layout():
     from ppnet_amd.segnet import SegNet
     m = SegNet()

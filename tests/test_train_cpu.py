@@ -1,0 +1,116 @@
+"""Training-step plumbing on the CPU: the two learning-rate schedules against their closed forms, the optimisers' settings, and
+the data-parallel gradient exchange on two gloo ranks (the N > 1 path of ppnet_amd/train.py; RCCL replaces gloo on the GPU)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ppnet_amd import train
+from ppnet_amd.gennet import AEViT
+
+
+def test_poly_lr_matches_reference_formula():
+    """GenNet/utils/scheduler.py:3-12: lr_i = max(base * (1 - i / max_iters) ** power, min_lr), stepped per iteration."""
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-3)
+    sch = train.PolyLR(opt, max_iters=50, power=0.9, min_lr=1e-6)
+    seen = []
+    for i in range(50):
+        seen.append(opt.param_groups[0]["lr"])
+        opt.step(); sch.step()
+    want = [max(1e-3 * (1 - i / 50) ** 0.9, 1e-6) for i in range(50)]
+    assert seen == pytest.approx(want, rel=1e-12)
+    assert opt.param_groups[0]["lr"] == pytest.approx(1e-6)                # (1 - 50/50) ** 0.9 = 0 -> the floor
+
+
+def test_mmseg_poly_warmup_schedule():
+    """setr_up_nat_base.py:50-56: poly power 1, min 0, linear warm-up over 1500 iterations from ratio 1e-6."""
+    base, T = 0.08, 160000
+    assert train.mmseg_poly_lr(base, 0, T) == pytest.approx(base * 1e-6)
+    assert train.mmseg_poly_lr(base, 750, T) == pytest.approx(base * (1 - 750 / T) * (1 - 0.5 * (1 - 1e-6)))
+    assert train.mmseg_poly_lr(base, 1500, T) == pytest.approx(base * (1 - 1500 / T))
+    assert train.mmseg_poly_lr(base, T, T) == 0.0
+    lrs = [train.mmseg_poly_lr(base, i, T) for i in range(0, T, 997)]
+    assert max(lrs) < base and all(a >= b for a, b in zip(lrs[2:], lrs[3:]))   # monotone after the warm-up
+
+
+def test_optimizer_settings():
+    net = AEViT(1, 1, img_resolution=56, dim=24)
+    opt = train.gennet_optimizer(net)
+    g = opt.param_groups[0]
+    assert isinstance(opt, torch.optim.AdamW) and g["lr"] == 1e-3 and g["betas"] == (0.0, 0.99) and g["eps"] == 1e-8 and g["weight_decay"] == 0
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = torch.nn.Linear(2, 2)
+            self.decode_head = torch.nn.Linear(2, 2)
+    opt = train.segnet_optimizer(Toy())
+    assert isinstance(opt, torch.optim.SGD) and [g["lr"] for g in opt.param_groups] == [0.08, 0.8]
+    assert all(g["momentum"] == 0.9 and g["weight_decay"] == 0.0 for g in opt.param_groups)
+    train.segnet_set_lr(opt, 1500, 160000)
+    assert [g["lr"] for g in opt.param_groups] == pytest.approx([0.08 * (1 - 1500 / 160000), 0.8 * (1 - 1500 / 160000)])
+
+
+def _tiny_gennet():
+    torch.manual_seed(0)
+    net = AEViT(1, 1, img_resolution=56, dim=24)
+    for blk in net.vit_blocks:
+        blk.drop_path_rate = 0.0                      # deterministic: the comparison below is exact arithmetic, not statistics
+    return net
+
+
+def _batch():
+    g = torch.Generator().manual_seed(3)
+    space = (torch.rand(4, 56, 56, generator=g) < 0.4).to(torch.uint8)
+    path = ((torch.rand(4, 56, 56, generator=g) < 0.05).to(torch.uint8) * 255)
+    return space, path
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = train.data_parallel(_tiny_gennet(), bucket_cap_mb=1)
+    assert isinstance(net, torch.nn.parallel.DistributedDataParallel)
+    opt = train.gennet_optimizer(net)
+    sch = train.PolyLR(opt, max_iters=10)
+    space, path = _batch()
+    lo, hi = rank * 2, rank * 2 + 2
+    loss = train.gennet_train_step(net, opt, sch, space[lo:hi], path[lo:hi])
+    torch.save({"loss": loss, "params": [p.detach().clone() for p in net.module.parameters()]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_step_equals_averaged_gradients(tmp_path):
+    """Two data-parallel ranks, two samples each, one AdamW step: the parameters afterwards are identical on both ranks and equal
+    a single process stepping on the MEAN of the two half-batch gradients (what MMDistributedDataParallel computes; BatchNorm
+    statistics stay per rank, as with the reference's broadcast_buffers=False)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in (0, 1))
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+    net = _tiny_gennet()
+    opt = train.gennet_optimizer(net)
+    space, path = _batch()
+    grads, losses = None, []
+    for lo in (0, 2):
+        net.train()
+        out = net(space[lo:lo + 2].float().unsqueeze(1))
+        loss = torch.nn.functional.mse_loss(out.squeeze(1), path[lo:lo + 2].float() / 255.0)
+        gs = torch.autograd.grad(loss, list(net.parameters()))
+        grads = gs if grads is None else [g0 + g1 for g0, g1 in zip(grads, gs)]
+        losses.append(loss.detach())
+    for p, g in zip(net.parameters(), grads):
+        p.grad = g / 2
+    opt.step()
+    assert float(r0["loss"]) == pytest.approx(float(losses[0]), rel=1e-6) and float(r1["loss"]) == pytest.approx(float(losses[1]), rel=1e-6)
+    for p, q in zip(net.parameters(), r0["params"]):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), float((p - q).abs().max())
