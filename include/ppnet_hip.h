@@ -343,6 +343,9 @@ int ppn_gennet_conv_s2_bf16(const void* x, const void* w, const float* bias, voi
  *   norm2.weight[24] norm2.bias[24] mlp.fc1.weight[96][24] mlp.fc1.bias[96] mlp.fc2.weight TRANSPOSED [96][24] mlp.fc2.bias[24] */
 #define PPN_GENNET_BLOCK_PARAMS 7224
 int ppn_gennet_trunk_bf16(const void* x, void* y, const float* params, int32_t B, int32_t N, int32_t n_blocks, void* stream);
+/* GenNet's output -> 8-bit heat map, per sample (GenNet/predict.py:95-102): out[b][i] = (uint8)(((y[b][i] - min_b) / (max_b - min_b)) * 255),
+ * float32 arithmetic in that order (bit-identical to the torch composition), y [B][n] float32 (dtype 0) or bfloat16 (1). */
+int ppn_heatmap_u8(const void* y, uint8_t* out, int32_t B, int32_t n, int32_t dtype, void* stream);
 /* SegNet's first tokenizer convolution (SegNet/nat.py:24-40, Conv2d(3, 64, 3, stride 2, padding 1)) straight from the occupancy
  * codes grid [B][H][W] u8: the input image is a 3-colour palette (see ppn_grid_to_image), so the convolution is a 64 x 28 table
  * times a one-hot column per output pixel.  lut [2][64][32] bfloat16: hi and lo halves of the float32 table

@@ -473,6 +473,13 @@ int ppn_gennet_trunk_bf16(const void* x, void* y, const float* params, int32_t B
     return PPN_OK;
 }
 
+int ppn_heatmap_u8(const void* y, uint8_t* out, int32_t B, int32_t n, int32_t dtype, void* stream) {
+    if (!y || !out || B <= 0 || n <= 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
+    const int e = ppn::heatmap_u8_launch(y, out, B, n, dtype, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_tokenizer_conv1_codes_bf16(const uint8_t* grid, const void* lut, void* out, int32_t B, int32_t H, int32_t W, void* stream) {
     if (!grid || !lut || !out || B <= 0 || H <= 0 || W <= 0) return PPN_E_INVALID;
     if ((H & 1) || (W % 32)) return PPN_E_UNSUPPORTED;

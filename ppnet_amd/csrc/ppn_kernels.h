@@ -85,6 +85,7 @@ int conv3x3_mfma_launch(const void* x, const void* w, const float* bias, void* y
                         int relu, const float* w2, float* logits, hipStream_t stream);
 int gennet_enc_conv_launch(const void* x, const void* wk, const float* bias, void* y, int B, int H, int W, float slope, hipStream_t stream);
 int gennet_dec_conv_launch(const void* x, const void* wt, const float* bias, void* y, int B, int H, int W, float slope, hipStream_t stream);
+int heatmap_u8_launch(const void* y, uint8_t* out, int B, int n, int dtype, hipStream_t stream);
 int tokenizer_codes_launch(const uint8_t* grid, const void* lut, void* out, int B, int H, int W, hipStream_t stream);
 int nat128_ln_qkv_launch(const void* s, const float* off, const void* lnw, const void* lnb, const void* w, const void* bias, void* qkv, long long tokens,
                          float eps, hipStream_t stream);

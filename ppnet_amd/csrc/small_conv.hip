@@ -133,6 +133,39 @@ int conv3x3_c1_launch(const void* x, const float* w, const float* bias, void* y,
     return (int)hipGetLastError();
 }
 
+// Per-sample min-max normalisation of GenNet's output to an 8-bit heat map (reference GenNet/predict.py:95-102:
+// (y - min) / (max - min), then ToPILImage's mul(255).byte()).  One workgroup per sample: pass 1 reduces min / max over the
+// sample's pixels (float32 of the stored values), pass 2 re-reads them (128 KB at 256 x 256 bfloat16: L2-resident) and writes
+// u8.  The arithmetic is the reference's, in its order and in float32 — (f - lo) / (hi - lo), * 255, truncate — so the result
+// is bit-identical to the torch composition it replaces (seven elementwise / reduction launches).
+template <typename T>
+__global__ __launch_bounds__(1024) void heatmap_u8_kernel(const T* __restrict__ y, uint8_t* __restrict__ out, int n) {
+    __shared__ float red[2][16];
+    const T* src = y + (size_t)blockIdx.x * n;
+    float lo = 3.0e38f, hi = -3.0e38f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float v = ld1(src + i);
+        lo = fminf(lo, v); hi = fmaxf(hi, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lo; red[1][threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    lo = red[0][0]; hi = red[1][0];
+    for (int w = 1; w < 16; ++w) { lo = fminf(lo, red[0][w]); hi = fmaxf(hi, red[1][w]); }
+    const float range = hi - lo;
+    uint8_t* dst = out + (size_t)blockIdx.x * n;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float nrm = (ld1(src + i) - lo) / range;
+        dst[i] = (uint8_t)(int)(nrm * 255.0f);                              // float -> uint8 as torch's .to(torch.uint8): truncation
+    }
+}
+
+int heatmap_u8_launch(const void* y, uint8_t* out, int B, int n, int dtype, hipStream_t stream) {
+    if (dtype == 0) hipLaunchKernelGGL((heatmap_u8_kernel<float>), dim3(B), dim3(1024), 0, stream, (const float*)y, out, n);
+    else hipLaunchKernelGGL((heatmap_u8_kernel<__hip_bfloat16>), dim3(B), dim3(1024), 0, stream, (const __hip_bfloat16*)y, out, n);
+    return (int)hipGetLastError();
+}
+
 int conv3x3_to1_launch(const void* x, const float* w, float bias, void* y, int B, int H, int W, int Cin, int dtype, hipStream_t stream) {
     const dim3 grid((unsigned)((long long)B * ((H + 15) / 16) * ((W + 15) / 16)));
 #define PPN_TO1(T, CG) hipLaunchKernelGGL((conv3x3_to1_kernel<T, CG>), grid, dim3(256), 0, stream, (const T*)x, w, bias, (T*)y, B, H, W)

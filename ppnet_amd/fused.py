@@ -208,6 +208,21 @@ def grid_to_image(grid_u8, mean, std, dtype):
     return img.permute(0, 3, 1, 2)
 
 
+def heatmap_u8(y):
+    """[B,R,R] u8 = per-sample min-max normalised y [B,1,R,R] or [B,R,R] (float32 / bfloat16) times 255, truncated
+    (ppn_heatmap_u8; GenNet/predict.py:95-102)."""
+    if not y.is_cuda or y.dtype not in _DT:
+        raise RuntimeError("ppnet_amd.fused.heatmap_u8: float32 / bfloat16 GPU tensors only")
+    y = y.contiguous()
+    B, H, W = y.shape[0], y.shape[-2], y.shape[-1]
+    assert y.numel() == B * H * W
+    out = torch.empty(B, H, W, dtype=torch.uint8, device=y.device)
+    with torch.cuda.device(y.device):
+        rc = L.lib.ppn_heatmap_u8(_p(y), _p(out), B, H * W, _DT[y.dtype], ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream))
+    L.check(rc, "ppn_heatmap_u8")
+    return out
+
+
 def tokenizer_lut(conv, mean, std):
     """The [2][64][32] bfloat16 table ppn_tokenizer_conv1_codes_bf16 reads, from the tokenizer's first convolution
     (Conv2d(3, 64, 3, 2, 1), bfloat16 parameters) and the image normalisation: column 3 * (ky * 3 + kx) + colour holds

@@ -82,7 +82,8 @@ class PPNet(torch.nn.Module):
         x = mask.to(self.weights_dtype or torch.float32).unsqueeze(1)        # my_dataset.py:15: values {0,1}
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             y = self.gennet(x)
-        return normalize_heatmap_u8(y)
+        from . import fused
+        return fused.heatmap_u8(y) if y.is_cuda else normalize_heatmap_u8(y)   # one kernel for predict.py:95-102's min-max
 
     @torch.no_grad()
     def plan(self, grid_u8, init, end, obstacles, n_obstacles, clearance=None, down_sample_rate=2):

@@ -223,3 +223,18 @@ def test_tokenizer_codes_path_matches_image_path():
         b = tok(fused.grid_to_image(grid, IMG_MEAN, IMG_STD, torch.bfloat16)).float()
     err = (a - b).abs()
     assert a.shape == b.shape and float(err.max()) < 0.08 and float(err.mean()) < 6e-3, (float(err.max()), float(err.mean()))
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_heatmap_u8_kernel_is_bit_identical_to_the_torch_composition(dtype):
+    """ppn_heatmap_u8 (predict.py:95-102 min-max + ToPILImage's mul(255).byte()) against gennet.normalize_heatmap_u8, the torch
+    composition of the same float32 operations in the same order: identical bytes."""
+    from ppnet_amd import fused
+    from ppnet_amd.gennet import normalize_heatmap_u8
+    g = torch.Generator().manual_seed(8)
+    y = (torch.randn(5, 1, 96, 160, generator=g) * 3 + 0.7).cuda().to(getattr(torch, dtype))
+    got = fused.heatmap_u8(y)
+    want = normalize_heatmap_u8(y)
+    assert got.shape == want.shape == (5, 96, 160) and got.dtype == torch.uint8
+    assert torch.equal(got, want)
+    assert int(got.reshape(5, -1).min(dim=1).values.max()) == 0 and int(got.reshape(5, -1).max(dim=1).values.min()) == 255
