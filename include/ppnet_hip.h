@@ -343,6 +343,16 @@ int ppn_gennet_conv_s2_bf16(const void* x, const void* w, const float* bias, voi
  *   norm2.weight[24] norm2.bias[24] mlp.fc1.weight[96][24] mlp.fc1.bias[96] mlp.fc2.weight TRANSPOSED [96][24] mlp.fc2.bias[24] */
 #define PPN_GENNET_BLOCK_PARAMS 7224
 int ppn_gennet_trunk_bf16(const void* x, void* y, const float* params, int32_t B, int32_t N, int32_t n_blocks, void* stream);
+/* extract_path's result as a fixed-size polyline per problem (process_map.py:355-359): full[b] = [init[b]] + wp[b][:wp_n[b]] * rate +
+ * [end[b]] in a [n][max_wp + 2][2] float64 array (rows beyond the plan: wp * rate, i.e. zeros), counts[b] = ok[b] ? wp_n[b] + 2 : 0.
+ * wp [n][max_wp][2] / wp_n / ok are ppn_extract_paths' outputs, init / end the full-resolution states. */
+int ppn_assemble_paths(const double* wp, const int32_t* wp_n, const uint8_t* ok, const double* init, const double* end, double rate, int32_t n,
+                       int32_t max_wp, double* full, int32_t* counts, void* stream);
+/* collision[b] = any consecutive-waypoint segment i < counts[b] - 1 of plan b hits any of its first n_obstacles[b] obstacle rows
+ * (process_map.py:491-495 over collision_check_circle_edge, :383-425; same float32 arithmetic as ppn_collision_segments_bound).
+ * waypoints [B][M][2] float64; obstacles [B][S][3] rows (ox, oy, size), float32 or float64 (obstacles_f64 != 0). */
+int ppn_plan_collision(const double* waypoints, const int32_t* counts, const void* obstacles, int32_t obstacles_f64, const int32_t* n_obstacles,
+                       int32_t B, int32_t M, int32_t S, float clearance, float bound, uint8_t* collision, void* stream);
 /* GenNet's output -> 8-bit heat map, per sample (GenNet/predict.py:95-102): out[b][i] = (uint8)(((y[b][i] - min_b) / (max_b - min_b)) * 255),
  * float32 arithmetic in that order (bit-identical to the torch composition), y [B][n] float32 (dtype 0) or bfloat16 (1). */
 int ppn_heatmap_u8(const void* y, uint8_t* out, int32_t B, int32_t n, int32_t dtype, void* stream);

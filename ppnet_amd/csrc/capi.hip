@@ -473,6 +473,23 @@ int ppn_gennet_trunk_bf16(const void* x, void* y, const float* params, int32_t B
     return PPN_OK;
 }
 
+int ppn_assemble_paths(const double* wp, const int32_t* wp_n, const uint8_t* ok, const double* init, const double* end, double rate, int32_t n,
+                       int32_t max_wp, double* full, int32_t* counts, void* stream) {
+    if (!wp || !wp_n || !ok || !init || !end || !full || !counts || n <= 0 || max_wp <= 0) return PPN_E_INVALID;
+    const int e = ppn::assemble_paths_launch(wp, wp_n, ok, init, end, rate, n, max_wp, full, counts, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
+int ppn_plan_collision(const double* waypoints, const int32_t* counts, const void* obstacles, int32_t obstacles_f64, const int32_t* n_obstacles,
+                       int32_t B, int32_t M, int32_t S, float clearance, float bound, uint8_t* collision, void* stream) {
+    if (!waypoints || !counts || !n_obstacles || !collision || B <= 0 || M < 2 || S < 0 || (S > 0 && !obstacles)) return PPN_E_INVALID;
+    const int e = ppn::plan_collision_launch(waypoints, counts, obstacles, obstacles_f64, n_obstacles, B, M, S, clearance, bound, collision,
+                                             (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_heatmap_u8(const void* y, uint8_t* out, int32_t B, int32_t n, int32_t dtype, void* stream) {
     if (!y || !out || B <= 0 || n <= 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
     const int e = ppn::heatmap_u8_launch(y, out, B, n, dtype, (hipStream_t)stream);

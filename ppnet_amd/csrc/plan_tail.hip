@@ -12,29 +12,24 @@
 
 namespace ppn {
 
-__global__ __launch_bounds__(256) void collision_segments_kernel(const float* s_in, const float* e_in,
-                                                                 const int32_t* prob, int n_seg, const float* obs,
-                                                                 const int32_t* obs_off, float clearance,
-                                                                 float bound, uint8_t* hit) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_seg) return;
-    const float s0 = s_in[i * 2], s1 = s_in[i * 2 + 1], e0 = e_in[i * 2], e1 = e_in[i * 2 + 1];
+// collision_check_circle_edge for one segment against `count` obstacle rows (ox, oy, size) of type T (float32 arithmetic on
+// float32 values: a float64 row is rounded first, as the reference's torch.tensor(..., dtype=float32) does).
+template <typename T>
+__device__ __forceinline__ uint8_t segment_hits(float s0, float s1, float e0, float e1, const T* obs, int count, float clearance, float bound) {
     // process_map.py:384-387 hard-codes the reference's 224-pixel maps; `bound` carries the map's resolution
-    if (s0 < 0.0f || s1 > bound || e0 < 0.0f || e1 > bound) { hit[i] = 1; return; }
+    if (s0 < 0.0f || s1 > bound || e0 < 0.0f || e1 > bound) return 1;
     const float sx = s1, sy = s0, ex = e1, ey = e0;                       // swap to (x, y), :388-389
     float dx = ex - sx, dy = ey - sy;
     const float nrm = sqrtf(dx * dx + dy * dy);
     float dirx = dy / nrm, diry = -dx / nrm;                              // :390-391
     const double lim_add = (double)clearance / 2.0;
-    const int p = prob[i];
-    uint8_t h = 0;
-    for (int k = obs_off[p]; k < obs_off[p + 1]; ++k) {
-        const float ox = obs[k * 3], oy = obs[k * 3 + 1];
-        const double size = (double)obs[k * 3 + 2];
+    for (int k = 0; k < count; ++k) {
+        const float ox = (float)obs[k * 3], oy = (float)obs[k * 3 + 1];
+        const double size = (double)(float)obs[k * 3 + 2];
         const double lim = size + lim_add;
         // scipy euclidean keeps the float32 of its inputs
         const float ddx = ex - ox, ddy = ey - oy;
-        if ((double)sqrtf(ddx * ddx + ddy * ddy) < lim) { h = 1; break; }   // :397 (tests e twice, never s)
+        if ((double)sqrtf(ddx * ddx + ddy * ddy) < lim) return 1;         // :397 (tests e twice, never s)
         const float qx = ox - sx, qy = oy - sy;
         float dis = dirx * qx + diry * qy;                                // np.dot, float32
         if (dis > 0.0f) { dirx = -dirx; diry = -diry; }                   // dir mutates across obstacles, :406-407
@@ -46,9 +41,71 @@ __global__ __launch_bounds__(256) void collision_segments_kernel(const float* s_
         float bx = px - ex, by = py - ey;
         const float bn = sqrtf(bx * bx + by * by);
         bx = bx / bn; by = by / bn;
-        if ((double)dis < lim && (ax * bx + ay * by) < 0.0f) { h = 1; break; }   // :414
+        if ((double)dis < lim && (ax * bx + ay * by) < 0.0f) return 1;    // :414
     }
-    hit[i] = h;
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void collision_segments_kernel(const float* s_in, const float* e_in,
+                                                                 const int32_t* prob, int n_seg, const float* obs,
+                                                                 const int32_t* obs_off, float clearance,
+                                                                 float bound, uint8_t* hit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_seg) return;
+    const int p = prob[i];
+    hit[i] = segment_hits<float>(s_in[i * 2], s_in[i * 2 + 1], e_in[i * 2], e_in[i * 2 + 1], obs + (size_t)obs_off[p] * 3, obs_off[p + 1] - obs_off[p],
+                                 clearance, bound);
+}
+
+// The planner tail's glue as two kernels instead of ~30 framework launches per batch (process_map.py:355-359, 491-495):
+//   assemble_paths_kernel   [init] + waypoints * rate + [end] into a fixed [n][max_wp + 2][2] polyline, counts = ok ? n_wp + 2 : 0
+//   plan_collision_kernel   one thread per consecutive-waypoint segment of every plan; collision[b] = any segment hits any of
+//                           the problem's first n_obs[b] obstacle rows (collision must be zeroed by the caller's launch)
+__global__ __launch_bounds__(256) void assemble_paths_kernel(const double* __restrict__ wp, const int32_t* __restrict__ wp_n, const uint8_t* __restrict__ ok,
+                                                             const double* __restrict__ init, const double* __restrict__ end, double rate, int n, int max_wp,
+                                                             double* __restrict__ full, int32_t* __restrict__ counts) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int M = max_wp + 2;
+    if (idx >= (long long)n * M) return;
+    const int b = (int)(idx / M), s = (int)(idx - (long long)b * M);
+    const int e_slot = min(wp_n[b] + 1, max_wp + 1);
+    double v0 = 0.0, v1 = 0.0;
+    if (s >= 1 && s <= max_wp) { v0 = wp[((size_t)b * max_wp + s - 1) * 2] * rate; v1 = wp[((size_t)b * max_wp + s - 1) * 2 + 1] * rate; }
+    if (s == 0) { v0 = init[b * 2]; v1 = init[b * 2 + 1]; }
+    if (s == e_slot) { v0 = end[b * 2]; v1 = end[b * 2 + 1]; }
+    full[idx * 2] = v0; full[idx * 2 + 1] = v1;
+    if (s == 0) counts[b] = ok[b] ? wp_n[b] + 2 : 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void plan_collision_kernel(const double* __restrict__ full, const int32_t* __restrict__ counts, const T* __restrict__ obstacles,
+                                                             const int32_t* __restrict__ n_obs, int B, int M, int S, float clearance, float bound,
+                                                             uint8_t* __restrict__ collision) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * (M - 1)) return;
+    const int b = (int)(idx / (M - 1)), i = (int)(idx - (long long)b * (M - 1));
+    if (i >= counts[b] - 1) return;
+    const double* p = full + ((size_t)b * M + i) * 2;
+    const int cnt = min(max(n_obs[b], 0), S);
+    if (segment_hits<T>((float)p[0], (float)p[1], (float)p[2], (float)p[3], obstacles + (size_t)b * S * 3, cnt, clearance, bound)) collision[b] = 1;
+}
+
+int assemble_paths_launch(const double* wp, const int32_t* wp_n, const uint8_t* ok, const double* init, const double* end, double rate, int n, int max_wp,
+                          double* full, int32_t* counts, hipStream_t stream) {
+    const long long total = (long long)n * (max_wp + 2);
+    hipLaunchKernelGGL(assemble_paths_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, wp, wp_n, ok, init, end, rate, n, max_wp, full, counts);
+    return (int)hipGetLastError();
+}
+
+int plan_collision_launch(const double* full, const int32_t* counts, const void* obstacles, int obs_f64, const int32_t* n_obs, int B, int M, int S,
+                          float clearance, float bound, uint8_t* collision, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(collision, 0, (size_t)B, stream);
+    if (e != hipSuccess) return (int)e;
+    const long long total = (long long)B * (M - 1);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (obs_f64) hipLaunchKernelGGL((plan_collision_kernel<double>), grid, dim3(256), 0, stream, full, counts, (const double*)obstacles, n_obs, B, M, S, clearance, bound, collision);
+    else hipLaunchKernelGGL((plan_collision_kernel<float>), grid, dim3(256), 0, stream, full, counts, (const float*)obstacles, n_obs, B, M, S, clearance, bound, collision);
+    return (int)hipGetLastError();
 }
 
 __global__ __launch_bounds__(64) void extract_paths_kernel(const float* heat, int n, int H, int W, const double* init,

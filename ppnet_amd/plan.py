@@ -45,13 +45,32 @@ def extract_paths(heat_u8, init_state, end_state, down_sample_rate=2, max_wp=L.M
         rc = L.lib.ppn_extract_paths(_ptr(heat.contiguous()), n, h2, w2, _ptr(init), _ptr(end), max_wp, _ptr(wp), _ptr(wp_n),
                                      _ptr(ok), _sp(dev))
     L.check(rc, "ppn_extract_paths")
-    # [init_state] + waypoints * rate + [end_state]  (process_map.py:355-359)
-    full = torch.zeros(n, max_wp + 2, 2, dtype=torch.float64, device=dev)
-    full[:, 0] = init_state.to(torch.float64)
-    full[:, 1:max_wp + 1] = wp * down_sample_rate
-    idx = (wp_n.to(torch.int64) + 1).clamp(max=max_wp + 1)
-    full[torch.arange(n, device=dev), idx] = end_state.to(torch.float64)
-    return ok.bool(), full, torch.where(ok.bool(), wp_n + 2, torch.zeros_like(wp_n))
+    # [init_state] + waypoints * rate + [end_state]  (process_map.py:355-359), one kernel
+    full = torch.empty(n, max_wp + 2, 2, dtype=torch.float64, device=dev)
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    i64, e64 = init_state.to(torch.float64).contiguous(), end_state.to(torch.float64).contiguous()
+    with torch.cuda.device(dev):
+        rc = L.lib.ppn_assemble_paths(_ptr(wp), _ptr(wp_n), _ptr(ok), _ptr(i64), _ptr(e64), float(down_sample_rate), n, max_wp, _ptr(full),
+                                      _ptr(counts), _sp(dev))
+    L.check(rc, "ppn_assemble_paths")
+    return ok.bool(), full, counts
+
+
+def plan_collision(waypoints, counts, obstacles, n_obstacles, clearance, bound=224.0):
+    """collision [B] bool: does any consecutive-waypoint segment of plan b (waypoints [B,M,2] f64, counts [B] i32 valid points) hit
+    one of its first n_obstacles[b] obstacle rows obstacles[b] ([S,3]: ox, oy, size; float32 or float64)?  One launch for the
+    whole batch (process_map.py:491-495)."""
+    B, M = waypoints.shape[0], waypoints.shape[1]
+    obs = obstacles if obstacles.dtype in (torch.float32, torch.float64) else obstacles.to(torch.float32)
+    obs = obs.contiguous()
+    S = obs.shape[1]
+    out = torch.empty(B, dtype=torch.uint8, device=waypoints.device)
+    with torch.cuda.device(waypoints.device):
+        rc = L.lib.ppn_plan_collision(_ptr(waypoints.contiguous()), _ptr(counts.to(torch.int32).contiguous()), _ptr(obs),
+                                      1 if obs.dtype == torch.float64 else 0, _ptr(n_obstacles.to(torch.int32).contiguous()), B, M, S,
+                                      float(clearance), float(bound), _ptr(out), _sp(waypoints.device))
+    L.check(rc, "ppn_plan_collision")
+    return out.bool()
 
 
 def collision_segments(s, e, prob, obs, obs_off, clearance, bound=224.0):

@@ -98,23 +98,9 @@ class PPNet(torch.nn.Module):
     def plan_tail(self, heat, init, end, obstacles, n_obstacles, clearance=None, down_sample_rate=2, max_wp=L.MAX_WAYPOINTS):
         """extract_path + collision_check_circle_edge over the consecutive waypoints (process_map.py:486-503) for B
         8-bit heat maps [B,R,R].  max_wp: the walk's step cap (stands in for the reference's 1 s timeout)."""
-        B = heat.shape[0]
-        dev = heat.device
         if clearance is None:
             clearance = 1 / 50 * self.resolution
         ok, wp, cnt = plan.extract_paths(heat, init, end, down_sample_rate, max_wp)
-        # consecutive-waypoint segments of every problem -> one collision launch (process_map.py:491-495)
-        M = wp.shape[1]
-        s = wp[:, :-1].reshape(-1, 2).to(torch.float32)
-        e = wp[:, 1:].reshape(-1, 2).to(torch.float32)
-        prob = torch.arange(B, device=dev, dtype=torch.int32).repeat_interleave(M - 1)
-        seg_valid = (torch.arange(M - 1, device=dev)[None, :] < (cnt[:, None] - 1)).reshape(-1)
-        S = obstacles.shape[1]
-        obs = obstacles.reshape(-1, 3).to(torch.float32)
-        off = (torch.arange(B + 1, device=dev, dtype=torch.int32) * S)
-        # only the first n_obstacles rows of each problem are real: give the rest zero size far away
-        pad = (torch.arange(S, device=dev)[None, :] >= n_obstacles[:, None].to(torch.int64)).reshape(-1)
-        obs = torch.where(pad[:, None], torch.tensor([-1e6, -1e6, 0.0], device=dev), obs)
-        hit = plan.collision_segments(s, e, prob, obs, off, clearance, bound=self.resolution)
-        collision = (hit & seg_valid).reshape(B, M - 1).any(dim=1)
+        # consecutive-waypoint segments of every problem against its own obstacles: one launch (process_map.py:491-495)
+        collision = plan.plan_collision(wp, cnt, obstacles, n_obstacles, clearance, bound=self.resolution)
         return dict(ok=ok, waypoints=wp, counts=cnt, collision=collision, success=ok & ~collision)

@@ -128,3 +128,34 @@ def test_extract_paths_vs_oracle_random_heat(dev):
         if o_ok:
             assert int(cnt[t]) == len(o_path)
             assert np.abs(full[t, :len(o_path)].cpu().numpy() - o_path).max() < 1e-9     # waypoints are exact lattice sums
+
+
+def test_batched_plan_collision_equals_per_segment_kernel(dev):
+    """ppn_plan_collision (one launch per batch: segments from the waypoint array, each problem's own obstacle rows) against the
+    per-segment kernel ppn_collision_segments_bound driven by the explicit segment / CSR lists — same flags, float32 and float64
+    obstacle rows, ragged counts (0, 1, 2 and many points) and ragged obstacle counts."""
+    import torch
+    from ppnet_amd import plan
+    g = torch.Generator().manual_seed(12)
+    B, M, S, R = 37, 20, 9, 256
+    wp = (torch.rand(B, M, 2, generator=g, dtype=torch.float64) * R).to(dev)
+    counts = torch.randint(0, M + 1, (B,), generator=g, dtype=torch.int32).to(dev)
+    counts[:4] = torch.tensor([0, 1, 2, M], dtype=torch.int32)
+    obs64 = torch.cat([torch.rand(B, S, 2, generator=g, dtype=torch.float64) * R, torch.rand(B, S, 1, generator=g, dtype=torch.float64) * 12 + 1], dim=2).to(dev)
+    n_obs = torch.randint(0, S + 1, (B,), generator=g, dtype=torch.int32).to(dev)
+    n_obs[:2] = torch.tensor([0, S], dtype=torch.int32)
+    clearance = R / 50
+    # the explicit composition: every consecutive pair below the count, CSR of each problem's first n_obs rows
+    s = wp[:, :-1].reshape(-1, 2).float(); e = wp[:, 1:].reshape(-1, 2).float()
+    prob = torch.arange(B, device=dev, dtype=torch.int32).repeat_interleave(M - 1)
+    valid = (torch.arange(M - 1, device=dev)[None, :] < (counts[:, None] - 1)).reshape(-1)
+    rows = torch.cat([obs64[b, :int(n_obs[b])] for b in range(B)]).float()
+    off = torch.zeros(B + 1, dtype=torch.int32, device=dev); off[1:] = torch.cumsum(n_obs, 0)
+    if rows.numel() == 0:
+        rows = torch.zeros(1, 3, device=dev)
+    hit = plan.collision_segments(s, e, prob, rows, off, clearance, bound=R)
+    want = (hit & valid).reshape(B, M - 1).any(dim=1)
+    for obs in (obs64, obs64.float()):
+        got = plan.plan_collision(wp, counts, obs, n_obs, clearance, bound=R)
+        assert got.dtype == torch.bool and torch.equal(got, want)
+    assert 0 < int(want.sum()) < B
