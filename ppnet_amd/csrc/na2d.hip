@@ -370,6 +370,13 @@ int na2d_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out
     // the dilated layers this file's kernel is the faster one (it skips the padded keys; 0.23 vs 0.27, 0.056 vs 0.060 ms).
     // PPNET_NA_MFMA=1 sends every bfloat16 launch to the MFMA kernel.
     static const bool all_mfma = getenv("PPNET_NA_MFMA") != nullptr;
+    // launches whose dilation groups are exactly 7 x 7 (the grids padded to kernel * dilation): a dense 49-key attention per group,
+    // one wave per (image, group, head) on the matrix cores (na2d_dense7.hip).  PPNET_NA_NO_DENSE7=1 switches it off (A/B runs).
+    static const bool no_dense7 = getenv("PPNET_NA_NO_DENSE7") != nullptr;
+    if (dtype == 1 && !valu && !no_dense7) {
+        const int rc = na2d_dense7_launch(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
+        if (rc != -2) return rc;
+    }
     const int hq_ = (Hr + dil - 1) / dil, wq_ = (Wr + dil - 1) / dil;
     auto util = [&](int t) { return (double)(hq_ * wq_) / ((double)((hq_ + t - 1) / t * t) * ((wq_ + t - 1) / t * t)); };
     const bool region16 = !(util(8) > util(16) + 0.05) && !(util(4) > util(16) + 0.05);

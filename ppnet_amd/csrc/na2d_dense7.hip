@@ -1,0 +1,180 @@
+// na2d_dense7.hip — neighbourhood attention for launches whose dilation groups are exactly 7 x 7 (H = W = 7 * dilation, the
+// grids NATTEN zero-pads to kernel * dilation: DiNAT-B at 256 x 256 runs 10 of its 30 attention layers this way — dilation 16
+// at 64 x 64, 8 at 32 x 32, 3 and 4 at 16 x 16, 2 at 8 x 8; reference SegNet/nat.py:111-120, dinat.py).  With 7 keys per axis the
+// clamped window of EVERY query of a group is the whole group: the op is a dense 49-key attention per (image, group, head) with a
+// bias that depends only on the (query, key) positions inside the group — no halo, no sharing between groups.
+//
+// One WAVE per (image, group, head), nothing shared between waves (no barriers):
+//   K rows straight from global memory as the MFMA A operand (a padded key reads the qkv bias vector: "virtual padding",
+//   ppn_na2d_fwd_vpad; slots 49..63 read a zero line), V rows by global_load_lds into the wave's private 4 KB of LDS and back
+//   transposed (ds_read_b64_tr_b16), Q as the B operand (only the REAL queries: 16 per group at dilation 16 / 8 / 4 / 2),
+//   S^T = K . Q^T (4 MFMAs per 16 queries), logits = S^T * scale * log2 e + T with T[head][query position][key slot] a small
+//   float32 table built per launch (rpb gathered by relative position, -1e30 on slots 49..63), exact softmax over the 64 slots,
+//   O^T = V^T . P^T (4 MFMAs).  ~100 VALU instructions per 16 queries; the kernel is bound by its q / k / v reads and out writes.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <cstdlib>
+#include "ppn_device.h"
+#include "ppn_kernels.h"
+
+namespace ppn {
+
+namespace {
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+constexpr int G7 = 7, NK = 49, HD7 = 32, D7_WAVES = 4;
+}  // namespace
+
+// T[h][u * 7 + v][slot]: rpb[h][kr - u + 6][kc - v + 6] * log2 e for key slot = kr * 7 + kc < 49, -1e30 beyond
+__global__ __launch_bounds__(256) void na2d_dense7_table_kernel(const float* __restrict__ rpb, float* __restrict__ table, int heads) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= heads * NK * 64) return;
+    const int slot = idx & 63, qp = (idx >> 6) % NK, h = idx / (NK * 64);
+    float v = -1.0e30f;
+    if (slot < NK) {
+        const int u = qp / G7, w = qp - u * G7, kr = slot / G7, kc = slot - kr * G7;
+        v = rpb[(size_t)h * 169 + (kr - u + 6) * 13 + (kc - w + 6)] * 1.4426950408889634f;
+    }
+    table[idx] = v;
+}
+
+__global__ __launch_bounds__(64 * D7_WAVES) void na2d_dense7_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pad_kv,
+                                                                    const float* __restrict__ table, __bf16* __restrict__ out, int B, int Hr, int Wr,
+                                                                    int heads, int dil, float scale, long long n_items, const __bf16* __restrict__ zero) {
+    __shared__ __attribute__((aligned(16))) unsigned char vimg_all[D7_WAVES][64 * 64];      // per wave: 64 key slots x 32 bf16 of V
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    unsigned char* vimg = vimg_all[wave];
+    const int j = lane & 15, g = lane >> 4, q4 = j >> 2, p4 = j & 3;
+    const uint32_t tokb = 3u * heads * HD7 * 2u;                             // bytes per token row; every byte offset below fits 32 bits (checked by the launcher)
+    const float sl2 = scale * 1.4426950408889634f;
+    const unsigned char* qkvb = reinterpret_cast<const unsigned char*>(qkv);
+    const unsigned char* padb = reinterpret_cast<const unsigned char*>(pad_kv);
+    const unsigned char* zerob = reinterpret_cast<const unsigned char*>(zero);
+    // this lane's key slots (the same for every item): slot 16 t + j as the MFMA A row, slot p >> 2 for the V pieces
+    int kkr[4], kkc[4], vkr[4], vkc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int kk = 16 * t + j, vk = (t * 64 + lane) >> 2;
+        kkr[t] = kk < NK ? kk / G7 : 99; kkc[t] = kk % G7;                  // row 99: beyond the group (slots 49..63)
+        vkr[t] = vk < NK ? vk / G7 : 99; vkc[t] = vk % G7;
+    }
+    const long long stride = (long long)gridDim.x * D7_WAVES;
+    for (long long item = (long long)blockIdx.x * D7_WAVES + wave; item < n_items; item += stride) {
+        // item -> (image, group, head), head fastest: the heads of a token share its 128-byte lines
+        const int h = (int)(item % heads);
+        long long r = item / heads;
+        const int gj = (int)(r % dil); r /= dil;
+        const int gi = (int)(r % dil);
+        const int b = (int)(r / dil);
+        const int hq = gi < Hr ? (Hr - gi + dil - 1) / dil : 0, wq = gj < Wr ? (Wr - gj + dil - 1) / dil : 0;   // real rows / columns of the group
+        const int nq = hq * wq;
+        if (nq == 0) continue;                                               // a group of padding only: no queries (wave-uniform)
+        const uint32_t g0 = ((uint32_t)(b * Hr + gi) * Wr + gj) * tokb;      // the group's first token (wave-uniform)
+        const uint32_t rowb = (uint32_t)dil * Wr * tokb, colb = (uint32_t)dil * tokb;
+        const uint32_t kh = (uint32_t)(heads + h) * (HD7 * 2), vh = (uint32_t)(2 * heads + h) * (HD7 * 2);
+
+        // K fragments: real token, padded token (the qkv bias: virtual padding) or a zero line (slots 49..63)
+        bf16x8 kf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool slot = kkr[t] < G7, real = kkr[t] < hq && kkc[t] < wq;
+            const unsigned char* src = real ? qkvb + (g0 + kkr[t] * rowb + kkc[t] * colb + kh) : ((slot && padb) ? padb + kh : zerob);
+            kf[t] = *reinterpret_cast<const bf16x8*>(src + 16 * g);
+        }
+        // V rows -> LDS (piece p = slot * 4 + chunk lives at byte 16 p): four 1 KiB DMAs per wave
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const bool slot = vkr[it] < G7, real = vkr[it] < hq && vkc[it] < wq;
+            const unsigned char* src = real ? qkvb + (g0 + vkr[it] * rowb + vkc[it] * colb + vh) : ((slot && padb) ? padb + vh : zerob);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * (lane & 3)),
+                                             (__attribute__((address_space(3))) void*)(vimg + it * 1024), 16, 0, 0);
+        }
+        for (int qt = 0; qt * 16 < nq; ++qt) {                               // 16 real queries at a time (one tile unless dilation 3)
+            const int qq = qt * 16 + j;
+            const bool qvalid = qq < nq;
+            const int qc = qvalid ? qq : nq - 1;                             // dead columns shadow the last real query, never stored
+            const int u = qc / wq, v = qc - u * wq;
+            const uint32_t trow = g0 + u * rowb + v * colb;                  // byte offset of the query's token row
+            const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qkvb + (trow + (uint32_t)h * (HD7 * 2) + 16 * g));
+            f32x4 s[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const float* tb = table + ((h * NK + (u * G7 + v)) * 64 + 4 * g);
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(tb + 16 * t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[t][e] = __builtin_fmaf(s[t][e], sl2, bias[e]); mx = fmaxf(mx, s[t][e]); }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float p = __builtin_amdgcn_exp2f(s[t][e] - mx); s[t][e] = p; sum += p; }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            if (qt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the V DMAs of this item have landed (same wave: no barrier)
+            // O^T = V^T . P^T: k slot (g, e) of step ks is key 4g + (e & 3) of tile 2 ks + (e >> 2) — the S^T registers in place
+            f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f32x4 pa = s[2 * ks], pb = s[2 * ks + 1];
+                const bf16x8 pf = {(__bf16)pa[0], (__bf16)pa[1], (__bf16)pa[2], (__bf16)pa[3], (__bf16)pb[0], (__bf16)pb[1], (__bf16)pb[2], (__bf16)pb[3]};
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const unsigned char* va = vimg + (32 * ks + 4 * g + q4) * 64 + 8 * p4 + cb * 32;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va + 16 * 64));
+                    const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[cb], 0, 0, 0);
+                }
+            }
+            if (qvalid) {
+                const float inv = 1.0f / sum;
+                // the output row of a token is a third of its qkv row: byte offset trow / 3
+                unsigned char* dst = reinterpret_cast<unsigned char*>(out) + (trow / 3u + (uint32_t)h * (HD7 * 2) + 8 * g);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+                    *reinterpret_cast<uint2*>(dst + cb * 32) = make_uint2(pack_bf16x2(o[cb][0] * inv, o[cb][1] * inv), pack_bf16x2(o[cb][2] * inv, o[cb][3] * inv));
+            }
+        }
+        // the next item's DMAs overwrite this wave's V image: its transposed reads must have returned (wave-local ordering)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// Serves a launch when every dilation group is 7 x 7: H == W == 7 * dil (the padded grid of the vpad entry point, or a real grid
+// of exactly that size).  Hr, Wr: the stored (real) token grid.  Returns -2 when the launch is not of this form.
+int na2d_dense7_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
+                       float scale, hipStream_t stream) {
+    if (H != G7 * dil || W != G7 * dil || (!pad_kv && (Hr != H || Wr != W))) return -2;
+    const __bf16* zero = (const __bf16*)zero_line();
+    if (!zero) return (int)hipErrorOutOfMemory;
+    const long long items = (long long)B * dil * dil * heads;
+    if (items <= 0 || (long long)B * Hr * Wr * 3 * heads * HD7 * 2 >= (1LL << 32)) return -2;     // 32-bit byte offsets inside
+    float* table = nullptr;                                                    // stream-ordered scratch, freed behind the attention kernel
+    const size_t tbytes = (size_t)heads * NK * 64 * sizeof(float);
+    hipError_t e = hipMallocAsync((void**)&table, tbytes, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(na2d_dense7_table_kernel, dim3((unsigned)((heads * NK * 64 + 255) / 256)), dim3(256), 0, stream, rpb, table, heads);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const long long want = (items + D7_WAVES - 1) / D7_WAVES;
+    const long long grid = want < (long long)cus * 8 ? want : (long long)cus * 8;          // 8 workgroups of 4 waves per CU, grid-stride over the rest
+    hipLaunchKernelGGL(na2d_dense7_kernel, dim3((unsigned)grid), dim3(64 * D7_WAVES), 0, stream, (const __bf16*)qkv, (const __bf16*)pad_kv, table,
+                       (__bf16*)out, B, Hr, Wr, heads, dil, scale, items, zero);
+    e = hipGetLastError();
+    const hipError_t f = hipFreeAsync(table, stream);
+    return (int)(e != hipSuccess ? e : f);
+}
+
+}  // namespace ppn
