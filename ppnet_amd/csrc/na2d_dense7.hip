@@ -1,8 +1,9 @@
-// na2d_dense7.hip — neighbourhood attention for launches whose dilation groups are exactly 7 x 7 (H = W = 7 * dilation, the
+// na2d_dense7.hip — neighbourhood attention for launches whose dilation groups are exactly 7 x 7 or 8 x 8.  7 x 7 (H = W = 7 * dilation, the
 // grids NATTEN zero-pads to kernel * dilation: DiNAT-B at 256 x 256 runs 10 of its 30 attention layers this way — dilation 16
 // at 64 x 64, 8 at 32 x 32, 3 and 4 at 16 x 16, 2 at 8 x 8; reference SegNet/nat.py:111-120, dinat.py).  With 7 keys per axis the
 // clamped window of EVERY query of a group is the whole group: the op is a dense 49-key attention per (image, group, head) with a
-// bias that depends only on the (query, key) positions inside the group — no halo, no sharing between groups.
+// bias that depends only on the (query, key) positions inside the group — no halo, no sharing between groups.  8 x 8 groups (dilation
+// 4 at 32 x 32, 2 at 16 x 16, 1 at 8 x 8) are the same thing with 64 keys and each query's 49-key window applied through the table.
 //
 // One WAVE per (image, group, head), nothing shared between waves (no barriers):
 //   K rows straight from global memory as the MFMA A operand (a padded key reads the qkv bias vector: "virtual padding",
@@ -25,25 +26,31 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-constexpr int G7 = 7, NK = 49, HD7 = 32, D7_WAVES = 4;
+constexpr int HD7 = 32, D7_WAVES = 4;
 }  // namespace
 
-// T[h][u * 7 + v][slot]: rpb[h][kr - u + 6][kc - v + 6] * log2 e for key slot = kr * 7 + kc < 49, -1e30 beyond
-__global__ __launch_bounds__(256) void na2d_dense7_table_kernel(const float* __restrict__ rpb, float* __restrict__ table, int heads) {
+// T[h][u * G + v][slot]: rpb[h][kr - u + 6][kc - v + 6] * log2 e for key slot = kr * G + kc inside the query's window
+// (start clamp(u - 3, 0, G - 7) per axis: the whole group for G = 7), -1e30 outside it and on slots >= G * G
+template <int G>
+__global__ __launch_bounds__(256) void na2d_dense_table_kernel(const float* __restrict__ rpb, float* __restrict__ table, int heads) {
+    constexpr int NK = G * G;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= heads * NK * 64) return;
     const int slot = idx & 63, qp = (idx >> 6) % NK, h = idx / (NK * 64);
     float v = -1.0e30f;
     if (slot < NK) {
-        const int u = qp / G7, w = qp - u * G7, kr = slot / G7, kc = slot - kr * G7;
-        v = rpb[(size_t)h * 169 + (kr - u + 6) * 13 + (kc - w + 6)] * 1.4426950408889634f;
+        const int u = qp / G, w = qp - u * G, kr = slot / G, kc = slot - kr * G;
+        const int wu = min(max(u - 3, 0), G - 7), ww = min(max(w - 3, 0), G - 7);
+        if (kr >= wu && kr < wu + 7 && kc >= ww && kc < ww + 7) v = rpb[(size_t)h * 169 + (kr - u + 6) * 13 + (kc - w + 6)] * 1.4426950408889634f;
     }
     table[idx] = v;
 }
 
+template <int G7>
 __global__ __launch_bounds__(64 * D7_WAVES) void na2d_dense7_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pad_kv,
                                                                     const float* __restrict__ table, __bf16* __restrict__ out, int B, int Hr, int Wr,
                                                                     int heads, int dil, float scale, long long n_items, const __bf16* __restrict__ zero) {
+    constexpr int NK = G7 * G7;                                            // 49 or 64 key slots in use
     __shared__ __attribute__((aligned(16))) unsigned char vimg_all[D7_WAVES][64 * 64];      // per wave: 64 key slots x 32 bf16 of V
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     unsigned char* vimg = vimg_all[wave];
@@ -99,17 +106,20 @@ __global__ __launch_bounds__(64 * D7_WAVES) void na2d_dense7_kernel(const __bf16
             const int u = qc / wq, v = qc - u * wq;
             const uint32_t trow = g0 + u * rowb + v * colb;                  // byte offset of the query's token row
             const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qkvb + (trow + (uint32_t)h * (HD7 * 2) + 16 * g));
+            // the table rows are requested together with q (one memory round trip per tile, not two); indexed by the position in the group
+            const float* tb = table + ((h * NK + (u * G7 + v)) * 64 + 4 * g);
+            f32x4 bias[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bias[t] = *reinterpret_cast<const f32x4*>(tb + 16 * t);
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 s[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            const float* tb = table + ((h * NK + (u * G7 + v)) * 64 + 4 * g);
             float mx = -3.0e38f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(tb + 16 * t);
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { s[t][e] = __builtin_fmaf(s[t][e], sl2, bias[e]); mx = fmaxf(mx, s[t][e]); }
-            }
+                for (int e = 0; e < 4; ++e) { s[t][e] = __builtin_fmaf(s[t][e], sl2, bias[t][e]); mx = fmaxf(mx, s[t][e]); }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             float sum = 0.f;
@@ -149,20 +159,15 @@ __global__ __launch_bounds__(64 * D7_WAVES) void na2d_dense7_kernel(const __bf16
     }
 }
 
-// Serves a launch when every dilation group is 7 x 7: H == W == 7 * dil (the padded grid of the vpad entry point, or a real grid
-// of exactly that size).  Hr, Wr: the stored (real) token grid.  Returns -2 when the launch is not of this form.
-int na2d_dense7_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
-                       float scale, hipStream_t stream) {
-    if (H != G7 * dil || W != G7 * dil || (!pad_kv && (Hr != H || Wr != W))) return -2;
-    const __bf16* zero = (const __bf16*)zero_line();
-    if (!zero) return (int)hipErrorOutOfMemory;
+template <int G>
+static int launch_dense_groups(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int Hr, int Wr, int heads, int dil, float scale,
+                               const __bf16* zero, hipStream_t stream) {
     const long long items = (long long)B * dil * dil * heads;
-    if (items <= 0 || (long long)B * Hr * Wr * 3 * heads * HD7 * 2 >= (1LL << 32)) return -2;     // 32-bit byte offsets inside
     float* table = nullptr;                                                    // stream-ordered scratch, freed behind the attention kernel
-    const size_t tbytes = (size_t)heads * NK * 64 * sizeof(float);
-    hipError_t e = hipMallocAsync((void**)&table, tbytes, stream);
+    const int n = heads * G * G * 64;
+    hipError_t e = hipMallocAsync((void**)&table, (size_t)n * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(na2d_dense7_table_kernel, dim3((unsigned)((heads * NK * 64 + 255) / 256)), dim3(256), 0, stream, rpb, table, heads);
+    hipLaunchKernelGGL(na2d_dense_table_kernel<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rpb, table, heads);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
@@ -170,11 +175,26 @@ int na2d_dense7_launch(const void* qkv, const void* pad_kv, const float* rpb, vo
     }
     const long long want = (items + D7_WAVES - 1) / D7_WAVES;
     const long long grid = want < (long long)cus * 8 ? want : (long long)cus * 8;          // 8 workgroups of 4 waves per CU, grid-stride over the rest
-    hipLaunchKernelGGL(na2d_dense7_kernel, dim3((unsigned)grid), dim3(64 * D7_WAVES), 0, stream, (const __bf16*)qkv, (const __bf16*)pad_kv, table,
+    hipLaunchKernelGGL(na2d_dense7_kernel<G>, dim3((unsigned)grid), dim3(64 * D7_WAVES), 0, stream, (const __bf16*)qkv, (const __bf16*)pad_kv, table,
                        (__bf16*)out, B, Hr, Wr, heads, dil, scale, items, zero);
     e = hipGetLastError();
     const hipError_t f = hipFreeAsync(table, stream);
     return (int)(e != hipSuccess ? e : f);
+}
+
+// Serves a launch when every dilation group is 7 x 7 (H == W == 7 * dil: the padded grid of the vpad entry point, or a real grid of
+// exactly that size) or 8 x 8 (H == W == 8 * dil, all tokens real: 64 keys per group, each query masked to its 49 by the table).
+// Hr, Wr: the stored (real) token grid.  Returns -2 when the launch is not of this form.
+int na2d_dense7_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
+                       float scale, hipStream_t stream) {
+    const bool g7 = H == 7 * dil && W == 7 * dil && (pad_kv || (Hr == H && Wr == W));
+    const bool g8 = H == 8 * dil && W == 8 * dil && Hr == H && Wr == W;
+    if (!g7 && !g8) return -2;
+    const __bf16* zero = (const __bf16*)zero_line();
+    if (!zero) return (int)hipErrorOutOfMemory;
+    if ((long long)B * dil * dil * heads <= 0 || (long long)B * Hr * Wr * 3 * heads * HD7 * 2 >= (1LL << 32)) return -2;     // 32-bit byte offsets inside
+    return g7 ? launch_dense_groups<7>(qkv, pad_kv, rpb, out, B, Hr, Wr, heads, dil, scale, zero, stream)
+              : launch_dense_groups<8>(qkv, pad_kv, rpb, out, B, Hr, Wr, heads, dil, scale, zero, stream);
 }
 
 }  // namespace ppn

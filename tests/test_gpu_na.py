@@ -36,7 +36,8 @@ def test_kernel_vs_oracle_f32(dev, B, H, W, heads, d):
     assert np.abs(got - want).max() < 2e-5
 
 
-@pytest.mark.parametrize("B,H,W,heads,d", [(2, 20, 17, 2, 2), (1, 64, 64, 4, 1), (2, 56, 56, 2, 8), (3, 7, 7, 1, 1), (1, 21, 21, 3, 3)])   # the last three: 7 x 7 groups (na2d_dense7.hip)
+@pytest.mark.parametrize("B,H,W,heads,d", [(2, 20, 17, 2, 2), (1, 64, 64, 4, 1), (2, 56, 56, 2, 8), (3, 7, 7, 1, 1), (1, 21, 21, 3, 3),
+                                           (2, 16, 16, 2, 2), (3, 8, 8, 3, 1), (1, 32, 32, 1, 4)])   # 7 x 7 and 8 x 8 dilation groups: na2d_dense7.hip
 def test_kernel_vs_oracle_bf16(dev, B, H, W, heads, d):
     import torch
     from ppnet_amd import na
