@@ -16,6 +16,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <cstdlib>
+#include <algorithm>
 #include "ppn_device.h"
 #include "ppn_kernels.h"
 
@@ -51,7 +52,9 @@ __global__ __launch_bounds__(64 * D7_WAVES) void na2d_dense7_kernel(const __bf16
                                                                     const float* __restrict__ table, __bf16* __restrict__ out, int B, int Hr, int Wr,
                                                                     int heads, int dil, float scale, long long n_items, const __bf16* __restrict__ zero) {
     constexpr int NK = G7 * G7;                                            // 49 or 64 key slots in use
+    constexpr int TP = 68;                                                 // table row pitch in floats: 16 consecutive rows start on 16 different bank groups
     __shared__ __attribute__((aligned(16))) unsigned char vimg_all[D7_WAVES][64 * 64];      // per wave: 64 key slots x 32 bf16 of V
+    __shared__ __attribute__((aligned(16))) float tl[NK * TP];             // this workgroup's head of the bias / window table
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     unsigned char* vimg = vimg_all[wave];
     const int j = lane & 15, g = lane >> 4, q4 = j >> 2, p4 = j & 3;
@@ -68,14 +71,19 @@ __global__ __launch_bounds__(64 * D7_WAVES) void na2d_dense7_kernel(const __bf16
         kkr[t] = kk < NK ? kk / G7 : 99; kkc[t] = kk % G7;                  // row 99: beyond the group (slots 49..63)
         vkr[t] = vk < NK ? vk / G7 : 99; vkc[t] = vk % G7;
     }
-    const long long stride = (long long)gridDim.x * D7_WAVES;
-    for (long long item = (long long)blockIdx.x * D7_WAVES + wave; item < n_items; item += stride) {
-        // item -> (image, group, head), head fastest: the heads of a token share its 128-byte lines
-        const int h = (int)(item % heads);
-        long long r = item / heads;
-        const int gj = (int)(r % dil); r /= dil;
-        const int gi = (int)(r % dil);
-        const int b = (int)(r / dil);
+    // A workgroup keeps ONE head (its table rows live in LDS, read 4 x 16 bytes per query tile instead of 4 KB per item from
+    // L2) and walks groups four at a time, one per wave.  Workgroups w and w + 8 sit on the same XCD (round-robin dispatch) and
+    // take the same groups with neighbouring heads, so the two heads of a 128-byte line still meet in one L2.
+    const int h = (int)((blockIdx.x >> 3) % heads);
+    const long long slot0 = (long long)(blockIdx.x / (8 * heads)) * 8 + (blockIdx.x & 7), nslots = (long long)(gridDim.x / (8 * heads)) * 8;
+    for (int i = threadIdx.x; i < NK * 64; i += 64 * D7_WAVES) tl[(i >> 6) * TP + (i & 63)] = table[(size_t)h * NK * 64 + i];
+    __syncthreads();
+    for (long long gq = slot0; gq * D7_WAVES < n_items; gq += nslots) {
+        const long long grp = gq * D7_WAVES + wave;                          // n_items = number of (image, group) pairs
+        if (grp >= n_items) break;
+        const int gj = (int)(grp % dil);
+        const int gi = (int)((grp / dil) % dil);
+        const int b = (int)(grp / ((long long)dil * dil));
         const int hq = gi < Hr ? (Hr - gi + dil - 1) / dil : 0, wq = gj < Wr ? (Wr - gj + dil - 1) / dil : 0;   // real rows / columns of the group
         const int nq = hq * wq;
         if (nq == 0) continue;                                               // a group of padding only: no queries (wave-uniform)
@@ -106,12 +114,11 @@ __global__ __launch_bounds__(64 * D7_WAVES) void na2d_dense7_kernel(const __bf16
             const int u = qc / wq, v = qc - u * wq;
             const uint32_t trow = g0 + u * rowb + v * colb;                  // byte offset of the query's token row
             const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qkvb + (trow + (uint32_t)h * (HD7 * 2) + 16 * g));
-            // the table rows are requested together with q (one memory round trip per tile, not two); indexed by the position in the group
-            const float* tb = table + ((h * NK + (u * G7 + v)) * 64 + 4 * g);
+            // bias / window rows of this query's position in the group, from LDS
+            const float* tb = tl + (u * G7 + v) * TP + 4 * g;
             f32x4 bias[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) bias[t] = *reinterpret_cast<const f32x4*>(tb + 16 * t);
-            __builtin_amdgcn_sched_barrier(0);
             f32x4 s[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(64 * D7_WAVES) void na2d_dense7_kernel(const __bf16
 template <int G>
 static int launch_dense_groups(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int Hr, int Wr, int heads, int dil, float scale,
                                const __bf16* zero, hipStream_t stream) {
-    const long long items = (long long)B * dil * dil * heads;
+    const long long groups = (long long)B * dil * dil;
     float* table = nullptr;                                                    // stream-ordered scratch, freed behind the attention kernel
     const int n = heads * G * G * 64;
     hipError_t e = hipMallocAsync((void**)&table, (size_t)n * sizeof(float), stream);
@@ -173,10 +180,11 @@ static int launch_dense_groups(const void* qkv, const void* pad_kv, const float*
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    const long long want = (items + D7_WAVES - 1) / D7_WAVES;
-    const long long grid = want < (long long)cus * 8 ? want : (long long)cus * 8;          // 8 workgroups of 4 waves per CU, grid-stride over the rest
-    hipLaunchKernelGGL(na2d_dense7_kernel<G>, dim3((unsigned)grid), dim3(64 * D7_WAVES), 0, stream, (const __bf16*)qkv, (const __bf16*)pad_kv, table,
-                       (__bf16*)out, B, Hr, Wr, heads, dil, scale, items, zero);
+    // workgroups come in sets of 8 * heads (one head each, see the kernel): as many sets as fill ~5 workgroups per CU, at least one
+    const long long per_set = 8LL * heads, want_sets = ((groups + D7_WAVES - 1) / D7_WAVES + 7) / 8;
+    long long sets = std::max<long long>(1, std::min<long long>(want_sets, ((long long)cus * 5) / per_set));
+    hipLaunchKernelGGL(na2d_dense7_kernel<G>, dim3((unsigned)(sets * per_set)), dim3(64 * D7_WAVES), 0, stream, (const __bf16*)qkv, (const __bf16*)pad_kv,
+                       table, (__bf16*)out, B, Hr, Wr, heads, dil, scale, groups, zero);
     e = hipGetLastError();
     const hipError_t f = hipFreeAsync(table, stream);
     return (int)(e != hipSuccess ? e : f);
@@ -192,7 +200,7 @@ int na2d_dense7_launch(const void* qkv, const void* pad_kv, const float* rpb, vo
     if (!g7 && !g8) return -2;
     const __bf16* zero = (const __bf16*)zero_line();
     if (!zero) return (int)hipErrorOutOfMemory;
-    if ((long long)B * dil * dil * heads <= 0 || (long long)B * Hr * Wr * 3 * heads * HD7 * 2 >= (1LL << 32)) return -2;     // 32-bit byte offsets inside
+    if ((long long)B * dil * dil <= 0 || (long long)B * Hr * Wr * 3 * heads * HD7 * 2 >= (1LL << 32)) return -2;     // 32-bit byte offsets inside
     return g7 ? launch_dense_groups<7>(qkv, pad_kv, rpb, out, B, Hr, Wr, heads, dil, scale, zero, stream)
               : launch_dense_groups<8>(qkv, pad_kv, rpb, out, B, Hr, Wr, heads, dil, scale, zero, stream);
 }
