@@ -5,13 +5,14 @@
 // bias that depends only on the (query, key) positions inside the group — no halo, no sharing between groups.  8 x 8 groups (dilation
 // 4 at 32 x 32, 2 at 16 x 16, 1 at 8 x 8) are the same thing with 64 keys and each query's 49-key window applied through the table.
 //
-// One WAVE per (image, group, head), nothing shared between waves (no barriers):
+// One WAVE per (image, group, head); a workgroup's four waves share only their head's bias table (staged once, no barrier after):
 //   K rows straight from global memory as the MFMA A operand (a padded key reads the qkv bias vector: "virtual padding",
 //   ppn_na2d_fwd_vpad; slots 49..63 read a zero line), V rows by global_load_lds into the wave's private 4 KB of LDS and back
 //   transposed (ds_read_b64_tr_b16), Q as the B operand (only the REAL queries: 16 per group at dilation 16 / 8 / 4 / 2),
 //   S^T = K . Q^T (4 MFMAs per 16 queries), logits = S^T * scale * log2 e + T with T[head][query position][key slot] a small
-//   float32 table built per launch (rpb gathered by relative position, -1e30 on slots 49..63), exact softmax over the 64 slots,
-//   O^T = V^T . P^T (4 MFMAs).  ~100 VALU instructions per 16 queries; the kernel is bound by its q / k / v reads and out writes.
+//   float32 table built per launch (rpb gathered by relative position, -1e30 outside the window and on slots 49..63) whose rows for
+//   the workgroup's head live in LDS, exact softmax over the 64 slots, O^T = V^T . P^T (4 MFMAs).  ~100 VALU instructions per 16
+//   queries; one memory round trip per item, so the kernel runs at the latency x occupancy product: 3.3-4.2 TB/s of algorithmic bytes.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
