@@ -28,7 +28,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-constexpr int HD7 = 32, D7_WAVES = 4;
+constexpr int HD7 = 32, D7_WAVES = 8;
 }  // namespace
 
 // T[h][u * G + v][slot]: rpb[h][kr - u + 6][kc - v + 6] * log2 e for key slot = kr * G + kc inside the query's window
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void na2d_dense_table_kernel(const float* __re
 }
 
 template <int G7>
-__global__ __launch_bounds__(64 * D7_WAVES) void na2d_dense7_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pad_kv,
+__global__ __launch_bounds__(64 * D7_WAVES, 6) void na2d_dense7_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pad_kv,
                                                                     const float* __restrict__ table, __bf16* __restrict__ out, int B, int Hr, int Wr,
                                                                     int heads, int dil, float scale, long long n_items, const __bf16* __restrict__ zero) {
     constexpr int NK = G7 * G7;                                            // 49 or 64 key slots in use
@@ -65,13 +65,6 @@ __global__ __launch_bounds__(64 * D7_WAVES) void na2d_dense7_kernel(const __bf16
     const unsigned char* padb = reinterpret_cast<const unsigned char*>(pad_kv);
     const unsigned char* zerob = reinterpret_cast<const unsigned char*>(zero);
     // this lane's key slots (the same for every item): slot 16 t + j as the MFMA A row, slot p >> 2 for the V pieces
-    int kkr[4], kkc[4], vkr[4], vkc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int kk = 16 * t + j, vk = (t * 64 + lane) >> 2;
-        kkr[t] = kk < NK ? kk / G7 : 99; kkc[t] = kk % G7;                  // row 99: beyond the group (slots 49..63)
-        vkr[t] = vk < NK ? vk / G7 : 99; vkc[t] = vk % G7;
-    }
     // A workgroup keeps ONE head (its table rows live in LDS, read 4 x 16 bytes per query tile instead of 4 KB per item from
     // L2) and walks groups four at a time, one per wave.  Workgroups w and w + 8 sit on the same XCD (round-robin dispatch) and
     // take the same groups with neighbouring heads, so the two heads of a 128-byte line still meet in one L2.
@@ -92,19 +85,27 @@ __global__ __launch_bounds__(64 * D7_WAVES) void na2d_dense7_kernel(const __bf16
         const uint32_t rowb = (uint32_t)dil * Wr * tokb, colb = (uint32_t)dil * tokb;
         const uint32_t kh = (uint32_t)(heads + h) * (HD7 * 2), vh = (uint32_t)(2 * heads + h) * (HD7 * 2);
 
+        // this lane's key slots, recomputed per item from an opaque copy of the lane id: as loop invariants they would pin eight
+        // registers, and this kernel's throughput is its occupancy (80 VGPRs = 6 waves per SIMD; a spill would put scratch traffic
+        // into the same in-order vmcnt queue as the loads below)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int j_o = lane_o & 15;
         // K fragments: real token, padded token (the qkv bias: virtual padding) or a zero line (slots 49..63)
         bf16x8 kf[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bool slot = kkr[t] < G7, real = kkr[t] < hq && kkc[t] < wq;
-            const unsigned char* src = real ? qkvb + (g0 + kkr[t] * rowb + kkc[t] * colb + kh) : ((slot && padb) ? padb + kh : zerob);
+            const int kk = 16 * t + j_o, kr = kk < NK ? kk / G7 : 99, kc = kk % G7;       // row 99: beyond the group (slots 49..63)
+            const bool slot = kr < G7, real = kr < hq && kc < wq;
+            const unsigned char* src = real ? qkvb + (g0 + kr * rowb + kc * colb + kh) : ((slot && padb) ? padb + kh : zerob);
             kf[t] = *reinterpret_cast<const bf16x8*>(src + 16 * g);
         }
         // V rows -> LDS (piece p = slot * 4 + chunk lives at byte 16 p): four 1 KiB DMAs per wave
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const bool slot = vkr[it] < G7, real = vkr[it] < hq && vkc[it] < wq;
-            const unsigned char* src = real ? qkvb + (g0 + vkr[it] * rowb + vkc[it] * colb + vh) : ((slot && padb) ? padb + vh : zerob);
+            const int vk = (it * 64 + lane_o) >> 2, kr = vk < NK ? vk / G7 : 99, kc = vk % G7;
+            const bool slot = kr < G7, real = kr < hq && kc < wq;
+            const unsigned char* src = real ? qkvb + (g0 + kr * rowb + kc * colb + vh) : ((slot && padb) ? padb + vh : zerob);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * (lane & 3)),
                                              (__attribute__((address_space(3))) void*)(vimg + it * 1024), 16, 0, 0);
         }
@@ -117,17 +118,16 @@ __global__ __launch_bounds__(64 * D7_WAVES) void na2d_dense7_kernel(const __bf16
             const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qkvb + (trow + (uint32_t)h * (HD7 * 2) + 16 * g));
             // bias / window rows of this query's position in the group, from LDS
             const float* tb = tl + (u * G7 + v) * TP + 4 * g;
-            f32x4 bias[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) bias[t] = *reinterpret_cast<const f32x4*>(tb + 16 * t);
             f32x4 s[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             float mx = -3.0e38f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(tb + 16 * t);             // LDS: read where it is used
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { s[t][e] = __builtin_fmaf(s[t][e], sl2, bias[t][e]); mx = fmaxf(mx, s[t][e]); }
+                for (int e = 0; e < 4; ++e) { s[t][e] = __builtin_fmaf(s[t][e], sl2, bias[e]); mx = fmaxf(mx, s[t][e]); }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             float sum = 0.f;
@@ -181,9 +181,9 @@ static int launch_dense_groups(const void* qkv, const void* pad_kv, const float*
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    // workgroups come in sets of 8 * heads (one head each, see the kernel): as many sets as fill ~5 workgroups per CU, at least one
+    // workgroups come in sets of 8 * heads (one head each, see the kernel): as many sets as fill the 3 workgroups (24 waves) a CU holds, at least one
     const long long per_set = 8LL * heads, want_sets = ((groups + D7_WAVES - 1) / D7_WAVES + 7) / 8;
-    long long sets = std::max<long long>(1, std::min<long long>(want_sets, ((long long)cus * 5) / per_set));
+    long long sets = std::max<long long>(1, std::min<long long>(want_sets, ((long long)cus * 3) / per_set));
     hipLaunchKernelGGL(na2d_dense7_kernel<G>, dim3((unsigned)(sets * per_set)), dim3(64 * D7_WAVES), 0, stream, (const __bf16*)qkv, (const __bf16*)pad_kv,
                        table, (__bf16*)out, B, Hr, Wr, heads, dil, scale, groups, zero);
     e = hipGetLastError();
