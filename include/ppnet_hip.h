@@ -335,6 +335,16 @@ int ppn_conv3x3_relu_classify2_bf16(const void* x, const void* w, const float* b
  * bias [32] float32 (24..31 zero). */
 int ppn_gennet_conv_s2_bf16(const void* x, const void* w, const float* bias, void* y, int32_t B, int32_t H, int32_t W, float negative_slope,
                             int32_t transposed, void* stream);
+/* GenNet's first convolution fused into its first encoder stage (ae_vit.py:24-36: Conv2d(1, 24, 3, 1, 1) + BN + LeakyReLU, then
+ * Conv2d(24, 24, 3, 2, 1) + BN + LeakyReLU; BatchNorms folded by the caller): x1 [B][H][W] bfloat16 -> y [B][H/2][W/2][24] bfloat16, the
+ * 24-channel full-resolution tensor in between never reaches memory.  H, W even.
+ *   w1 [2][16][32] bfloat16: row = channel (24..31 zero), columns 0..8 = bfloat16(w[c][tap]) (hi), 16..24 = bfloat16(w - hi) (lo),
+ *       columns 9 / 25 = hi / lo of the bias (the kernel feeds a constant 1 there), else 0;  b1 [32] float32: unused, kept for the layout;
+ *   the first LeakyReLU's slope must be <= 1;
+ *   wk2 [2][9][16][32] bfloat16: [co tile][tap ky*3+kx][co row][k-slot], slot 8g + e = input channel 4g + e (e < 4) or
+ *       16 + 4g + e - 4 (e >= 4, g < 2; zero for g >= 2);  bias2 [32] float32.  ppnet_amd/gennet.py packs all four. */
+int ppn_gennet_first_enc_bf16(const void* x1, const void* w1, const float* b1, const void* wk2, const float* bias2, void* y, int32_t B, int32_t H, int32_t W,
+                              float slope1, float slope2, void* stream);
 /* The ViT blocks of GenNet's AE-ViT (ae_vit.py:38-42,68-70; vit.py:88-161: pre-LN attention + MLP residual blocks, dim 24, 3 heads,
  * MLP x4, LayerNorm eps 1e-6, erf GELU) as one kernel: x, y [B][N][24] bfloat16 token rows (the NHWC feature map), N <= 1024,
  * N % 8 == 0.  One workgroup per problem holds the residual stream in registers (float32) across all n_blocks blocks and the

@@ -466,6 +466,14 @@ int ppn_gennet_conv_s2_bf16(const void* x, const void* w, const float* bias, voi
     return PPN_OK;
 }
 
+int ppn_gennet_first_enc_bf16(const void* x1, const void* w1, const float* b1, const void* wk2, const float* bias2, void* y, int32_t B, int32_t H, int32_t W,
+                              float slope1, float slope2, void* stream) {
+    if (!x1 || !w1 || !b1 || !wk2 || !bias2 || !y || B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1)) return PPN_E_INVALID;
+    const int e = ppn::gennet_first_enc_launch(x1, w1, b1, wk2, bias2, y, B, H, W, slope1, slope2, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_gennet_trunk_bf16(const void* x, void* y, const float* params, int32_t B, int32_t N, int32_t n_blocks, void* stream) {
     if (!x || !y || !params || B <= 0 || N <= 0 || N > 1024 || (N % 8) != 0 || n_blocks <= 0) return PPN_E_INVALID;
     const int e = ppn::gennet_trunk_launch(x, y, params, B, N, n_blocks, (hipStream_t)stream);

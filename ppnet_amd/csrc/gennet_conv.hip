@@ -136,6 +136,113 @@ __global__ __launch_bounds__(256) void gennet_dec_conv_kernel(const __bf16* __re
     }
 }
 
+// GenNet's first convolution (1 -> 24, 3x3, stride 1, + BN + LeakyReLU, ae_vit.py:24-28) FUSED into the first encoder stage
+// (24 -> 24, stride 2): the 24-channel full-resolution tensor between them (805 MB at batch 256, 256 x 256) is never written.
+// Per 16 output pixels and per encoder tap t (9 of them), the first convolution's output at the tap's position is itself a
+// matrix product — [24 channels] x [9 input taps + 1], weights split hi + lo bfloat16 into one K = 32 step (slots 0..8 hi, 16..24
+// lo; the input values sit in both halves; slots 9 / 25 carry the bias against a constant 1) — whose accumulator layout (lane = pixel, 4 consecutive channels per register group of
+// each of the two channel tiles) is taken AS the encoder product's B operand: the encoder's k order is free, so tap t is one
+// k-step whose slot (g, e) is channel 4g + e (e < 4) or 16 + 4g + e - 4 (e >= 4, g < 2), and the weights are packed to match.
+// 2 + 2 MFMAs per tap, LeakyReLU + zero-padding mask on 8 values per lane in between (slope1 must be <= 1); every lane keeps the 5 x 5 input
+// patch of its pixel (15 dword loads) and cuts the nine 3 x 3 windows out of it.
+//   x1: [B][H][W] bfloat16;  w1: [2 tiles][16 rows][32] bfloat16 (hi | lo as above incl. the bias columns, rows = channel);
+//   wk2: [2 tiles][9 taps][16 rows co][32 k-slots] bfloat16;  bias2: [32] float32;  y: [B][H/2][W/2][24] bfloat16.
+__global__ __launch_bounds__(256) void gennet_first_enc_kernel(const __bf16* __restrict__ x1, const __bf16* __restrict__ w1, const float* __restrict__ /*b1: inside w1*/,
+                                                               const __bf16* __restrict__ wk2, const float* __restrict__ bias2, __bf16* __restrict__ y,
+                                                               int B, int H, int W, float slope1, float slope2) {
+    const int lane = threadIdx.x & 63, pl = lane & 15, g = lane >> 4;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long long total = (long long)B * Ho * Wo;
+    bf16x8 wa1[2], wa2[2][9];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        wa1[nt] = ld8(w1 + (nt * 16 + pl) * 32 + g * 8);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wa2[nt][t] = ld8(wk2 + ((nt * 9 + t) * 16 + pl) * 32 + g * 8);
+    }
+    const float4 d0 = *reinterpret_cast<const float4*>(bias2 + 4 * g), d1 = *reinterpret_cast<const float4*>(bias2 + 16 + 4 * g);
+    // 32-bit index arithmetic throughout (the launcher checks B * H * W < 2^31): 64-bit divisions cost hundreds of instructions per iteration
+    const uint32_t total32 = (uint32_t)total, wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const uint32_t per_img = (uint32_t)Wo * Ho;
+    for (uint32_t base = wave * 16; base < total32; base += nwaves * 16) {
+        uint32_t pix = base + pl;
+        const bool live = pix < total32;
+        if (!live) pix = total32 - 1;
+        const uint32_t img = pix / per_img, rem = pix - img * per_img;
+        const int oy = (int)(rem / (uint32_t)Wo), ox = (int)(rem - (uint32_t)oy * Wo);
+        const __bf16* xb = x1 + (size_t)img * H * W;                         // wave-uniform only when a group does not straddle images: keep per lane
+        // the 5 x 5 input patch around (2 oy, 2 ox): rows 2oy-2 .. 2oy+2, columns 2ox-2 .. 2ox+3 as three dwords per row (W is even
+        // and the first column is even: a dword is wholly inside or wholly outside the image)
+        uint32_t patch[5][3];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int iy = 2 * oy - 2 + r;
+            const int cy = min(max(iy, 0), H - 1);
+            const bool rin = iy >= 0 && iy < H;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int ix = 2 * ox - 2 + 2 * k;
+                const bool in = rin && ix >= 0 && ix < W;
+                // unconditional load from a clamped address, then the select (a load inside a divergent branch would serialise)
+                const int cx = min(max(ix, 0), W - 2);
+                const uint32_t d = *reinterpret_cast<const uint32_t*>(xb + (uint32_t)(cy * W + cx));
+                patch[r][k] = in ? d : 0u;
+            }
+        }
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        const bool odd = g & 1;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ty = t / 3, tx = t % 3;
+            // window of the position (2oy + ty - 1, 2ox + tx - 1): patch rows ty .. ty+2, patch columns tx .. tx+2.  Its nine 16-bit
+            // values are paired straight into operand dwords: element i of the window is patch value (ty + i / 3, tx + i % 3), and a
+            // pair of values is one byte-permute of (at most) two patch dwords.
+            auto val2 = [&](int i0, int i1) -> uint32_t {                  // dword holding window elements i0 (low half) and i1 (high half)
+                const int r0 = ty + i0 / 3, c0_ = tx + i0 % 3, r1 = ty + i1 / 3, c1_ = tx + i1 % 3;
+                const uint32_t da = patch[r0][c0_ >> 1], db = patch[r1][c1_ >> 1];
+                // v_perm_b32(hi_src, lo_src, sel): byte k of the result = byte sel[k] of {hi_src : lo_src} (bytes 4..7 : 0..3)
+                const uint32_t sel = ((c0_ & 1) ? 0x0302u : 0x0100u) | (((c1_ & 1) ? 0x0706u : 0x0504u) << 16);
+                return __builtin_amdgcn_perm(db, da, sel);
+            };
+            // even lane quarters hold input taps 0..7, odd quarters tap 8 and the constant 1 that carries the bias column
+            const uint32_t e0 = val2(0, 1), e1 = val2(2, 3), e2 = val2(4, 5), e3 = val2(6, 7);
+            const uint32_t w8 = (patch[ty + 2][(tx + 2) >> 1] >> (((tx + 2) & 1) * 16)) & 0xffffu;
+            typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_;
+            const u32x4_ fw = {odd ? (w8 | 0x3F800000u) : e0, odd ? 0u : e1, odd ? 0u : e2, odd ? 0u : e3};
+            const bf16x8 bw = __builtin_bit_cast(bf16x8, fw);
+            f32x4 y0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa1[0], bw, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            f32x4 y1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa1[1], bw, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            // LeakyReLU (slope < 1: max(v, v * slope)); positions outside the image are the encoder's zero padding
+            const int py = 2 * oy + ty - 1, px = 2 * ox + tx - 1;
+            const bool inside = py >= 0 && py < H && px >= 0 && px < W;
+            float v[8] = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * slope1);
+            u32x4_ fv = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            if (!inside) fv = u32x4_{0u, 0u, 0u, 0u};
+            const bf16x8 fb = __builtin_bit_cast(bf16x8, fv);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa2[0][t], fb, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa2[1][t], fb, a1, 0, 0, 0);
+        }
+        if (live) {
+            __bf16* dst = y + (size_t)pix * GC;
+            store4(dst + 4 * g, a0, d0, slope2);                             // co = 4g .. 4g+3
+            if (g < 2) store4(dst + 16 + 4 * g, a1, d1, slope2);             // co = 16 + 4g ..; 24..31 are padding
+        }
+    }
+}
+
+int gennet_first_enc_launch(const void* x1, const void* w1, const float* b1, const void* wk2, const float* bias2, void* y, int B, int H, int W, float slope1,
+                            float slope2, hipStream_t stream) {
+    const long long total = (long long)B * (H / 2) * (W / 2);
+    if ((long long)B * H * W >= (1LL << 31)) return (int)hipErrorInvalidValue;
+    long long blocks = (total + 63) / 64;
+    if (blocks > 256 * 12) blocks = 256 * 12;                    // grid-stride: the register-resident weights are loaded once per wave
+    hipLaunchKernelGGL(gennet_first_enc_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const __bf16*)x1, (const __bf16*)w1, b1,
+                       (const __bf16*)wk2, bias2, (__bf16*)y, B, H, W, slope1, slope2);
+    return (int)hipGetLastError();
+}
+
 int gennet_enc_conv_launch(const void* x, const void* wk, const float* bias, void* y, int B, int H, int W, float slope, hipStream_t stream) {
     const long long total = (long long)B * (H / 2) * (W / 2);
     long long blocks = (total + 16 * GROUPS * 4 - 1) / (16 * GROUPS * 4);

@@ -373,6 +373,23 @@ def nat128_ln_mlp_(s, offset, ln, fc1, fc2):
     return s
 
 
+def gennet_first_enc(x, w1, b1, wk2, b2, slope1, slope2):
+    """GenNet's first convolution + first encoder stage as one kernel (ppn_gennet_first_enc_bf16): x [B,1,H,W] bfloat16 ->
+    channels_last [B,24,H/2,W/2]; parameters from gennet.pack_first_enc_weights."""
+    if not x.is_cuda or x.dtype != torch.bfloat16:
+        raise RuntimeError("ppnet_amd.fused.gennet_first_enc: bfloat16 GPU tensors only")
+    B, _, H, W = x.shape
+    x = x.contiguous()
+    assert w1.shape == (2, 16, 32) and wk2.shape == (2, 9, 16, 32) and w1.dtype == wk2.dtype == torch.bfloat16
+    assert b1.dtype == b2.dtype == torch.float32 and b1.numel() == b2.numel() == 32
+    y = torch.empty(B, H // 2, W // 2, 24, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = L.lib.ppn_gennet_first_enc_bf16(_p(x), _p(w1), _p(b1), _p(wk2), _p(b2), _p(y), B, H, W, float(slope1), float(slope2),
+                                             ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    L.check(rc, "ppn_gennet_first_enc_bf16")
+    return y.permute(0, 3, 1, 2)
+
+
 def gennet_trunk(x_nchw_cl, params32, n_blocks):
     """GenNet's ViT blocks as one kernel (ppn_gennet_trunk_bf16): channels_last bfloat16 [B,24,H,W] in and out; params32 from
     gennet.pack_trunk_params."""

@@ -98,6 +98,38 @@ def pack_s2_weights(conv):
     return wk.to(torch.bfloat16).contiguous(), bias
 
 
+def pack_first_enc_weights(conv1, conv2):
+    """The four parameter blocks of ppn_gennet_first_enc_bf16 (include/ppnet_hip.h) from the BatchNorm-folded first convolution
+    (1 -> 24, 3x3, stride 1) and first encoder convolution (24 -> 24, 3x3, stride 2)."""
+    C = 24
+    dev = conv1.weight.device
+    w = conv1.weight.detach().float().reshape(C, 9)
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    w1 = torch.zeros(32, 32, dtype=torch.bfloat16, device=dev)
+    w1[:C, 0:9] = hi
+    w1[:C, 16:25] = lo
+    b1 = torch.zeros(32, dtype=torch.float32, device=dev)
+    b1[:C] = conv1.bias.detach().float()
+    bh = b1[:C].to(torch.bfloat16)                                         # the bias rides in the product: columns 9 (hi) and 25 (lo)
+    w1[:C, 9] = bh                                                         # against the kernel's constant-1 input slots
+    w1[:C, 25] = (b1[:C] - bh.float()).to(torch.bfloat16)
+    w2 = conv2.weight.detach().float()                                     # [co][ci][ky][kx]
+    slot_ci = [(4 * g + e) if e < 4 else ((16 + 4 * g + e - 4) if g < 2 else -1) for g in range(4) for e in range(8)]
+    wk2 = torch.zeros(2, 9, 16, 32, dtype=torch.float32, device=dev)
+    for k, ci in enumerate(slot_ci):
+        if ci < 0:
+            continue
+        taps = w2[:, ci].reshape(C, 9)                                     # [co][tap]
+        for nt in range(2):
+            rows = min(16, C - nt * 16)
+            wk2[nt, :, :rows, k] = taps[nt * 16:nt * 16 + rows].t()
+    b2 = torch.zeros(32, dtype=torch.float32, device=dev)
+    if conv2.bias is not None:
+        b2[:C] = conv2.bias.detach().float()
+    return w1.reshape(2, 16, 32).contiguous(), b1, wk2.to(torch.bfloat16).contiguous(), b2
+
+
 def _is_s2_stage(c):
     return (c.in_channels == 24 and c.out_channels == 24 and c.kernel_size == (3, 3) and c.stride == (2, 2) and c.padding == (1, 1)
             and c.dilation == (1, 1) and c.groups == 1 and (not isinstance(c, nn.ConvTranspose2d) or c.output_padding == (1, 1)))
@@ -183,10 +215,35 @@ class AEViT(nn.Module):
         self._final_f32 = (None, cf.weight.detach().float().contiguous(), float(cf.bias.detach().float()[0]) if cf.bias is not None and cf.out_channels == 1 else 0.0)
         return self
 
+    _first_enc = None                                 # packed parameters of the fused first convolution + first encoder stage
+
+    def _fused_first_stage(self, x):
+        """Prepared bfloat16 inference: conv_first and enc_conv[0] as one kernel (ppn_gennet_first_enc_bf16), or None."""
+        import os
+        cf = self.conv_first
+        if not (isinstance(cf, _FusedStage) and len(self.enc_conv) > 0 and isinstance(self.enc_conv[0], _FusedStage) and x.is_cuda
+                and x.dtype == torch.bfloat16 and not os.environ.get("PPNET_GENNET_UNFUSED")):
+            return None
+        c1, c2 = cf.conv, self.enc_conv[0].conv
+        if not (isinstance(c1, nn.Conv2d) and c1.in_channels == 1 and c1.out_channels == 24 and c1.kernel_size == (3, 3) and c1.stride == (1, 1)
+                and c1.padding == (1, 1) and c1.bias is not None and isinstance(c2, nn.Conv2d) and _is_s2_stage(c2)
+                and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0):
+            return None
+        from . import fused
+        if self._first_enc is None or self._first_enc[0].device != x.device:
+            self._first_enc = pack_first_enc_weights(c1, c2)
+        return fused.gennet_first_enc(x, *self._first_enc, cf.slope, self.enc_conv[0].slope)
+
     def forward(self, x):
-        x = self.conv_first(x)
-        for blk in self.enc_conv:
-            x = blk(x)
+        y = self._fused_first_stage(x)
+        if y is not None:
+            x = y
+            for blk in self.enc_conv[1:]:
+                x = blk(x)
+        else:
+            x = self.conv_first(x)
+            for blk in self.enc_conv:
+                x = blk(x)
         B, C, H, W = x.shape
         import os
         if (x.is_cuda and x.dtype == torch.bfloat16 and self._final_f32 is not None and C == 24 and H * W <= 1024 and (H * W) % 8 == 0

@@ -238,3 +238,47 @@ def test_heatmap_u8_kernel_is_bit_identical_to_the_torch_composition(dtype):
     assert got.shape == want.shape == (5, 96, 160) and got.dtype == torch.uint8
     assert torch.equal(got, want)
     assert int(got.reshape(5, -1).min(dim=1).values.max()) == 0 and int(got.reshape(5, -1).max(dim=1).values.min()) == 255
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 34, 50), (3, 256, 256)])
+def test_gennet_fused_first_stage_vs_float64(B, H, W):
+    """ppn_gennet_first_enc_bf16 (ae_vit.py:24-36: first convolution + first stride-2 stage in one kernel) against the two
+    convolutions in float64 on the same bfloat16 parameters, with the intermediate rounded to bfloat16 where the two-kernel path
+    stores it.  Inputs are the {0,1} mask GenNet sees plus a general bfloat16 image.  Tolerance: the float32 accumulations and
+    the final bfloat16 rounding — 2^-8 relative + 2e-3."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from ppnet_amd import fused
+    from ppnet_amd.gennet import pack_first_enc_weights
+    torch.manual_seed(H + W)
+    c1, c2 = nn.Conv2d(1, 24, 3, 1, 1).cuda().to(torch.bfloat16), nn.Conv2d(24, 24, 3, 2, 1).cuda().to(torch.bfloat16)
+    packed = pack_first_enc_weights(c1, c2)
+    g = torch.Generator().manual_seed(B)
+    for x in ((torch.rand(B, 1, H, W, generator=g) < 0.4).float(), torch.randn(B, 1, H, W, generator=g)):
+        x = x.cuda().to(torch.bfloat16)
+        got = fused.gennet_first_enc(x, *packed, 0.01, 0.2).double()
+        y1 = F.leaky_relu(F.conv2d(x.double(), c1.weight.double(), c1.bias.double(), 1, 1), 0.01).to(torch.bfloat16).double()
+        want = F.leaky_relu(F.conv2d(y1, c2.weight.double(), c2.bias.double(), 2, 1), 0.2)
+        assert got.shape == want.shape == (B, 24, H // 2, W // 2)
+        err = (got - want).abs()
+        # a float32-vs-float64 difference can flip the intermediate's bfloat16 rounding (one ulp of one of 216 terms): allow for it
+        assert bool((err <= want.abs() * 2.0 ** -7 + 6e-3).all()), float(err.max())
+        assert float(err.mean()) < 1e-3
+
+
+def test_gennet_fused_first_stage_matches_two_kernel_path(monkeypatch):
+    """AEViT (prepared, bfloat16) with the fused first stage against the same module with PPNET_GENNET_UNFUSED=1."""
+    from ppnet_amd.gennet import AEViT
+    torch.manual_seed(11)
+    net = AEViT(1, 1, img_resolution=64, dim=24).cuda().eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.8, 1.2); m.bias.normal_(0, 0.1)
+        net.prepare_inference().to(torch.bfloat16)
+        x = (torch.rand(4, 1, 64, 64, device="cuda") < 0.5).to(torch.bfloat16)
+        a = net(x).float()
+        monkeypatch.setenv("PPNET_GENNET_UNFUSED", "1")
+        b = net(x).float()
+    err = (a - b).abs()
+    assert float(err.max()) < 0.05 * float(b.abs().max()) + 1e-3 and float(err.mean()) < 5e-3 * float(b.abs().mean()) + 1e-4
