@@ -459,7 +459,7 @@ int ppn_conv3x3_relu_classify2_bf16(const void* x, const void* w, const float* b
 int ppn_gennet_conv_s2_bf16(const void* x, const void* w, const float* bias, void* y, int32_t B, int32_t H, int32_t W, float negative_slope,
                             int32_t transposed, void* stream) {
     if (!x || !w || !bias || !y || B <= 0 || H <= 0 || W <= 0 || (!transposed && ((H | W) & 1))) return PPN_E_INVALID;
-    if ((long long)B * H * W * 4 >= (1LL << 40)) return PPN_E_UNSUPPORTED;
+    if ((long long)B * H * W * 4 >= (1LL << 31)) return PPN_E_UNSUPPORTED;          // 32-bit pixel indices inside
     const int e = transposed ? ppn::gennet_dec_conv_launch(x, w, bias, y, B, H, W, negative_slope, (hipStream_t)stream)
                              : ppn::gennet_enc_conv_launch(x, w, bias, y, B, H, W, negative_slope, (hipStream_t)stream);
     if (e != 0) return hip_fail((hipError_t)e);

@@ -55,16 +55,17 @@ __global__ __launch_bounds__(256) void gennet_enc_conv_kernel(const __bf16* __re
             long long pix = base + q * 16 + pl;
             const bool live = pix < total;
             if (!live) pix = total - 1;
-            const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho);
-            const long long img = pix / ((long long)Wo * Ho);
-            const __bf16* xb = x + img * H * W * GC;
+            // 32-bit divisions (the launcher checks the pixel count): the 64-bit form costs hundreds of instructions per group
+            const uint32_t p32 = (uint32_t)pix, img = p32 / (uint32_t)(Wo * Ho), rem = p32 - img * (uint32_t)(Wo * Ho);
+            const int oy = (int)(rem / (uint32_t)Wo), ox = (int)(rem - (uint32_t)oy * Wo);
+            const __bf16* xb = x + (size_t)img * H * W * GC;
 #pragma unroll
             for (int ks = 0; ks < 7; ++ks) {
                 const int c = ks * 4 + g;                        // chunk of 8 reduction elements: tap c / 3, channels (c % 3) * 8 ..
                 const int tap = c / 3, ci0 = (c - tap * 3) * 8;
                 const int iy = 2 * oy + tap / 3 - 1, ix = 2 * ox + tap % 3 - 1;
                 const bool in = live && c < 27 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-                fb[q][ks] = in ? ld8(xb + ((long long)iy * W + ix) * GC + ci0) : zero8();
+                fb[q][ks] = in ? ld8(xb + (uint32_t)((iy * W + ix) * GC + ci0)) : zero8();
             }
         }
 #pragma unroll
@@ -107,9 +108,9 @@ __global__ __launch_bounds__(256) void gennet_dec_conv_kernel(const __bf16* __re
         long long pos = base + pl;
         const bool live = pos < total;
         if (!live) pos = total - 1;
-        const int ix = (int)(pos % W), iy = (int)((pos / W) % H);
-        const long long img = pos / ((long long)W * H);
-        const __bf16* xb = x + img * H * W * GC;
+        const uint32_t p32 = (uint32_t)pos, img = p32 / (uint32_t)(W * H), rem = p32 - img * (uint32_t)(W * H);   // 32-bit divisions, see the encoder
+        const int iy = (int)(rem / (uint32_t)W), ix = (int)(rem - (uint32_t)iy * W);
+        const __bf16* xb = x + (size_t)img * H * W * GC;
         bf16x8 fb[3];
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void gennet_dec_conv_kernel(const __bf16* __re
             const int p = c / 3, ci0 = (c - p * 3) * 8;
             const int yy = iy + (p >> 1), xx = ix + (p & 1);
             const bool in = live && yy < H && xx < W;
-            fb[ks] = in ? ld8(xb + ((long long)yy * W + xx) * GC + ci0) : zero8();
+            fb[ks] = in ? ld8(xb + (uint32_t)((yy * W + xx) * GC + ci0)) : zero8();
         }
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl) {
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void gennet_dec_conv_kernel(const __bf16* __re
                 a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cl][1][ks], fb[ks], a1, 0, 0, 0);
             }
             if (live) {
-                __bf16* dst = y + ((img * 2 * H + (2 * iy + (cl >> 1))) * Wo + (2 * ix + (cl & 1))) * GC;
+                __bf16* dst = y + ((size_t)(img * 2 * H + (2 * iy + (cl >> 1))) * Wo + (2 * ix + (cl & 1))) * GC;
                 store4(dst + 4 * g, a0, b0, slope);
                 if (g < 2) store4(dst + 16 + 4 * g, a1, b1, slope);
             }
