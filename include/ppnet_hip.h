@@ -372,6 +372,14 @@ int ppn_heatmap_u8(const void* y, uint8_t* out, int32_t B, int32_t n, int32_t dt
  * L[co][3 * (ky * 3 + kx) + colour] = sum_ci w[co][ci][ky][kx] * image_ci(colour)  (colour 0 free, 1 marker, 2 other), column 27 =
  * bias (hi half only), 28..31 zero.  out [B][H/2][W/2][64] bfloat16.  H even, W % 32 == 0 (else PPN_E_UNSUPPORTED). */
 int ppn_tokenizer_conv1_codes_bf16(const uint8_t* grid, const void* lut, void* out, int32_t B, int32_t H, int32_t W, void* stream);
+/* SegNet's whole tokenizer (SegNet/nat.py:17-46: Conv2d(3, 64, 3, 2, 1) -> Conv2d(64, 128, 3, 2, 1) -> LayerNorm(128)) from the occupancy
+ * codes grid [B][H][W] u8 in one kernel: tokens [B][H/4][W/4][128] bfloat16.  H % 4 == 0, W % 64 == 0 (else PPN_E_UNSUPPORTED).
+ *   lut [2][64][32] bfloat16: the palette table of ppn_tokenizer_conv1_codes_bf16 with rows in natural channel order;
+ *   w2p [8][9][2][16][32] bfloat16: the second convolution's weight as MFMA A fragments — [output tile nt][tap ky*3+kx][k-step s][row i][slot],
+ *       row (nt, i) = output channel (nt>>2)*64 + 16*(i>>2) + 4*(nt&3) + (i&3), slot 8g + e = input channel (2s + (e>>2))*16 + 4g + (e&3);
+ *   vec [3][128] float32: the second convolution's bias, the LayerNorm weight, the LayerNorm bias.  ppnet_amd/fused.py packs all three. */
+int ppn_tokenizer_codes_bf16(const uint8_t* grid, const void* lut, const void* w2p, const float* vec, void* tokens, int32_t B, int32_t H, int32_t W,
+                             float eps, void* stream);
 /* The dense half of a 128-channel NAT layer (DiNAT-B level 0) as two token-streaming kernels with the weights resident in LDS
  * (SegNet/nat.py:101-153), bfloat16 token rows, float32 accumulation.  tokens % 16 == 0 (else PPN_E_UNSUPPORTED).
  *   ppn_nat128_ln_qkv_bf16:  qkv[tokens][384] = LN(s + offset) . w[384][128]^T + bias     (norm1 -> attn.qkv; offset, bias may be NULL)

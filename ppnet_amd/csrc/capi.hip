@@ -513,6 +513,15 @@ int ppn_tokenizer_conv1_codes_bf16(const uint8_t* grid, const void* lut, void* o
     return PPN_OK;
 }
 
+int ppn_tokenizer_codes_bf16(const uint8_t* grid, const void* lut, const void* w2p, const float* vec, void* tokens, int32_t B, int32_t H, int32_t W,
+                             float eps, void* stream) {
+    if (!grid || !lut || !w2p || !vec || !tokens || B <= 0 || H <= 0 || W <= 0) return PPN_E_INVALID;
+    if ((H % 4) || (W % 64)) return PPN_E_UNSUPPORTED;
+    const int e = ppn::tokenizer_fused_launch(grid, lut, w2p, vec, tokens, B, H, W, eps, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_nat128_ln_qkv_bf16(const void* s, const float* offset, const void* ln_w, const void* ln_b, const void* w, const void* bias, void* qkv,
                            int64_t tokens, float eps, void* stream) {
     if (!s || !ln_w || !ln_b || !w || !qkv || tokens <= 0) return PPN_E_INVALID;

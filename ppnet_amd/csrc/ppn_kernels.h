@@ -94,6 +94,8 @@ int na2d_dense7_launch(const void* qkv, const void* pad_kv, const float* rpb, vo
 int gennet_first_enc_launch(const void* x1, const void* w1, const float* b1, const void* wk2, const float* bias2, void* y, int B, int H, int W, float slope1,
                             float slope2, hipStream_t stream);
 int heatmap_u8_launch(const void* y, uint8_t* out, int B, int n, int dtype, hipStream_t stream);
+int tokenizer_fused_launch(const uint8_t* grid, const void* lut, const void* w2p, const float* vec, void* out, int B, int H, int W, float eps,
+                           hipStream_t stream);
 int tokenizer_codes_launch(const uint8_t* grid, const void* lut, void* out, int B, int H, int W, hipStream_t stream);
 int nat128_ln_qkv_launch(const void* s, const float* off, const void* lnw, const void* lnb, const void* w, const void* bias, void* qkv, long long tokens,
                          float eps, hipStream_t stream);

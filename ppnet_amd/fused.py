@@ -240,7 +240,40 @@ def tokenizer_lut(conv, mean, std):
     t_hi = table.to(torch.float32).to(torch.bfloat16)
     t_lo = (table - t_hi.double()).to(torch.float32).to(torch.bfloat16)
     t_lo[:, 27:] = 0
-    return torch.stack([t_hi, t_lo]).contiguous()
+    return torch.stack([t_hi, t_lo]).contiguous()        # rows = channels; each kernel applies its own row order when it loads
+
+
+def tokenizer_pack(conv2, ln):
+    """(w2p, vec) of ppn_tokenizer_codes_bf16 from the tokenizer's second convolution (Conv2d(64, 128, 3, 2, 1), bfloat16) and its
+    LayerNorm: the weight as MFMA A fragments [8][9][2][16][32] and [3][128] float32 = (conv bias, LN weight, LN bias)."""
+    w = conv2.weight.detach().float()                                      # [co 128][ci 64][ky][kx]
+    assert w.shape == (128, 64, 3, 3)
+    dev = w.device
+    co = torch.tensor([[(nt >> 2) * 64 + 16 * (i >> 2) + 4 * (nt & 3) + (i & 3) for i in range(16)] for nt in range(8)], device=dev)         # [8][16]
+    ci = torch.tensor([[(2 * s + (e >> 2)) * 16 + 4 * g + (e & 3) for g in range(4) for e in range(8)] for s in range(2)], device=dev)      # [2][32]
+    taps = w.reshape(128, 64, 9)
+    w2p = taps[co][:, :, ci]                                               # [8][16][2][32][9]
+    w2p = w2p.permute(0, 4, 2, 1, 3).contiguous()                          # [8][9][2][16][32]
+    bias = conv2.bias.detach().float() if conv2.bias is not None else torch.zeros(128, device=dev)
+    vec = torch.stack([bias, ln.weight.detach().float(), ln.bias.detach().float()]).contiguous()
+    return w2p.to(torch.bfloat16).contiguous(), vec
+
+
+def tokenizer_codes(grid_u8, lut, w2p, vec, eps):
+    """Tokens [B,R/4,R/4,128] bfloat16 of the palette image of u8 occupancy codes [B,R,R]: both tokenizer convolutions and the
+    LayerNorm in one kernel (ppn_tokenizer_codes_bf16)."""
+    if not grid_u8.is_cuda or grid_u8.dtype != torch.uint8:
+        raise RuntimeError("ppnet_amd.fused.tokenizer_codes: u8 GPU code grids only")
+    g = grid_u8.contiguous()
+    B, H, W = g.shape
+    assert lut.shape == (2, 64, 32) and w2p.shape == (8, 9, 2, 16, 32) and vec.shape == (3, 128)
+    assert lut.dtype == w2p.dtype == torch.bfloat16 and vec.dtype == torch.float32 and lut.is_contiguous() and w2p.is_contiguous() and vec.is_contiguous()
+    out = torch.empty(B, H // 4, W // 4, 128, dtype=torch.bfloat16, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = L.lib.ppn_tokenizer_codes_bf16(_p(g), _p(lut), _p(w2p), _p(vec), _p(out), B, H, W, float(eps),
+                                            ctypes.c_void_p(torch.cuda.current_stream(g.device).cuda_stream))
+    L.check(rc, "ppn_tokenizer_codes_bf16")
+    return out
 
 
 def tokenizer_conv1_codes(grid_u8, lut):

@@ -70,11 +70,15 @@ class ConvTokenizer(nn.Module):
         convolution is a table product on the matrix cores (ppn_tokenizer_conv1_codes_bf16), the second convolution runs
         without its bias, which the LayerNorm kernel adds in registers — the normalised image and two bias passes are
         never written."""
+        c1 = self.proj[1]
         if self._codes is None or self._codes[0].device != grid_u8.device:
             self._codes = (fused.tokenizer_lut(self.proj[0], IMG_MEAN, IMG_STD).to(grid_u8.device),
-                           self.proj[1].bias.detach().float().contiguous())
-        lut, b2 = self._codes
-        c1 = self.proj[1]
+                           c1.bias.detach().float().contiguous()) + fused.tokenizer_pack(c1, self.norm)
+        lut, b2, w2p, vec = self._codes
+        if (c1.weight.shape == (128, 64, 3, 3) and grid_u8.shape[1] % 4 == 0 and grid_u8.shape[2] % 64 == 0
+                and not os.environ.get("PPNET_TOKENIZER_TWO_KERNELS")):
+            # both convolutions and the LayerNorm in one kernel (ppn_tokenizer_codes_bf16): no library convolution, no intermediate
+            return fused.tokenizer_codes(grid_u8, lut, w2p, vec, self.norm.eps)
         x = fused.tokenizer_conv1_codes(grid_u8, lut).permute(0, 3, 1, 2)
         x = F.conv2d(x, c1.weight, None, c1.stride, c1.padding).permute(0, 2, 3, 1)
         return fused.layer_norm(x, self.norm, offset=b2)

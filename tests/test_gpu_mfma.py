@@ -203,8 +203,9 @@ def test_tokenizer_palette_conv_vs_float64(B, R):
     conv = torch.nn.Conv2d(3, 64, 3, 2, 1).cuda().to(torch.bfloat16)
     grid = _code_grids(B, R, R + B)
     img = fused.grid_to_image(grid, IMG_MEAN, IMG_STD, torch.bfloat16)
-    want = torch.nn.functional.conv2d(img.double(), conv.weight.double(), conv.bias.double(), 2, 1).permute(0, 2, 3, 1)
-    got = fused.tokenizer_conv1_codes(grid, fused.tokenizer_lut(conv, IMG_MEAN, IMG_STD)).double()
+    # float64 reference on the host (a float64 convolution on the GPU can send MIOpen into a long search)
+    want = torch.nn.functional.conv2d(img.double().cpu(), conv.weight.double().cpu(), conv.bias.double().cpu(), 2, 1).permute(0, 2, 3, 1)
+    got = fused.tokenizer_conv1_codes(grid, fused.tokenizer_lut(conv, IMG_MEAN, IMG_STD)).double().cpu()
     assert got.shape == want.shape
     assert bool(((got - want).abs() <= want.abs() * 2.0 ** -8 + 1e-4).all()), float((got - want).abs().max())
 
@@ -256,9 +257,10 @@ def test_gennet_fused_first_stage_vs_float64(B, H, W):
     g = torch.Generator().manual_seed(B)
     for x in ((torch.rand(B, 1, H, W, generator=g) < 0.4).float(), torch.randn(B, 1, H, W, generator=g)):
         x = x.cuda().to(torch.bfloat16)
-        got = fused.gennet_first_enc(x, *packed, 0.01, 0.2).double()
-        y1 = F.leaky_relu(F.conv2d(x.double(), c1.weight.double(), c1.bias.double(), 1, 1), 0.01).to(torch.bfloat16).double()
-        want = F.leaky_relu(F.conv2d(y1, c2.weight.double(), c2.bias.double(), 2, 1), 0.2)
+        got = fused.gennet_first_enc(x, *packed, 0.01, 0.2).double().cpu()
+        h = lambda t: t.detach().double().cpu()                            # float64 reference on the host
+        y1 = F.leaky_relu(F.conv2d(h(x), h(c1.weight), h(c1.bias), 1, 1), 0.01).to(torch.bfloat16).double()
+        want = F.leaky_relu(F.conv2d(y1, h(c2.weight), h(c2.bias), 2, 1), 0.2)
         assert got.shape == want.shape == (B, 24, H // 2, W // 2)
         err = (got - want).abs()
         # a float32-vs-float64 difference can flip the intermediate's bfloat16 rounding (one ulp of one of 216 terms): allow for it
@@ -282,3 +284,42 @@ def test_gennet_fused_first_stage_matches_two_kernel_path(monkeypatch):
         b = net(x).float()
     err = (a - b).abs()
     assert float(err.max()) < 0.05 * float(b.abs().max()) + 1e-3 and float(err.mean()) < 5e-3 * float(b.abs().mean()) + 1e-4
+
+
+@pytest.mark.parametrize("B,R", [(1, 64), (3, 128), (2, 256)])
+def test_tokenizer_one_kernel_vs_float64(B, R):
+    """ppn_tokenizer_codes_bf16 (SegNet/nat.py:17-46: both convolutions + LayerNorm from the occupancy codes) against float64:
+    conv2d on the rendered bfloat16 palette image, the intermediate rounded to bfloat16 (where the two-kernel path stores it),
+    second conv2d, layer_norm — all with the module's bfloat16 parameters.  The output is O(1) after the LayerNorm: 0.03 absolute
+    covers the final bfloat16 rounding plus the rare one-ulp flips of the intermediate; the mean error is an order below."""
+    import torch.nn.functional as F
+    from ppnet_amd import fused
+    from ppnet_amd.segnet import ConvTokenizer, IMG_MEAN, IMG_STD
+    torch.manual_seed(R)
+    tok = ConvTokenizer(3, 128, torch.nn.LayerNorm).cuda().to(torch.bfloat16).eval()
+    with torch.no_grad():
+        tok.norm.weight.uniform_(0.5, 1.5); tok.norm.bias.normal_(0, 0.2)
+    grid = _code_grids(B, R, R + B)
+    d = lambda t: t.detach().double().cpu()                                 # the float64 reference runs on the host: a float64 convolution
+    with torch.no_grad():                                                   # on the GPU sends MIOpen into a minutes-long search
+        got = tok.forward_codes(grid).double().cpu()
+        img = fused.grid_to_image(grid, IMG_MEAN, IMG_STD, torch.bfloat16).double().cpu()
+        y1 = F.conv2d(img, d(tok.proj[0].weight), d(tok.proj[0].bias), 2, 1).to(torch.bfloat16).double()
+        y2 = F.conv2d(y1, d(tok.proj[1].weight), d(tok.proj[1].bias), 2, 1).permute(0, 2, 3, 1)
+        want = F.layer_norm(y2, (128,), d(tok.norm.weight), d(tok.norm.bias), tok.norm.eps)
+    assert got.shape == want.shape == (B, R // 4, R // 4, 128)
+    err = (got - want).abs()
+    assert float(err.max()) < 0.03 and float(err.mean()) < 3e-3, (float(err.max()), float(err.mean()))
+
+
+def test_tokenizer_one_kernel_matches_two_kernel_path(monkeypatch):
+    from ppnet_amd.segnet import ConvTokenizer
+    torch.manual_seed(4)
+    tok = ConvTokenizer(3, 128, torch.nn.LayerNorm).cuda().to(torch.bfloat16).eval()
+    grid = _code_grids(2, 128, 9)
+    with torch.no_grad():
+        a = tok.forward_codes(grid).float()
+        monkeypatch.setenv("PPNET_TOKENIZER_TWO_KERNELS", "1")
+        b = tok.forward_codes(grid).float()
+    err = (a - b).abs()
+    assert a.shape == b.shape and float(err.max()) < 0.05 and float(err.mean()) < 4e-3, (float(err.max()), float(err.mean()))
