@@ -223,6 +223,20 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg):
     na_launches = len(na.TIMING)
     na.TIMING = None
     t_seg, t_gen, t_tail = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
+    # The same batch as ONE HIP graph (PPNet.capture: the ~290 launches recorded once, replayed by a single hipGraphLaunch), timed
+    # beside the eager loop.  Measured at batch 256: the GPU is never waiting for the host (26.99 ms eager, 27.24 ms replayed), so
+    # the timed region below stays eager; the graph is what pays at small batches, where the launches are the time.
+    ms_graph = None
+    if world == 1 and not os.environ.get("PPNET_NO_GRAPH"):
+        cp = model.capture(g, init, end, obs, n_obs, tail_heat=ridge)
+        cp.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            cp.replay()
+        torch.cuda.synchronize()
+        ms_graph = (time.perf_counter() - t1) / steps * 1e3
+        del cp
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -249,6 +263,7 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg):
            "workload": "PPNet inference batch=256 over 256x256 maps: DiNAT-B + SETR-UP -> AE-ViT -> extract_path -> collision check"
                        + (" -> all-gather of plan records" if world > 1 else ""),
            "ms_segnet": round(t_seg, 2), "ms_gennet": round(t_gen, 2), "ms_tail": round(t_tail, 2),
+           "ms_per_batch_hip_graph": round(ms_graph, 2) if ms_graph is not None else None,
            "weights": "seeded random init (no trained weights in the reference)",
            "tail_input": "ridge heat maps along the label paths (GenNet's training target, blurred); the networks' own output is noise",
            "tail": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ev_tail.items()},

@@ -262,7 +262,8 @@ typedef __attribute__((ext_vector_type(4))) short ts16x4;
 typedef __attribute__((ext_vector_type(8))) short ts16x8;
 typedef __attribute__((ext_vector_type(4))) float tf32x4;
 
-__global__ __launch_bounds__(512) void gennet_trunk_mfma_kernel(const __bf16* __restrict__ xin, __bf16* __restrict__ yout,
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void gennet_trunk_mfma_kernel(const __bf16* __restrict__ xin, __bf16* __restrict__ yout,
                                                                 const float* __restrict__ params, int N, int n_blocks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tl[];
     unsigned char* Ql = tl;                                                // [N][48 B]: q (scaled), later the attention output
@@ -270,14 +271,17 @@ __global__ __launch_bounds__(512) void gennet_trunk_mfma_kernel(const __bf16* __
     unsigned char* Vl = tl + (size_t)N * 96;                               // + 64 B of slack behind it (transposed reads of head 2)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int prob = blockIdx.x;
-    const int tok[2] = {tid, tid + 512};
-    const bool live[2] = {tok[0] < N, tok[1] < N};
+    constexpr int TPT = 1024 / NTHR, NWAVES = NTHR / 64;                  // tokens per thread (N <= 1024), waves
+    int tok[TPT];
+    bool live[TPT];
+#pragma unroll
+    for (int s = 0; s < TPT; ++s) { tok[s] = tid + s * NTHR; live[s] = tok[s] < N; }
     const int j = lane & 15, g = lane >> 4, q4 = j >> 2, p4 = j & 3;
     const int ntile = N >> 4;
 
-    float x[2][TC];
+    float x[TPT][TC];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < TPT; ++s) {
         if (live[s]) {
             const __bf16* src = xin + ((size_t)prob * N + tok[s]) * TC;
 #pragma unroll
@@ -296,29 +300,34 @@ __global__ __launch_bounds__(512) void gennet_trunk_mfma_kernel(const __bf16* __
     const float qscale = 0.35355339059327373f * 1.4426950408889634f;      // head_dim^-0.5 * log2(e)
     for (int blk = 0; blk < n_blocks; ++blk) {
         const float* P = params + (size_t)blk * BLOCK_PARAMS;
-        float y[2][TC];
+        float y[TPT][TC];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) layer_norm24(x[s], P + O_LN1W, P + O_LN1B, y[s]);
+        for (int s = 0; s < TPT; ++s) layer_norm24(x[s], P + O_LN1W, P + O_LN1B, y[s]);
         // ---- qkv rows to LDS (the previous block's phase C read only this thread's own Q rows; K / V readers are past the
         // barrier that closed the attention phase)
 #pragma unroll
         for (int part = 0; part < 3; ++part)
 #pragma unroll
             for (int h = 0; h < TH; ++h) {
-                float o8[2][THD];
+                float o8[TPT][THD];
 #pragma unroll
                 for (int c = 0; c < THD; ++c) {
                     const int row = part * TC + h * THD + c;
                     const float* wr = P + O_WQKV + row * TC;
-                    float a0 = P[O_BQKV + row], a1 = a0;
+                    float a[TPT];
 #pragma unroll
-                    for (int i = 0; i < TC; ++i) { a0 += wr[i] * y[0][i]; a1 += wr[i] * y[1][i]; }
-                    o8[0][c] = a0; o8[1][c] = a1;
+                    for (int s = 0; s < TPT; ++s) a[s] = P[O_BQKV + row];
+#pragma unroll
+                    for (int i = 0; i < TC; ++i)
+#pragma unroll
+                        for (int s = 0; s < TPT; ++s) a[s] += wr[i] * y[s][i];
+#pragma unroll
+                    for (int s = 0; s < TPT; ++s) o8[s][c] = a[s];
                 }
                 unsigned char* base = part == 0 ? Ql : (part == 1 ? Kl : Vl);
                 const float sc = part == 0 ? qscale : 1.0f;
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < TPT; ++s)
                     if (live[s])
                         *reinterpret_cast<uint4*>(base + (size_t)tok[s] * 48 + h * 16) =
                             make_uint4(pack_bf16x2(o8[s][0] * sc, o8[s][1] * sc), pack_bf16x2(o8[s][2] * sc, o8[s][3] * sc),
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(512) void gennet_trunk_mfma_kernel(const __bf16* __
 
         // ---- attention on the matrix cores: this wave's query tiles, head by head
         const bf16x8 zf = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int qt = wave; qt < ntile; qt += 8) {
+        for (int qt = wave; qt < ntile; qt += NWAVES) {
 #pragma unroll 1
             for (int h = 0; h < TH; ++h) {
                 const unsigned char* kh = Kl + (size_t)j * 48 + h * 16;
@@ -387,9 +396,9 @@ __global__ __launch_bounds__(512) void gennet_trunk_mfma_kernel(const __bf16* __
         __syncthreads();
 
         // ---- proj + residual, from the attention rows in LDS
-        float att[2][TC];
+        float att[TPT][TC];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < TPT; ++s)
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 const bf16x8 v = live[s] ? *reinterpret_cast<const bf16x8*>(Ql + (size_t)tok[s] * 48 + p * 16) : zf;
@@ -399,37 +408,49 @@ __global__ __launch_bounds__(512) void gennet_trunk_mfma_kernel(const __bf16* __
 #pragma unroll
         for (int oc = 0; oc < TC; ++oc) {
             const float* wr = P + O_WPROJ + oc * TC;
-            float a0 = P[O_BPROJ + oc], a1 = a0;
+            float a[TPT];
 #pragma unroll
-            for (int i = 0; i < TC; ++i) { a0 += wr[i] * att[0][i]; a1 += wr[i] * att[1][i]; }
-            x[0][oc] += a0; x[1][oc] += a1;
+            for (int s = 0; s < TPT; ++s) a[s] = P[O_BPROJ + oc];
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int s = 0; s < TPT; ++s) a[s] += wr[i] * att[s][i];
+#pragma unroll
+            for (int s = 0; s < TPT; ++s) x[s][oc] += a[s];
         }
         // ---- MLP: one hidden unit at a time, never materialised
 #pragma unroll
-        for (int s = 0; s < 2; ++s) layer_norm24(x[s], P + O_LN2W, P + O_LN2B, y[s]);
-        float acc[2][TC];
+        for (int s = 0; s < TPT; ++s) layer_norm24(x[s], P + O_LN2W, P + O_LN2B, y[s]);
+        float acc[TPT][TC];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < TPT; ++s)
 #pragma unroll
             for (int c = 0; c < TC; ++c) acc[s][c] = P[O_B2 + c];
         for (int jh = 0; jh < THID; ++jh) {
             const float* w1 = P + O_W1 + jh * TC;
             const float* w2 = P + O_W2T + jh * TC;
-            float h0 = P[O_B1 + jh], h1 = h0;
+            float hh[TPT];
 #pragma unroll
-            for (int i = 0; i < TC; ++i) { h0 += w1[i] * y[0][i]; h1 += w1[i] * y[1][i]; }
-            h0 = gelu_fast(h0); h1 = gelu_fast(h1);
+            for (int s = 0; s < TPT; ++s) hh[s] = P[O_B1 + jh];
 #pragma unroll
-            for (int c = 0; c < TC; ++c) { acc[0][c] += h0 * w2[c]; acc[1][c] += h1 * w2[c]; }
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int s = 0; s < TPT; ++s) hh[s] += w1[i] * y[s][i];
+#pragma unroll
+            for (int s = 0; s < TPT; ++s) hh[s] = gelu_fast(hh[s]);
+#pragma unroll
+            for (int c = 0; c < TC; ++c)
+#pragma unroll
+                for (int s = 0; s < TPT; ++s) acc[s][c] += hh[s] * w2[c];
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < TPT; ++s)
 #pragma unroll
             for (int c = 0; c < TC; ++c) x[s][c] += acc[s][c];
     }
 
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < TPT; ++s) {
         if (!live[s]) continue;
         __bf16* dst = yout + ((size_t)prob * N + tok[s]) * TC;
 #pragma unroll
@@ -443,15 +464,21 @@ int gennet_trunk_launch(const void* x, void* y, const float* params, int B, int 
     // the matrix-core form needs whole groups of 4 key tiles (N % 64 == 0: 1024 tokens at R = 256 / 512 / 64); PPNET_TRUNK_VALU=1
     // keeps the v_dot2 kernel (A/B runs), which also serves the other token counts (784 at R = 224)
     static const bool valu = getenv("PPNET_TRUNK_VALU") != nullptr;
+    // 1024 threads (one token per thread, 4 waves per SIMD) unless PPNET_TRUNK_512=1 keeps the first form (two tokens per thread,
+    // 2 waves per SIMD): the kernel is a chain of MFMA -> exp -> MFMA and scalar-load -> FMA latencies, and there is exactly one
+    // workgroup per CU at batch 256, so the only latency hiding there is comes from the waves of that workgroup
+    static const bool t512 = getenv("PPNET_TRUNK_512") != nullptr;
     if (!valu && N % 64 == 0) {
         const size_t lds_m = (size_t)N * 144 + 64;
         static std::atomic<int> attr_m{0};
         if (!attr_m.load()) {
-            const hipError_t e = hipFuncSetAttribute((const void*)gennet_trunk_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
+            hipError_t e = hipFuncSetAttribute((const void*)gennet_trunk_mfma_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gennet_trunk_mfma_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
             if (e != hipSuccess) return (int)e;
             attr_m.store(1);
         }
-        hipLaunchKernelGGL(gennet_trunk_mfma_kernel, dim3(B), dim3(512), lds_m, stream, (const __bf16*)x, (__bf16*)y, params, N, n_blocks);
+        if (t512) hipLaunchKernelGGL(gennet_trunk_mfma_kernel<512>, dim3(B), dim3(512), lds_m, stream, (const __bf16*)x, (__bf16*)y, params, N, n_blocks);
+        else hipLaunchKernelGGL(gennet_trunk_mfma_kernel<1024>, dim3(B), dim3(1024), lds_m, stream, (const __bf16*)x, (__bf16*)y, params, N, n_blocks);
         return (int)hipGetLastError();
     }
     const size_t lds = (size_t)N * 48 + (size_t)3 * (N / 2) * 8 * 4;

@@ -23,7 +23,7 @@ _PADDED = {}
 def _padded_buffer(B, Hp, Wp, C, dtype, device):
     """Persistent zero-initialised [B,Hp,Wp,C] buffer: the kernels only ever write the real tokens, so the pad
     region stays zero; consumers (the qkv projection) read it before the next same-shaped producer runs."""
-    key = (B, Hp, Wp, C, dtype, device)
+    key = (B, Hp, Wp, C, dtype, device, torch.cuda.current_stream(device).cuda_stream)     # batches in flight on two streams must not share it
     buf = _PADDED.get(key)
     if buf is None:
         buf = _PADDED[key] = torch.zeros(B, Hp, Wp, C, dtype=dtype, device=device)

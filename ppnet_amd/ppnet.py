@@ -33,6 +33,18 @@ def _use_tuned_gemms():
         print(f"ppnet_amd: tuned GEMM table not used ({e})", file=sys.stderr)
 
 
+class CapturedPlan:
+    """One recorded batch of PPNet.capture(): static inputs (grid, init, end, obstacles, n_obstacles, tail_heat), the HIP graph,
+    and the buffers its kernels write (mask, heat, result = plan_tail's dict).  replay() enqueues the graph on the current
+    stream and returns `result`; the buffers are overwritten by the next replay."""
+    graph = None
+    mask = heat = result = None
+
+    def replay(self):
+        self.graph.replay()
+        return self.result
+
+
 class PPNet(torch.nn.Module):
     def __init__(self, resolution=256, segnet=None, gennet=None, amp_dtype=None, weights_dtype=torch.bfloat16):
         """weights_dtype=bfloat16 (default): both networks hold bf16 weights and activations (fp32 accumulation inside
@@ -93,6 +105,34 @@ class PPNet(torch.nn.Module):
         the resolution as well.  Returns dict(ok, waypoints, counts, collision, success)."""
         heat = self.heatmap(self.segment(grid_u8) if os.environ.get("PPNET_NO_FUSED_TAIL") else self.segment_u8(grid_u8))
         return self.plan_tail(heat, init, end, obstacles, n_obstacles, clearance, down_sample_rate)
+
+    @torch.no_grad()
+    def capture(self, grid_u8, init, end, obstacles, n_obstacles, tail_heat=None, clearance=None, down_sample_rate=2, warmup=2):
+        """The whole batch — segment_u8 -> heatmap -> plan_tail, ~290 kernel launches — recorded once as ONE HIP graph
+        (hipStreamBeginCapture through torch.cuda.graph) for this batch shape; returns a CapturedPlan whose replay() is a single
+        hipGraphLaunch.  The arguments become the graph's static input buffers (copy a new batch into `.grid`, `.init`, ... before
+        replay()); the results live in `.mask`, `.heat`, `.result`.  tail_heat: 8-bit heat maps the planner tail walks instead of
+        the network's own output (bench.py: ridge maps, see there).  Nothing in the path synchronises or allocates outside the
+        caching allocator, so the recorded launches are exactly the eager ones (tests/test_ppnet_config3.py compares the two)."""
+        cp = CapturedPlan()
+        cp.grid, cp.init, cp.end, cp.obstacles, cp.n_obstacles, cp.tail_heat = grid_u8, init, end, obstacles, n_obstacles, tail_heat
+
+        def body():
+            cp.mask = self.segment_u8(cp.grid)
+            cp.heat = self.heatmap(cp.mask)
+            cp.result = self.plan_tail(cp.heat if cp.tail_heat is None else cp.tail_heat, cp.init, cp.end, cp.obstacles,
+                                       cp.n_obstacles, clearance, down_sample_rate)
+        side = torch.cuda.Stream(grid_u8.device)
+        side.wait_stream(torch.cuda.current_stream(grid_u8.device))
+        with torch.cuda.stream(side):                     # persistent buffers, library workspaces and solution picks: outside the capture
+            for _ in range(max(1, warmup)):
+                body()
+        torch.cuda.current_stream(grid_u8.device).wait_stream(side)
+        torch.cuda.synchronize(grid_u8.device)
+        cp.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cp.graph):
+            body()
+        return cp
 
     @torch.no_grad()
     def plan_tail(self, heat, init, end, obstacles, n_obstacles, clearance=None, down_sample_rate=2, max_wp=L.MAX_WAYPOINTS):

@@ -239,3 +239,31 @@ def test_plan_batch_256_properties(dev, segnet_models):
     ev = evaluate.evaluate_plans(res2, (pb.length.repeat_interleave(100) * R / 50)[:B])
     print("ridge heat maps, batch 256:", ev)
     assert ev["extract_ok"] > 0.9 and ev["success"] > 0.5
+
+
+@pytest.mark.gpu
+def test_captured_graph_equals_eager(dev, stage_b, segnet_models):
+    """PPNet.capture(): the batch recorded as one HIP graph writes what the eager calls write — same kernels, same buffers —
+    bit for bit, and a replay after new inputs were copied into the static buffers follows the new inputs."""
+    from ppnet_amd import evaluate
+    _, _, p16 = segnet_models
+    pb, mb = stage_b
+    g = mb.grid.clone()
+    init, end = mb.segpoint[:, 0].contiguous(), mb.segpoint[:, 10].contiguous()
+    obs, n_obs = mb.obstacles.clone(), mb.n_obstacles[:, 0].contiguous()
+    ridge = evaluate.label_heatmaps(pb, mb, 4).contiguous()
+
+    def eager(grid, heat_for_tail):
+        mask = p16.segment_u8(grid)
+        heat = p16.heatmap(mask)
+        return mask, heat, p16.plan_tail(heat_for_tail if heat_for_tail is not None else heat, init, end, obs, n_obs)
+    for tail_heat in (None, ridge):
+        cp = p16.capture(g, init, end, obs, n_obs, tail_heat=tail_heat)
+        for grid in (mb.grid, mb.grid.flip(0).contiguous()):                    # second pass: a different batch through the same graph
+            cp.grid.copy_(grid)
+            res = cp.replay()
+            torch.cuda.synchronize()
+            mask, heat, want = eager(grid, tail_heat)
+            assert torch.equal(cp.mask, mask) and torch.equal(cp.heat, heat)
+            for k in ("ok", "counts", "collision", "success", "waypoints"):
+                assert torch.equal(res[k], want[k]), k
