@@ -555,10 +555,13 @@ int ppn_resize_bilinear_u8(const uint8_t* in, int32_t n, int32_t H, int32_t W, i
                            uint8_t* out, void* stream) {
     if (!in || n < 0 || H <= 0 || W <= 0 || outH <= 0 || outW <= 0 || !tmp || !out) return PPN_E_INVALID;
     if (n == 0) return PPN_OK;
-    const long long t1 = (long long)n * H * outW, t2 = (long long)n * outH * outW;
-    hipLaunchKernelGGL(ppn::resize_pass_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, n, H, W,
+    // a thread computes its output coordinate's filter weights once and walks PPN_RESIZE_REP lines (pass 1) / images (pass 2)
+    const long long g1 = ((long long)n * H + ppn::PPN_RESIZE_REP - 1) / ppn::PPN_RESIZE_REP;
+    const long long g2 = (((long long)n + ppn::PPN_RESIZE_REP - 1) / ppn::PPN_RESIZE_REP) * outH;
+    if (g1 >= (1LL << 31) || g2 >= (1LL << 31) || (outW + 255) / 256 > 65535) return PPN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(ppn::resize_pass_kernel, dim3((unsigned)g1, (unsigned)((outW + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, n, H, W,
                        H, outW, 1, tmp);
-    hipLaunchKernelGGL(ppn::resize_pass_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(ppn::resize_pass_kernel, dim3((unsigned)g2, (unsigned)((outW + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t*)tmp, n, H, outW, outH, outW, 0, out);
     PPN_HIP(hipGetLastError());
     return PPN_OK;

@@ -220,15 +220,19 @@ __global__ __launch_bounds__(64) void extract_paths_kernel(const float* heat, in
 
 // One pass of Pillow's ImagingResample for 8-bit pixels with the bilinear (triangle) filter.
 // horizontal != 0: in [n][inH][inW] -> out [n][inH][outW]; else in [n][inH][inW] -> out [n][outH][inW].
-// Coefficients are recomputed per output sample in double with Pillow's operation order
-// (precompute_coeffs + normalize_coeffs_8bpc, PRECISION_BITS = 22).
+// Coefficients follow Pillow's operation order in double (precompute_coeffs + normalize_coeffs_8bpc, PRECISION_BITS = 22).
+// They depend only on the output coordinate along the resampled axis, so a thread computes them ONCE (the two double loops with
+// a division per tap were the kernel's whole cost: 0.15 ms per 256 heat maps) and then walks RESIZE_REP rows (horizontal: rows of
+// the whole batch are independent lines) or RESIZE_REP images (vertical) with them.  Same integer arithmetic per output: bit-exact.
+constexpr int RESIZE_REP = PPN_RESIZE_REP, RESIZE_TAPS = 8;
 __global__ __launch_bounds__(256) void resize_pass_kernel(const uint8_t* in, int n, int inH, int inW, int outH, int outW,
                                                           int horizontal, uint8_t* out) {
     const int oH = horizontal ? inH : outH, oW = horizontal ? outW : inW;
-    const long long total = (long long)n * oH * oW;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int x = (int)(idx % oW), y = (int)((idx / oW) % oH), img = (int)(idx / ((long long)oW * oH));
+    // grid.y = 256-pixel pieces of an output row;  grid.x = groups of RESIZE_REP lines of the batch (horizontal: n * inH lines) or
+    // (group of RESIZE_REP images, output row) pairs (vertical) — block-uniform, split on the scalar unit
+    const int x = (int)(blockIdx.y * 256u + threadIdx.x);
+    if (x >= oW) return;
+    const int y = horizontal ? 0 : (int)(blockIdx.x % (uint32_t)oH);
     const int inSize = horizontal ? inW : inH, outSize = horizontal ? outW : outH, xx = horizontal ? x : y;
     const double scale = (double)inSize / (double)outSize;
     double filterscale = scale;
@@ -247,20 +251,44 @@ __global__ __launch_bounds__(256) void resize_pass_kernel(const uint8_t* in, int
         if (a < 0.0) a = -a;
         ww += a < 1.0 ? 1.0 - a : 0.0;
     }
-    int acc = 1 << 21;
-    const uint8_t* base = in + (size_t)img * inH * inW;
-    for (int t = 0; t < xmax; ++t) {
+    const bool cached = xmax <= RESIZE_TAPS;                                  // down-sampling by more than 4 falls back to per-output weights
+    int kq[RESIZE_TAPS];
+#pragma unroll
+    for (int t = 0; t < RESIZE_TAPS; ++t) {
         double a = ((double)(t + xmin) - center + 0.5) * ss;
         if (a < 0.0) a = -a;
         double w = a < 1.0 ? 1.0 - a : 0.0;
         if (ww != 0.0) w = w / ww;
-        const int kq = w < 0.0 ? (int)(-0.5 + w * 4194304.0) : (int)(0.5 + w * 4194304.0);
-        const int pix = horizontal ? base[(size_t)y * inW + xmin + t] : base[(size_t)(xmin + t) * inW + x];
-        acc += pix * kq;
+        kq[t] = (t < xmax) ? (w < 0.0 ? (int)(-0.5 + w * 4194304.0) : (int)(0.5 + w * 4194304.0)) : 0;
     }
-    int v = acc >> 22;
-    v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    out[idx] = (uint8_t)v;
+    const long long lines = horizontal ? (long long)n * inH : (long long)n;
+    const long long first = (long long)(horizontal ? blockIdx.x : blockIdx.x / (uint32_t)oH) * RESIZE_REP;
+    for (int r = 0; r < RESIZE_REP; ++r) {
+        const long long line = first + r;
+        if (line >= lines) break;
+        // horizontal: `line` is a row of the batch (image line / inH, row line % inH — contiguous either way); vertical: an image
+        const uint8_t* src = horizontal ? in + (size_t)line * inW + xmin : in + ((size_t)line * inH + xmin) * inW + x;
+        const size_t step = horizontal ? 1 : (size_t)inW;
+        int acc = 1 << 21;
+        if (cached) {
+#pragma unroll
+            for (int t = 0; t < RESIZE_TAPS; ++t)
+                if (t < xmax) acc += (int)src[(size_t)t * step] * kq[t];
+        } else {
+            for (int t = 0; t < xmax; ++t) {
+                double a = ((double)(t + xmin) - center + 0.5) * ss;
+                if (a < 0.0) a = -a;
+                double w = a < 1.0 ? 1.0 - a : 0.0;
+                if (ww != 0.0) w = w / ww;
+                const int k = w < 0.0 ? (int)(-0.5 + w * 4194304.0) : (int)(0.5 + w * 4194304.0);
+                acc += (int)src[(size_t)t * step] * k;
+            }
+        }
+        int v = acc >> 22;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        const size_t o = horizontal ? (size_t)line * oW + x : ((size_t)line * oH + y) * oW + x;
+        out[o] = (uint8_t)v;
+    }
 }
 
 __global__ __launch_bounds__(256) void philox_doubles_kernel(uint64_t seed, uint32_t stream_id, uint64_t instance,

@@ -56,6 +56,7 @@ __global__ void collision_segments_kernel(const float* s, const float* e, const 
 __global__ void extract_paths_kernel(const float* heat, int n, int H, int W, const double* init,
                                      const double* end, int max_wp, double* wp, int32_t* wp_n, uint8_t* ok, int vis_dim, int stage_heat);
 
+constexpr int PPN_RESIZE_REP = 16;      // lines / images one thread of resize_pass_kernel walks with its filter weights
 __global__ void resize_pass_kernel(const uint8_t* in, int n, int inH, int inW, int outH, int outW, int horizontal,
                                    uint8_t* out);
 __global__ void philox_doubles_kernel(uint64_t seed, uint32_t stream_id, uint64_t instance, uint32_t first, int count,

@@ -160,13 +160,14 @@ def test_upsample2x_relu_vs_torch(dtype):
     from ppnet_amd import fused
     dt = getattr(torch, dtype)
     torch.manual_seed(2)
-    x = torch.randn(3, 64, 9, 13, device="cuda", dtype=dt).contiguous(memory_format=torch.channels_last)
-    for relu in (False, True):
-        got = fused.upsample2x_nhwc(x, relu)
-        ref = torch.nn.functional.interpolate(torch.relu(x.float()) if relu else x.float(), scale_factor=2, mode="bilinear",
-                                              align_corners=False)
-        assert got.shape == ref.shape
-        assert (got.float() - ref).abs().max() < (1e-5 if dt == torch.float32 else 2e-2)
+    for (h, w) in ((9, 13), (1, 1), (1, 5), (2, 2), (16, 16)):            # the kernel works on 2 x 2 output blocks: borders and 1-wide images
+        x = torch.randn(3, 64, h, w, device="cuda", dtype=dt).contiguous(memory_format=torch.channels_last)
+        for relu in (False, True):
+            got = fused.upsample2x_nhwc(x, relu)
+            ref = torch.nn.functional.interpolate(torch.relu(x.float()) if relu else x.float(), scale_factor=2, mode="bilinear",
+                                                  align_corners=False)
+            assert got.shape == ref.shape
+            assert (got.float() - ref).abs().max() < (1e-5 if dt == torch.float32 else 2e-2)
 
 
 @pytest.mark.gpu
