@@ -28,6 +28,17 @@ __device__ __forceinline__ void store4(__bf16* dst, const f32x4 v, const float4 
     for (int r = 0; r < 4; ++r) o[r] = o[r] > 0.f ? o[r] : o[r] * slope;
     *reinterpret_cast<bf16x4*>(dst) = bf16x4{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
 }
+// a0 / a1: rows 4g .. 4g+3 of the two output-channel tiles.  The rows of a tile are ASSIGNED to channels so that they are this
+// lane's channels 8g .. 8g+3 and 8g+4 .. 8g+7 (row_channel below): one 16-byte store per lane quarter g < 3 instead of an 8-byte
+// store per tile (the stages are store-bound: 805 MB out of the last decoder stage).
+__device__ __forceinline__ void store8(__bf16* dst, const f32x4 a0, const f32x4 a1, const float4 b0, const float4 b1, float slope) {
+    float o[8] = {a0[0] + b0.x, a0[1] + b0.y, a0[2] + b0.z, a0[3] + b0.w, a1[0] + b1.x, a1[1] + b1.y, a1[2] + b1.z, a1[3] + b1.w};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = o[r] > 0.f ? o[r] : o[r] * slope;
+    *reinterpret_cast<bf16x8*>(dst) = bf16x8{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3], (__bf16)o[4], (__bf16)o[5], (__bf16)o[6], (__bf16)o[7]};
+}
+// output channel of row `row` (0 .. 15) of tile nt: 8 (row / 4) + 4 nt + row % 4   (24 .. 31: the zero rows of the padded weights)
+__device__ __forceinline__ int row_channel(int nt, int row) { return 8 * (row >> 2) + 4 * nt + (row & 3); }
 }  // namespace
 
 constexpr int GC = 24;                 // channels
@@ -45,8 +56,8 @@ __global__ __launch_bounds__(256) void gennet_enc_conv_kernel(const __bf16* __re
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < 7; ++ks) wa[nt][ks] = ld8(wk + (nt * 16 + pl) * 224 + ks * 32 + g * 8);
-    const float4 b0 = *reinterpret_cast<const float4*>(bias + 4 * g), b1 = *reinterpret_cast<const float4*>(bias + 16 + 4 * g);
+        for (int ks = 0; ks < 7; ++ks) wa[nt][ks] = ld8(wk + row_channel(nt, pl) * 224 + ks * 32 + g * 8);
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + 8 * g), b1 = *reinterpret_cast<const float4*>(bias + 8 * g + 4);
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
     for (long long base = wave * (16 * GROUPS); base < total; base += nwaves * (16 * GROUPS)) {
         bf16x8 fb[GROUPS][7];
@@ -77,11 +88,7 @@ __global__ __launch_bounds__(256) void gennet_enc_conv_kernel(const __bf16* __re
                 a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1][ks], fb[q][ks], a1, 0, 0, 0);
             }
             const long long pix = base + q * 16 + pl;
-            if (pix < total) {
-                __bf16* dst = y + pix * GC;
-                store4(dst + 4 * g, a0, b0, slope);                       // co = 4g .. 4g+3
-                if (g < 2) store4(dst + 16 + 4 * g, a1, b1, slope);       // co = 16 + 4g ..; 24..31 are padding
-            }
+            if (pix < total && g < 3) store8(y + pix * GC + 8 * g, a0, a1, b0, b1, slope);      // co = 8g .. 8g+7; g = 3 is padding
         }
     }
 }
@@ -100,8 +107,8 @@ __global__ __launch_bounds__(256) void gennet_dec_conv_kernel(const __bf16* __re
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) wa[cl][nt][ks] = ld8(wt + ((cl * 32) + nt * 16 + pl) * 96 + ks * 32 + g * 8);
-    const float4 b0 = *reinterpret_cast<const float4*>(bias + 4 * g), b1 = *reinterpret_cast<const float4*>(bias + 16 + 4 * g);
+            for (int ks = 0; ks < 3; ++ks) wa[cl][nt][ks] = ld8(wt + ((cl * 32) + row_channel(nt, pl)) * 96 + ks * 32 + g * 8);
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + 8 * g), b1 = *reinterpret_cast<const float4*>(bias + 8 * g + 4);
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
     const int Wo = 2 * W;
     for (long long base = wave * 16; base < total; base += nwaves * 16) {
@@ -128,11 +135,8 @@ __global__ __launch_bounds__(256) void gennet_dec_conv_kernel(const __bf16* __re
                 a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cl][0][ks], fb[ks], a0, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cl][1][ks], fb[ks], a1, 0, 0, 0);
             }
-            if (live) {
-                __bf16* dst = y + ((size_t)(img * 2 * H + (2 * iy + (cl >> 1))) * Wo + (2 * ix + (cl & 1))) * GC;
-                store4(dst + 4 * g, a0, b0, slope);
-                if (g < 2) store4(dst + 16 + 4 * g, a1, b1, slope);
-            }
+            if (live && g < 3)
+                store8(y + ((size_t)(img * 2 * H + (2 * iy + (cl >> 1))) * Wo + (2 * ix + (cl & 1))) * GC + 8 * g, a0, a1, b0, b1, slope);
         }
     }
 }

@@ -4,6 +4,7 @@
 // library's implicit-GEMM kernels take 0.54 + 0.72 ms per 256-problem batch where the tensors' HBM time is 0.16 ms each.
 // NHWC (channels_last) on the multi-channel side, float32 accumulation, bias (+ LeakyReLU for conv_first) fused.
 #include <hip/hip_bf16.h>
+#include <cstdlib>
 #include "ppn_device.h"
 #include "ppn_kernels.h"
 
@@ -121,6 +122,75 @@ __global__ __launch_bounds__(256) void conv3x3_to1_kernel(const T* __restrict__ 
     if constexpr (sizeof(T) == 2) *out = __float2bfloat16(acc); else *out = acc;
 }
 
+// The same convolution for GenNet's case (24 input channels, bfloat16) on the matrix cores, as TAP RESPONSES: with one output
+// channel the nine taps can be the MFMA's rows — T[tap][p] = sum_c w[tap][c] x[p][c] for every pixel p of the tile's halo is ONE
+// v_mfma_f32_16x16x32_bf16 per 16 pixels (rows = taps, 9 of 16 used; k = channels, 24 of 32 used; the float32 weights enter as
+// hi + lo bfloat16 fragments, two MFMAs, so the products are the float32 kernel's to 2^-17) — and the output is nine shifted reads,
+// y[i][j] = bias + sum_{di,dj} T[3 di + dj][i + di - 1][j + dj - 1].  Every input pixel is loaded from HBM / L2 exactly once per
+// tile, 16 bytes per lane straight into the B operand (pixel = column, 8 channels per lane quarter) — no LDS staging of the
+// image, 1/5 of the VALU form's LDS reads (it spends 108 ds_read_b128 per pixel on 216 FMAs and runs at 2 TB/s of its 805 MB).
+// Tile: 32 x 16 outputs per 256-thread workgroup, halo 34 x 18 = 612 pixels = 39 groups of 16 over the 4 waves, T in LDS as
+// [pixel][12 floats] (a lane's 4 taps = one 16-byte write), 29 KB.
+namespace {
+typedef __attribute__((ext_vector_type(8))) __bf16 t1_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float t1_f32x4;
+constexpr int T1_W = 32, T1_H = 16, T1_HW = T1_W + 2, T1_HH = T1_H + 2, T1_PIX = T1_HW * T1_HH, T1_GROUPS = (T1_PIX + 15) / 16;
+constexpr int T1_GPW = (T1_GROUPS + 3) / 4;                                // groups per wave
+}  // namespace
+
+__global__ __launch_bounds__(256) void conv3x3_to1_mfma_kernel(const __bf16* __restrict__ x, const float* __restrict__ w, float bias,
+                                                               __bf16* __restrict__ y, int B, int H, int W, const __bf16* __restrict__ zero) {
+    __shared__ __attribute__((aligned(16))) float Tl[T1_GROUPS * 16 * 12];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int tiles_x = (W + T1_W - 1) / T1_W, tiles_y = (H + T1_H - 1) / T1_H;
+    const int b = blockIdx.x / (tiles_x * tiles_y), tt = blockIdx.x - b * tiles_x * tiles_y;
+    const int i0 = (tt / tiles_x) * T1_H, j0 = (tt % tiles_x) * T1_W;
+    // A operand: row = tap (lane & 15), k = channel 8g .. 8g+7 (g = 3 and taps 9 .. 15: zero).  w is [24][9] float32 (ci * 9 + tap).
+    t1_bf16x8 ahi, alo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float wv = (j < 9 && g < 3) ? w[(8 * g + e) * 9 + j] : 0.0f;
+        const __bf16 h = (__bf16)wv;
+        ahi[e] = h; alo[e] = (__bf16)(wv - (float)h);
+    }
+    const __bf16* xb = x + (size_t)b * H * W * 24;
+    // all of this wave's pixel groups in flight before the first MFMA (unconditional addresses: out-of-image pixels and the
+    // unused lane quarter read a line of zeros, which is also the convolution's zero padding)
+    t1_bf16x8 fb[T1_GPW];
+#pragma unroll
+    for (int q = 0; q < T1_GPW; ++q) {
+        const int grp = wave * T1_GPW + q;
+        const int e = min(grp * 16 + j, T1_PIX - 1);
+        const int hy = e / T1_HW, hx = e - hy * T1_HW;
+        const int ii = i0 + hy - 1, jj = j0 + hx - 1;
+        const bool in = grp < T1_GROUPS && g < 3 && ii >= 0 && ii < H && jj >= 0 && jj < W;
+        const __bf16* src = in ? xb + ((size_t)ii * W + jj) * 24 + 8 * g : zero;
+        fb[q] = *reinterpret_cast<const t1_bf16x8*>(src);
+    }
+#pragma unroll
+    for (int q = 0; q < T1_GPW; ++q) {
+        const int grp = wave * T1_GPW + q;
+        t1_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, fb[q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, fb[q], acc, 0, 0, 0);
+        // lane (j, g) holds taps 4g .. 4g+3 of pixel 16 grp + j
+        if (grp < T1_GROUPS && g < 3) *reinterpret_cast<float4*>(Tl + (grp * 16 + j) * 12 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;               // two output rows per thread: ty0 and ty0 + 8
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int ty = ty0 + 8 * r;
+        const int i = i0 + ty, jx = j0 + tx;
+        float acc = bias;
+#pragma unroll
+        for (int di = 0; di < 3; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) acc += Tl[((ty + di) * T1_HW + tx + dj) * 12 + di * 3 + dj];
+        if (i < H && jx < W) y[((size_t)b * H + i) * W + jx] = (__bf16)acc;
+    }
+}
+
 int conv3x3_c1_launch(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cout, float slope, int dtype,
                       hipStream_t stream) {
     const long long total = (long long)B * H * W;
@@ -167,6 +237,16 @@ int heatmap_u8_launch(const void* y, uint8_t* out, int B, int n, int dtype, hipS
 }
 
 int conv3x3_to1_launch(const void* x, const float* w, float bias, void* y, int B, int H, int W, int Cin, int dtype, hipStream_t stream) {
+    // GenNet's shape on the matrix cores (PPNET_TO1_VALU=1 keeps the direct form for A/B runs)
+    static const bool valu = getenv("PPNET_TO1_VALU") != nullptr;
+    if (dtype == 1 && Cin == 24 && !valu) {
+        const __bf16* zero = (const __bf16*)zero_line();
+        if (!zero) return (int)hipErrorOutOfMemory;
+        const long long tiles = (long long)B * ((H + T1_H - 1) / T1_H) * ((W + T1_W - 1) / T1_W);
+        if (tiles >= (1LL << 31)) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL(conv3x3_to1_mfma_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, (const __bf16*)x, w, bias, (__bf16*)y, B, H, W, zero);
+        return (int)hipGetLastError();
+    }
     const dim3 grid((unsigned)((long long)B * ((H + 15) / 16) * ((W + 15) / 16)));
 #define PPN_TO1(T, CG) hipLaunchKernelGGL((conv3x3_to1_kernel<T, CG>), grid, dim3(256), 0, stream, (const T*)x, w, bias, (T*)y, B, H, W)
     const int cg = Cin / 8;
