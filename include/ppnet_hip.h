@@ -335,6 +335,13 @@ int ppn_conv3x3_relu_classify2_bf16(const void* x, const void* w, const float* b
  * bias [32] float32 (24..31 zero). */
 int ppn_gennet_conv_s2_bf16(const void* x, const void* w, const float* bias, void* y, int32_t B, int32_t H, int32_t W, float negative_slope,
                             int32_t transposed, void* stream);
+/* GenNet's LAST decoder stage fused with its final convolution (ae_vit.py:44-58: ConvTranspose2d(24, 24, 3, 2, 1, output_padding=1) + BN +
+ * LeakyReLU, then Conv2d(24, 1, 3, 1, 1)): x [B][H][W][24] bfloat16 -> y [B][2H][2W] bfloat16; the 24-channel tensor at the output
+ * resolution never reaches memory.  w / bias / negative_slope: the decoder stage as for ppn_gennet_conv_s2_bf16 (transposed form);
+ * w_final [24][9] float32 (input channel, tap ky*3+kx) = the final convolution's weight [1][24][3][3]; bias_final its bias.
+ * Bit-identical to ppn_gennet_conv_s2_bf16 followed by ppn_conv3x3_to1_nhwc on bfloat16 tensors. */
+int ppn_gennet_dec_final_bf16(const void* x, const void* w, const float* bias, float negative_slope, const float* w_final, float bias_final, void* y,
+                              int32_t B, int32_t H, int32_t W, void* stream);
 /* GenNet's first convolution fused into its first encoder stage (ae_vit.py:24-36: Conv2d(1, 24, 3, 1, 1) + BN + LeakyReLU, then
  * Conv2d(24, 24, 3, 2, 1) + BN + LeakyReLU; BatchNorms folded by the caller): x1 [B][H][W] bfloat16 -> y [B][H/2][W/2][24] bfloat16, the
  * 24-channel full-resolution tensor in between never reaches memory.  H, W even.

@@ -474,6 +474,15 @@ int ppn_gennet_first_enc_bf16(const void* x1, const void* w1, const float* b1, c
     return PPN_OK;
 }
 
+int ppn_gennet_dec_final_bf16(const void* x, const void* w, const float* bias, float negative_slope, const float* w_final, float bias_final, void* y,
+                              int32_t B, int32_t H, int32_t W, void* stream) {
+    if (!x || !w || !bias || !w_final || !y || B <= 0 || H <= 0 || W <= 0) return PPN_E_INVALID;
+    if ((long long)B * H * W * 4 * 24 >= (1LL << 32)) return PPN_E_UNSUPPORTED;     // 32-bit element offsets inside one image batch
+    const int e = ppn::gennet_dec_final_launch(x, w, bias, negative_slope, w_final, bias_final, y, B, H, W, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_gennet_trunk_bf16(const void* x, void* y, const float* params, int32_t B, int32_t N, int32_t n_blocks, void* stream) {
     if (!x || !y || !params || B <= 0 || N <= 0 || N > 1024 || (N % 8) != 0 || n_blocks <= 0) return PPN_E_INVALID;
     const int e = ppn::gennet_trunk_launch(x, y, params, B, N, n_blocks, (hipStream_t)stream);

@@ -141,6 +141,113 @@ __global__ __launch_bounds__(256) void gennet_dec_conv_kernel(const __bf16* __re
     }
 }
 
+// The LAST decoder stage fused with GenNet's final convolution (ae_vit.py:44-58: ConvTranspose2d + BN + LeakyReLU, then
+// Conv2d(dim, 1, 3, 1, 1)): the 24-channel full-resolution tensor (805 MB per batch of 256 at 256 x 256) is neither written nor read.
+// A workgroup owns a 32 x 16 tile of the final image.  Its 34 x 18 halo lies inside the 2 x 2 output blocks of 18 x 10 decoder
+// input positions; for each group of 16 positions the decoder product runs as in gennet_dec_conv_kernel, and its accumulators —
+// bias, LeakyReLU, rounded to bfloat16 exactly as the stored tensor was — ARE the B operand (pixel = column, lane quarter g =
+// channels 8g .. 8g+7) of the final convolution's tap-response product of small_conv.hip (T[tap][pixel] = sum_c w1[tap][c] x[pixel][c],
+// float32 weights as hi + lo bfloat16): two more MFMAs per class, T to LDS (zero for pixels outside the image: the convolution's
+// padding), then y[i][j] = bias1 + sum of the nine shifted taps.  Same values in the same order as the two-kernel path: bit-identical.
+namespace {
+constexpr int DF_W = 32, DF_H = 16;                                        // final-resolution outputs per workgroup
+constexpr int DF_PW = DF_W / 2 + 2, DF_PH = DF_H / 2 + 2, DF_POS = DF_PW * DF_PH;      // decoder input positions: 18 x 10
+constexpr int DF_TW = 2 * DF_PW, DF_TH = 2 * DF_PH;                        // T region: 36 x 20 pixels, origin (i0 - 2, j0 - 2)
+constexpr int DF_GROUPS = (DF_POS + 15) / 16, DF_GPW = (DF_GROUPS + 3) / 4;
+}  // namespace
+
+__global__ __launch_bounds__(256) void gennet_dec_final_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ wt, const float* __restrict__ bias,
+                                                               float slope, const float* __restrict__ w1, float bias1, __bf16* __restrict__ y,
+                                                               int B, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float Tl[DF_TW * DF_TH * 12];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pl = lane & 15, g = lane >> 4;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const int tiles_x = (Wo + DF_W - 1) / DF_W, tiles_y = (Ho + DF_H - 1) / DF_H;
+    const int total_tiles = B * tiles_x * tiles_y;
+    bf16x8 wa[4][2][3];
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) wa[cl][nt][ks] = ld8(wt + ((cl * 32) + row_channel(nt, pl)) * 96 + ks * 32 + g * 8);
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + 8 * g), b1 = *reinterpret_cast<const float4*>(bias + 8 * g + 4);
+    // final convolution: row = tap (lane & 15), k = channel 8g .. 8g+7; w1 is [24][9] float32 (ci * 9 + tap)
+    bf16x8 ahi, alo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float wv = (pl < 9 && g < 3) ? w1[(8 * g + e) * 9 + pl] : 0.0f;
+        const __bf16 h = (__bf16)wv;
+        ahi[e] = h; alo[e] = (__bf16)(wv - (float)h);
+    }
+    // persistent: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... so the 26 weight fragments above are loaded once
+    // per wave, not once per 512 outputs (they are 11x the bytes of a tile's own input)
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const int b = tile / (tiles_x * tiles_y), tt = tile - b * tiles_x * tiles_y;
+    const int i0 = (tt / tiles_x) * DF_H, j0 = (tt % tiles_x) * DF_W;
+    const __bf16* xb = x + (size_t)b * H * W * GC;
+    bf16x8 fb[DF_GPW][3];
+#pragma unroll
+    for (int q = 0; q < DF_GPW; ++q) {
+        const int e = min((wave * DF_GPW + q) * 16 + pl, DF_POS - 1);
+        const int py = e / DF_PW, px = e - py * DF_PW;
+        const int iy = (i0 >> 1) - 1 + py, ix = (j0 >> 1) - 1 + px;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int c = ks * 4 + g;                            // chunk: input pixel c / 3 of the 2x2 block, channels (c % 3) * 8 ..
+            const int p = c / 3, ci0 = (c - p * 3) * 8;
+            const int yy = iy + (p >> 1), xx = ix + (p & 1);
+            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            fb[q][ks] = in ? ld8(xb + (uint32_t)((yy * W + xx) * GC + ci0)) : zero8();
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < DF_GPW; ++q) {
+        const int grp = wave * DF_GPW + q;
+        const int e = min(grp * 16 + pl, DF_POS - 1);
+        const int py = e / DF_PW, px = e - py * DF_PW;
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cl][0][ks], fb[q][ks], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cl][1][ks], fb[q][ks], a1, 0, 0, 0);
+            }
+            // this lane's 8 channels of output pixel (ly, lx) of the T region, as the tensor the unfused path stores
+            const int ly = 2 * py + (cl >> 1), lx = 2 * px + (cl & 1);
+            const int oy = i0 - 2 + ly, ox = j0 - 2 + lx;
+            const bool inside = oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+            float o[8] = {a0[0] + b0.x, a0[1] + b0.y, a0[2] + b0.z, a0[3] + b0.w, a1[0] + b1.x, a1[1] + b1.y, a1[2] + b1.z, a1[3] + b1.w};
+            bf16x8 xv;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float v = o[r] > 0.f ? o[r] : o[r] * slope;
+                xv[r] = (inside && g < 3) ? (__bf16)v : (__bf16)0.0f;
+            }
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, xv, t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, xv, t, 0, 0, 0);
+            if (grp < DF_GROUPS && g < 3) *reinterpret_cast<float4*>(Tl + (ly * DF_TW + lx) * 12 + 4 * g) = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;               // two output rows per thread: ty0 and ty0 + 8
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int ty = ty0 + 8 * r;
+        const int i = i0 + ty, jx = j0 + tx;
+        float acc = bias1;
+#pragma unroll
+        for (int di = 0; di < 3; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) acc += Tl[((ty + 1 + di) * DF_TW + tx + 1 + dj) * 12 + di * 3 + dj];
+        if (i < Ho && jx < Wo) y[((size_t)b * Ho + i) * Wo + jx] = (__bf16)acc;
+    }
+    __syncthreads();                                                        // T is rewritten by the next tile
+    }
+}
+
 // GenNet's first convolution (1 -> 24, 3x3, stride 1, + BN + LeakyReLU, ae_vit.py:24-28) FUSED into the first encoder stage
 // (24 -> 24, stride 2): the 24-channel full-resolution tensor between them (805 MB at batch 256, 256 x 256) is never written.
 // Per 16 output pixels and per encoder tap t (9 of them), the first convolution's output at the tap's position is itself a
@@ -254,6 +361,18 @@ int gennet_enc_conv_launch(const void* x, const void* wk, const float* bias, voi
     if (blocks > 256 * 16) blocks = 256 * 16;                    // grid-stride: the register-resident weights are loaded once per wave
     hipLaunchKernelGGL(gennet_enc_conv_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)wk, bias,
                        (__bf16*)y, B, H, W, slope);
+    return (int)hipGetLastError();
+}
+
+int gennet_dec_final_launch(const void* x, const void* wt, const float* bias, float slope, const float* w1, float bias1, void* y, int B, int H, int W,
+                            hipStream_t stream) {
+    const long long tiles = (long long)B * ((2 * H + DF_H - 1) / DF_H) * ((2 * W + DF_W - 1) / DF_W);
+    if (tiles >= (1LL << 31)) return (int)hipErrorInvalidValue;
+    static int cus = 0;
+    if (!cus) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; else cus = 256; }
+    const long long grid = tiles < 2LL * cus ? tiles : 2LL * cus;          // 2 workgroups per CU (212 VGPRs: two waves per SIMD)
+    hipLaunchKernelGGL(gennet_dec_final_kernel, dim3((unsigned)grid), dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)wt, bias, slope, w1, bias1,
+                       (__bf16*)y, B, H, W);
     return (int)hipGetLastError();
 }
 

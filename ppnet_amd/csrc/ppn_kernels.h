@@ -92,6 +92,8 @@ int plan_collision_launch(const double* full, const int32_t* counts, const void*
                           float clearance, float bound, uint8_t* collision, hipStream_t stream);
 int na2d_dense7_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
                        float scale, hipStream_t stream);
+int gennet_dec_final_launch(const void* x, const void* wt, const float* bias, float slope, const float* w1, float bias1, void* y, int B, int H, int W,
+                            hipStream_t stream);
 int gennet_first_enc_launch(const void* x1, const void* w1, const float* b1, const void* wk2, const float* bias2, void* y, int B, int H, int W, float slope1,
                             float slope2, hipStream_t stream);
 int heatmap_u8_launch(const void* y, uint8_t* out, int B, int n, int dtype, hipStream_t stream);

@@ -406,6 +406,25 @@ def nat128_ln_mlp_(s, offset, ln, fc1, fc2):
     return s
 
 
+def gennet_dec_final(x_nchw_cl, w_packed, bias32, negative_slope, w_final32, bias_final):
+    """GenNet's last decoder stage + final convolution as one kernel (ppn_gennet_dec_final_bf16): x channels_last bfloat16
+    [B,24,H,W] -> [B,1,2H,2W]; w_packed / bias32 from gennet.pack_s2_weights (transposed), w_final32 the final convolution's
+    float32 weight [1,24,3,3], bias_final a Python float."""
+    if not (x_nchw_cl.is_cuda and x_nchw_cl.dtype == torch.bfloat16):
+        raise RuntimeError("ppnet_amd.fused.gennet_dec_final: bfloat16 GPU tensors only")
+    x = x_nchw_cl.permute(0, 2, 3, 1)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, H, W, C = x.shape
+    assert C == 24 and w_final32.dtype == torch.float32 and w_final32.is_contiguous() and w_final32.numel() == 24 * 9
+    y = torch.empty(B, 1, 2 * H, 2 * W, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = L.lib.ppn_gennet_dec_final_bf16(_p(x), _p(w_packed), _p(bias32), float(negative_slope), _p(w_final32), float(bias_final), _p(y), B, H, W,
+                                             ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    L.check(rc, "ppn_gennet_dec_final_bf16")
+    return y
+
+
 def gennet_first_enc(x, w1, b1, wk2, b2, slope1, slope2):
     """GenNet's first convolution + first encoder stage as one kernel (ppn_gennet_first_enc_bf16): x [B,1,H,W] bfloat16 ->
     channels_last [B,24,H/2,W/2]; parameters from gennet.pack_first_enc_weights."""

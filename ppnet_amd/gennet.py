@@ -256,9 +256,23 @@ class AEViT(nn.Module):
         else:
             t = self.vit_blocks(x.flatten(2).transpose(1, 2))                # feature2token / token2feature, base.py:43-52
             x = t.transpose(1, 2).reshape(B, C, H, W)
+        c = self.conv_final
+        last = self.dec_conv[-1] if len(self.dec_conv) else None
+        if (isinstance(last, _FusedStage) and x.is_cuda and x.dtype == torch.bfloat16 and self._final_f32 is not None and c.out_channels == 1
+                and c.in_channels == 24 and isinstance(last.conv, nn.ConvTranspose2d) and _is_s2_stage(last.conv)
+                and not os.environ.get("PPNET_GENNET_UNFUSED_TAIL") and not os.environ.get("PPNET_LIBRARY_CONV")):
+            # prepared bfloat16 inference: the last decoder stage and the final convolution are one kernel — the 24-channel tensor
+            # at the output resolution never reaches memory (ppn_gennet_dec_final_bf16; bit-identical to the two kernels)
+            from . import fused
+            for blk in self.dec_conv[:-1]:
+                x = blk(x)
+            if last._s2 is None or last._s2[0] != x.device:
+                last._s2 = (x.device,) + pack_s2_weights(last.conv)
+            if self._final_f32[0] != x.device:
+                self._final_f32 = (x.device, c.weight.detach().float().contiguous().to(x.device), self._final_f32[2])
+            return fused.gennet_dec_final(x, last._s2[1], last._s2[2], last.slope, self._final_f32[1], self._final_f32[2])
         for blk in self.dec_conv:
             x = blk(x)
-        c = self.conv_final
         if x.is_cuda and self._final_f32 is not None and c.out_channels == 1 and c.in_channels % 8 == 0 and c.in_channels <= 32:
             from . import fused                                               # dim -> 1 at full resolution: direct HIP kernel
             if self._final_f32[0] != x.device:

@@ -323,3 +323,30 @@ def test_tokenizer_one_kernel_matches_two_kernel_path(monkeypatch):
         b = tok.forward_codes(grid).float()
     err = (a - b).abs()
     assert a.shape == b.shape and float(err.max()) < 0.05 and float(err.mean()) < 4e-3, (float(err.max()), float(err.mean()))
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 8, 8), (3, 9, 21), (2, 128, 128), (1, 40, 24)])
+def test_gennet_fused_decoder_tail_is_bit_identical_to_the_two_kernels(B, H, W):
+    """ppn_gennet_dec_final_bf16 (last ConvTranspose2d stage + bias + LeakyReLU, then the 24 -> 1 convolution, the 24-channel
+    tensor never stored) against ppn_gennet_conv_s2_bf16 followed by ppn_conv3x3_to1_nhwc: the same products in the same order,
+    so every bfloat16 output is EQUAL (ragged tiles, image borders and odd sizes included); and against float32 torch."""
+    import torch.nn as nn
+    from ppnet_amd import fused
+    from ppnet_amd.gennet import pack_s2_weights
+    torch.manual_seed(3 * B + H)
+    dec = nn.ConvTranspose2d(24, 24, 3, 2, 1, output_padding=1).cuda()
+    fin = nn.Conv2d(24, 1, 3, 1, 1).cuda()
+    with torch.no_grad():
+        dec.weight.copy_(dec.weight.to(BF).float())
+    x = torch.randn(B, 24, H, W, device="cuda").to(BF).contiguous(memory_format=torch.channels_last)
+    wp, bp = pack_s2_weights(dec)
+    w1 = fin.weight.detach().float().contiguous()
+    b1 = float(fin.bias.detach()[0])
+    mid = fused.gennet_conv_s2(x, wp, bp, 0.01, True)
+    two = fused.conv3x3_to1(mid, w1, b1)
+    one = fused.gennet_dec_final(x, wp, bp, 0.01, w1, b1)
+    assert one.shape == two.shape == (B, 1, 2 * H, 2 * W) and one.dtype == BF
+    assert torch.equal(one, two)
+    with torch.no_grad():
+        want = fin(F.leaky_relu(dec(x.float()), 0.01).to(BF).float())
+    _close(one, want)
