@@ -395,7 +395,7 @@ def main():
         if exchange and sent[m] is not None:
             s_maps.wait_event(sent[m])        # the records of batch it-2 have left this maps buffer
         edage.generate_maps(pviews[b][sub], PLACEMENTS, OBST_SIZE, K, seed=SEED, first_map_id=first_map, out=mbs[m])
-        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=ev0 is not None)      # the hand-off marker carries a timestamp only on the sampled launches
         ev1.record()
         if sub == GROUP - 1:
             consumed[b] = ev1                     # the last step of the group releases the path buffer

@@ -11,7 +11,7 @@ from .gennet import AEViT, normalize_heatmap_u8
 from .segnet import SegNet, normalize_images
 
 
-_TUNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gemm_gfx950_b256.csv")
+_TUNED = os.environ.get("PPNET_TUNED_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gemm_gfx950_b256.csv")
 
 
 def _use_tuned_gemms():
