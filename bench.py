@@ -294,8 +294,12 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # Defaults: 0.1 s of untimed steps, then 0.35 s of timed ones.  A step is 0.17-0.2 ms, and the chip needs tens of milliseconds of
+    # load to leave its idle clocks: measured on one box (profiles/r02_steps_sweep.txt) 20 timed steps after 3 give 49-52 M
+    # instances/s (maps kernel 0.187-0.190 ms), 400 steps 55-59 M, 4 000 steps 59-60 M (0.157-0.160 ms), and 16 000 steps (3 s)
+    # 53-55 M once the power limit pulls the clock back.  --steps / --warmup given on the command line are used as they are.
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ppnet", action="store_true", help="skip the PPNet plans/s leg (BASELINE config 3)")
     ap.add_argument("--ppnet-batch", type=int, default=256)
@@ -328,7 +332,7 @@ def main():
     GROUP = int(os.environ.get("BENCH_PATH_GROUP", "1"))
     if GROUP > 1 and (args.warmup % GROUP or args.steps % GROUP):
         raise SystemExit(f"BENCH_PATH_GROUP={GROUP}: --warmup and --steps must be multiples of it (the timed region must hold whole groups)")
-    TIMED_EVERY = 2          # every 2nd launch carries a start marker: >= 10 launches averaged at the default --steps 20
+    TIMED_EVERY = 2 if args.steps < 80 else 4      # every 2nd / 4th launch carries a start marker: >= 10 launches averaged from --steps 20 on
     NPB = DEPTH + 1
     pbs = [edage.PathsBatch(PATHS * GROUP, R, MAP_SIZE, CLEARANCE, dev) for _ in range(NPB)]
     pviews = [[pb.view(k * PATHS, PATHS) for k in range(GROUP)] for pb in pbs]
@@ -342,8 +346,14 @@ def main():
         s_comm = torch.cuda.Stream(dev)
         gathered = [torch.empty(max(world, 1) * PATHS * PLACEMENTS, shard.RECORD_WIDTH, dtype=torch.float64, device=dev) for _ in range(NMB)]
         sent = [None] * NMB       # the records of the batch in maps buffer m have been read by the collective (it may be rewritten)
-    s_paths = [torch.cuda.Stream(dev) for _ in range(DEPTH)]
+    prio = os.environ.get("BENCH_PRIO", "")
+    lo_p, hi_p = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+    s_paths = [torch.cuda.Stream(dev, priority=hi_p if prio == "paths" else (lo_p if prio == "maps" else 0)) for _ in range(DEPTH)]
     s_maps = torch.cuda.current_stream(dev)
+    if prio == "maps":
+        s_maps = torch.cuda.Stream(dev, priority=hi_p)
+        s_maps.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(s_maps)
     ready = [None] * NPB          # paths of buffer b are complete
     consumed = [None] * NPB       # the maps kernel reading buffer b has finished
     launched = [-1]               # newest batch whose stage A has been launched
@@ -395,7 +405,7 @@ def main():
         if exchange and sent[m] is not None:
             s_maps.wait_event(sent[m])        # the records of batch it-2 have left this maps buffer
         edage.generate_maps(pviews[b][sub], PLACEMENTS, OBST_SIZE, K, seed=SEED, first_map_id=first_map, out=mbs[m])
-        ev1 = torch.cuda.Event(enable_timing=ev0 is not None)      # the hand-off marker carries a timestamp only on the sampled launches
+        ev1 = torch.cuda.Event(enable_timing=ev0 is not None or bool(os.environ.get("BENCH_TIMED_HANDOFF")))   # a timestamp only on the sampled launches
         ev1.record()
         if sub == GROUP - 1:
             consumed[b] = ev1                     # the last step of the group releases the path buffer

@@ -29,10 +29,13 @@ __device__ unsigned long long g_phase_cycles[16];
 #define PPN_STAMP_INIT do {} while (0)
 #endif
 
-// Two waves per map: the placement is one wave's work, and with four waves three of them idled through it (measured 0.204 ->
-// 0.198 ms per bench step; 22 waves per CU, LDS-limited, against 28 before).
+// Waves per map.  The placement is one wave's work, so a four-wave workgroup idles three waves through it, and at the chip's idle
+// clocks (a 20-step run) two waves per map measured 3 % faster per bench step (0.204 -> 0.198 ms).  Once the chip has been under
+// load for a few hundred milliseconds (bench.py's default window) four waves win by the same 3 % on one box, three alternations:
+// 52.6-53.1 M instances/s (maps kernel 0.181-0.183 ms) with two, 54.0-54.8 M (0.174-0.176 ms) with four — the raster and the
+// 64 KiB store phase finish sooner per map and fewer maps are in flight per CU.  `make w2` builds the two-wave library for A/B runs.
 #ifndef PPN_MAPS_THREADS
-#define PPN_MAPS_THREADS 128
+#define PPN_MAPS_THREADS 256
 #endif
 #ifndef PPN_MAPS_WAVES_PER_EU
 #define PPN_MAPS_WAVES_PER_EU 6   // register budget of the stage-B kernel: waves per SIMD it must allow (6 -> <= 80 VGPRs, no spills)

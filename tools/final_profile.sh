@@ -6,9 +6,9 @@ set -e
 TAG=${1:-r02}
 ROOT=$PWD; OUT=$ROOT/gpurun_out/final; mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py --steps 50 > $OUT/bench.json 2> $OUT/bench.err
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 $ROOT/bench.py --no-cpu-baseline --no-ppnet --steps 50 > $OUT/ks.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 $ROOT/bench.py --no-cpu-baseline --no-ppnet > $OUT/ks.log 2>&1
 cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ppnet > $OUT/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ppnet > $OUT/pw.log 2>&1
@@ -29,5 +29,10 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/na_f -- python3 $ROOT/too
 python3 $ROOT/tools/pmc_avg.py /tmp/na_f | grep na2d > $OUT/na_pmc_fetch.txt || true
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/na_w -- python3 $ROOT/tools/na_timing.py > $OUT/na_w.log 2>&1
 python3 $ROOT/tools/pmc_avg.py /tmp/na_w | grep na2d > $OUT/na_pmc_write.txt || true
-tools/micro/gemm_bench > $OUT/gemm_bench.txt 2>&1 || true
+cd $ROOT
+GEMM_ONE_TILE_PER_BLOCK=1 tools/micro/gemm_bench > $OUT/gemm_bench.txt 2>&1 || true
+tools/micro/gemm_bench >> $OUT/gemm_bench.txt 2>&1 || true
+python3 tools/gemm_vs_lib.py > $OUT/gemm_vs_lib.txt 2>&1 || true
+python3 tools/graph_latency.py > $OUT/graph_latency.txt 2>&1 || true
+bash tools/steps_sweep.sh > $OUT/steps_sweep.txt 2>&1 || true
 tail -c 900 $OUT/bench.json
