@@ -267,3 +267,33 @@ def test_captured_graph_equals_eager(dev, stage_b, segnet_models):
             assert torch.equal(cp.mask, mask) and torch.equal(cp.heat, heat)
             for k in ("ok", "counts", "collision", "success", "waypoints"):
                 assert torch.equal(res[k], want[k]), k
+
+
+@pytest.mark.gpu
+def test_batches_on_two_streams_equal_one_stream(dev, stage_b, segnet_models):
+    """bench.py alternates consecutive batches over two HIP streams.  Every buffer of the path belongs to its call (or is keyed
+    by the stream), so two batches in flight must produce exactly what they produce one after the other."""
+    _, _, p16 = segnet_models
+    pb, mb = stage_b
+    init, end = mb.segpoint[:, 0].contiguous(), mb.segpoint[:, 10].contiguous()
+    obs, n_obs = mb.obstacles, mb.n_obstacles[:, 0].contiguous()
+    grids = [mb.grid, mb.grid.flip(0).contiguous(), mb.grid.flip(1).contiguous(), mb.grid.flip(2).contiguous()]
+
+    def one(g):
+        mask = p16.segment_u8(g)
+        heat = p16.heatmap(mask)
+        return mask, heat, p16.plan_tail(heat, init, end, obs, n_obs)
+    want = [one(g) for g in grids]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dev) for _ in range(2)]
+    got = []
+    for rep in range(2):                                                       # second round: the streams' allocator pools are warm
+        got = []
+        for i, g in enumerate(grids):
+            with torch.cuda.stream(streams[i % 2]):
+                got.append(one(g))
+        torch.cuda.synchronize()
+        for (m0, h0, r0), (m1, h1, r1) in zip(want, got):
+            assert torch.equal(m0, m1) and torch.equal(h0, h1)
+            for k in ("ok", "counts", "collision", "waypoints"):
+                assert torch.equal(r0[k], r1[k]), k
