@@ -1,0 +1,24 @@
+#!/bin/bash
+# The A/B knobs select older / library paths of the same ops: every one of them must still pass the tests of the op it touches.
+# Run on the GPU box from the repo root; one pytest process per knob.
+mkdir -p gpurun_out
+rc=0
+run() { # knob, test selection...
+  local knob=$1; shift
+  if env $knob timeout -k 10 600 python -m pytest "$@" -x -q -m gpu > gpurun_out/knob.log 2>&1; then echo "ok    $knob   $(tail -1 gpurun_out/knob.log)"; else echo "FAIL  $knob"; tail -15 gpurun_out/knob.log; rc=1; fi
+}
+G="tests/test_gennet_golden.py tests/test_ppnet_config3.py"
+S="tests/test_segnet.py tests/test_ppnet_config3.py"
+run PPNET_TRUNK_512=1 $G tests/test_gpu_mfma.py
+run PPNET_TRUNK_VALU=1 $G tests/test_gpu_mfma.py
+run PPNET_TO1_VALU=1 $G tests/test_segnet.py
+run PPNET_GENNET_UNFUSED_TAIL=1 $G
+run PPNET_GENNET_UNFUSED=1 $G
+run PPNET_LIBRARY_TRUNK=1 $G
+run PPNET_NA_VALU=1 tests/test_gpu_na.py $S
+run PPNET_NA_NO_DENSE7=1 tests/test_gpu_na.py $S
+run PPNET_LIBRARY_NAT128=1 $S
+run PPNET_TOKENIZER_TWO_KERNELS=1 $S
+run PPNET_LIBRARY_TOKENIZER=1 $S
+run PPNET_NO_FOLD=1 $S
+exit $rc
