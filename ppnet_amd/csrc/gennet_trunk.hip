@@ -264,11 +264,13 @@ typedef __attribute__((ext_vector_type(4))) float tf32x4;
 
 template <int NTHR>
 __global__ __launch_bounds__(NTHR) void gennet_trunk_mfma_kernel(const __bf16* __restrict__ xin, __bf16* __restrict__ yout,
-                                                                const float* __restrict__ params, int N, int n_blocks) {
+                                                                const float* __restrict__ params, int N, int n_blocks, float bound_max) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tl[];
     unsigned char* Ql = tl;                                                // [N][48 B]: q (scaled), later the attention output
     unsigned char* Kl = tl + (size_t)N * 48;
     unsigned char* Vl = tl + (size_t)N * 96;                               // + 64 B of slack behind it (transposed reads of head 2)
+    float* Qn = reinterpret_cast<float*>(tl + (size_t)N * 144 + 64);       // [N][3]: |q| of every token and head (upper bound, see below)
+    float* Kred = Qn + (size_t)N * 3;                                      // [NWAVES][3]: per-wave max |k|^2
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int prob = blockIdx.x;
     constexpr int TPT = 1024 / NTHR, NWAVES = NTHR / 64;                  // tokens per thread (N <= 1024), waves
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(NTHR) void gennet_trunk_mfma_kernel(const __bf16* _
         for (int s = 0; s < TPT; ++s) layer_norm24(x[s], P + O_LN1W, P + O_LN1B, y[s]);
         // ---- qkv rows to LDS (the previous block's phase C read only this thread's own Q rows; K / V readers are past the
         // barrier that closed the attention phase)
+        float k2max[TH] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int part = 0; part < 3; ++part)
 #pragma unroll
@@ -326,6 +329,19 @@ __global__ __launch_bounds__(NTHR) void gennet_trunk_mfma_kernel(const __bf16* _
                 }
                 unsigned char* base = part == 0 ? Ql : (part == 1 ? Kl : Vl);
                 const float sc = part == 0 ? qscale : 1.0f;
+                if (part < 2) {
+                    // |q| (scaled) per token and the workgroup's max |k|^2 per head: with them |q . k| <= |q| max|k| bounds every
+                    // logit of a query, which replaces the pass over all keys that only found the row maximum (the 1 % margin
+                    // covers the bfloat16 rounding of the stored q and k: 2^-9 per component)
+#pragma unroll
+                    for (int s = 0; s < TPT; ++s) {
+                        float n2 = 0.f;
+#pragma unroll
+                        for (int c = 0; c < THD; ++c) n2 += (o8[s][c] * sc) * (o8[s][c] * sc);
+                        if (part == 0) { if (live[s]) Qn[(size_t)tok[s] * 3 + h] = sqrtf(n2) * 1.01f; }
+                        else k2max[h] = fmaxf(k2max[h], live[s] ? n2 : 0.f);
+                    }
+                }
 #pragma unroll
                 for (int s = 0; s < TPT; ++s)
                     if (live[s])
@@ -333,7 +349,21 @@ __global__ __launch_bounds__(NTHR) void gennet_trunk_mfma_kernel(const __bf16* _
                             make_uint4(pack_bf16x2(o8[s][0] * sc, o8[s][1] * sc), pack_bf16x2(o8[s][2] * sc, o8[s][3] * sc),
                                        pack_bf16x2(o8[s][4] * sc, o8[s][5] * sc), pack_bf16x2(o8[s][6] * sc, o8[s][7] * sc));
             }
+#pragma unroll
+        for (int h = 0; h < TH; ++h) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) k2max[h] = fmaxf(k2max[h], __shfl_xor(k2max[h], o, 64));
+            if (lane == 0) Kred[wave * 3 + h] = k2max[h];
+        }
         __syncthreads();
+        float kmax[TH];
+#pragma unroll
+        for (int h = 0; h < TH; ++h) {
+            float m2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) m2 = fmaxf(m2, Kred[w * 3 + h]);
+            kmax[h] = sqrtf(m2) * 1.01f;
+        }
 
         // ---- attention on the matrix cores: this wave's query tiles, head by head
         const bf16x8 zf = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -343,8 +373,12 @@ __global__ __launch_bounds__(NTHR) void gennet_trunk_mfma_kernel(const __bf16* _
                 const unsigned char* kh = Kl + (size_t)j * 48 + h * 16;
                 bf16x8 qf = zf;
                 if (g == 0) qf = *reinterpret_cast<const bf16x8*>(Ql + (size_t)(qt * 16 + j) * 48 + h * 16);
-                // pass 1: the row maximum
-                float mx = -1.0e30f;
+                // The softmax's stabiliser: any mx >= the row maximum works as long as exp2(s - mx) stays a normal number, and
+                // |s| <= bound = |q| max|k| gives exp2(s - bound) in [2^(-2 bound), 1].  Up to bound = 40 (logits of +-28 in natural
+                // units; bound_max) that is what is used — no pass over the keys; beyond it the wave takes the exact row maximum (pass 1).
+                float mx = Qn[(size_t)(qt * 16 + j) * 3 + h] * kmax[h];
+                if (__any(mx > bound_max)) {
+                mx = -1.0e30f;
                 for (int kt = 0; kt < ntile; kt += 4) {
                     bf16x8 kf[4];
 #pragma unroll
@@ -357,7 +391,9 @@ __global__ __launch_bounds__(NTHR) void gennet_trunk_mfma_kernel(const __bf16* _
                 }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                }
                 // pass 2: probabilities and P V
+                const tf32x4 nmx = {-mx, -mx, -mx, -mx};
                 float lsum = 0.f;
                 tf32x4 oacc = {0.f, 0.f, 0.f, 0.f};
                 const unsigned char* vb = Vl + (size_t)(4 * g + q4) * 48 + h * 16 + 8 * p4;
@@ -371,11 +407,13 @@ __global__ __launch_bounds__(NTHR) void gennet_trunk_mfma_kernel(const __bf16* _
                     }
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
-                        tf32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[2 * half], qf, tf32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                        tf32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[2 * half + 1], qf, tf32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        // the row maximum rides in as the initial accumulator (this lane's four rows all belong to query j):
+                        // S' = K Q^T - max leaves the matrix pipe ready for exp2, no subtraction per logit
+                        tf32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[2 * half], qf, nmx, 0, 0, 0);
+                        tf32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[2 * half + 1], qf, nmx, 0, 0, 0);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            s0[r] = __builtin_amdgcn_exp2f(s0[r] - mx); s1[r] = __builtin_amdgcn_exp2f(s1[r] - mx);
+                            s0[r] = __builtin_amdgcn_exp2f(s0[r]); s1[r] = __builtin_amdgcn_exp2f(s1[r]);
                             lsum += s0[r] + s1[r];
                         }
                         const bf16x8 pf = {(__bf16)s0[0], (__bf16)s0[1], (__bf16)s0[2], (__bf16)s0[3], (__bf16)s1[0], (__bf16)s1[1], (__bf16)s1[2], (__bf16)s1[3]};
@@ -469,16 +507,18 @@ int gennet_trunk_launch(const void* x, void* y, const float* params, int B, int 
     // workgroup per CU at batch 256, so the only latency hiding there is comes from the waves of that workgroup
     static const bool t512 = getenv("PPNET_TRUNK_512") != nullptr;
     if (!valu && N % 64 == 0) {
-        const size_t lds_m = (size_t)N * 144 + 64;
+        const size_t lds_m = (size_t)N * 144 + 64 + (size_t)N * 12 + 16 * 3 * 4;      // Q, K, V rows + slack, |q| per (token, head), per-wave max |k|^2
         static std::atomic<int> attr_m{0};
         if (!attr_m.load()) {
-            hipError_t e = hipFuncSetAttribute((const void*)gennet_trunk_mfma_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gennet_trunk_mfma_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024 + 64);
+            hipError_t e = hipFuncSetAttribute((const void*)gennet_trunk_mfma_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024 + 64 + 192);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gennet_trunk_mfma_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024 + 64 + 192);
             if (e != hipSuccess) return (int)e;
             attr_m.store(1);
         }
-        if (t512) hipLaunchKernelGGL(gennet_trunk_mfma_kernel<512>, dim3(B), dim3(512), lds_m, stream, (const __bf16*)x, (__bf16*)y, params, N, n_blocks);
-        else hipLaunchKernelGGL(gennet_trunk_mfma_kernel<1024>, dim3(B), dim3(1024), lds_m, stream, (const __bf16*)x, (__bf16*)y, params, N, n_blocks);
+        // PPNET_TRUNK_EXACT_MAX=1: always take the exact row maximum (the two-pass softmax) instead of the norm bound — A/B and tests
+        const float bound_max = getenv("PPNET_TRUNK_EXACT_MAX") ? -1.0f : 40.0f;
+        if (t512) hipLaunchKernelGGL(gennet_trunk_mfma_kernel<512>, dim3(B), dim3(512), lds_m, stream, (const __bf16*)x, (__bf16*)y, params, N, n_blocks, bound_max);
+        else hipLaunchKernelGGL(gennet_trunk_mfma_kernel<1024>, dim3(B), dim3(1024), lds_m, stream, (const __bf16*)x, (__bf16*)y, params, N, n_blocks, bound_max);
         return (int)hipGetLastError();
     }
     const size_t lds = (size_t)N * 48 + (size_t)3 * (N / 2) * 8 * 4;

@@ -119,6 +119,37 @@ def test_gennet_trunk_vs_torch_blocks(B, side):
     _close(got.cpu(), want, rel=2e-2)
 
 
+@pytest.mark.parametrize("gain", [1.0, 4.0, 8.0])
+def test_gennet_trunk_softmax_stabiliser_paths(gain, monkeypatch):
+    """The trunk's softmax subtracts either the bound |q| max|k| (no pass over the keys; taken while the bound is <= 40) or the exact
+    row maximum (two passes).  gain 1: ordinary logits, the bound path by default — it must agree with the forced exact path
+    (PPNET_TRUNK_EXACT_MAX=1) to the bfloat16 rounding of the output.  gain 4: q and k weights x4, logits x16, the bound exceeds
+    40 for some (gain 4) or nearly all (gain 8) query tiles and those take the exact path by themselves — against float32 torch
+    (a peaked softmax amplifies the bfloat16 rounding of q and k: 5 % of the output scale) and again close to the forced path."""
+    from ppnet_amd import fused
+    from ppnet_amd.gennet import _Block, pack_trunk_params
+    torch.manual_seed(17)
+    blocks = torch.nn.Sequential(*[_Block(24, 3, 4) for _ in range(3)]).cuda().eval()
+    with torch.no_grad():
+        for b in blocks:
+            b.attn.qkv.weight[:48] *= gain
+            b.attn.qkv.bias[:48] *= gain
+        for p in blocks.parameters():
+            p.copy_(p.to(BF).float())
+    x = torch.randn(3, 24, 32, 32, device="cuda").to(BF).contiguous(memory_format=torch.channels_last)
+    params = pack_trunk_params(blocks).cuda()
+    got = fused.gennet_trunk(x, params, 3)
+    monkeypatch.setenv("PPNET_TRUNK_EXACT_MAX", "1")
+    exact = fused.gennet_trunk(x, params, 3)
+    monkeypatch.delenv("PPNET_TRUNK_EXACT_MAX")
+    d = (got.float() - exact.float()).abs()
+    assert float(d.max()) <= 2.0 ** -6 * float(exact.float().abs().max()) and float(d.mean()) < 1e-3 * float(exact.float().abs().mean())
+    with torch.no_grad():
+        t = blocks.cpu()(x.float().cpu().flatten(2).transpose(1, 2))
+        want = t.transpose(1, 2).reshape(3, 24, 32, 32)
+    _close(got.cpu(), want, rel={1.0: 2e-2, 4.0: 5e-2, 8.0: 0.12}[gain])     # logits x64 at gain 8: q / k rounding times a one-hot softmax
+
+
 def _nat128_modules(seed):
     import torch.nn as nn
     g = torch.Generator().manual_seed(seed)
