@@ -295,9 +295,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # Defaults: 0.1 s of untimed steps, then 0.35 s of timed ones.  A step is 0.17-0.2 ms, and the chip needs tens of milliseconds of
-    # load to leave its idle clocks: measured on one box (profiles/r02_steps_sweep.txt) 20 timed steps after 3 give 49-52 M
-    # instances/s (maps kernel 0.187-0.190 ms), 400 steps 55-59 M, 4 000 steps 59-60 M (0.157-0.160 ms), and 16 000 steps (3 s)
-    # 53-55 M once the power limit pulls the clock back.  --steps / --warmup given on the command line are used as they are.
+    # load to leave its idle clocks: measured back to back on one box (profiles/r02_steps_sweep.txt) 20 timed steps give 45 M
+    # instances/s (maps kernel 0.211 ms), 100 steps 52 M, 400 to 16 000 steps a flat 54-55 M (0.175 ms); another box reached
+    # 59-60 M at 4 000 steps and fell back to 53-55 M over 3 s.  --steps / --warmup given on the command line are used as they are.
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
