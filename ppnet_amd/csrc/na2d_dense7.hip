@@ -130,20 +130,20 @@ __global__ __launch_bounds__(64 * D7_WAVES, 6) void na2d_dense7_kernel(const __b
             }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float sum = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float p = __builtin_amdgcn_exp2f(s[t][e] - mx); s[t][e] = p; sum += p; }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+                for (int e = 0; e < 4; ++e) s[t][e] = __builtin_amdgcn_exp2f(s[t][e] - mx);
             if (qt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the V DMAs of this item have landed (same wave: no barrier)
             // O^T = V^T . P^T: k slot (g, e) of step ks is key 4g + (e & 3) of tile 2 ks + (e >> 2) — the S^T registers in place
-            f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            // the denominator: an all-ones A operand sums each query's (bfloat16-rounded) probabilities in the matrix pipe
+            f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, lsum = {0.f, 0.f, 0.f, 0.f};
+            const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const f32x4 pa = s[2 * ks], pb = s[2 * ks + 1];
                 const bf16x8 pf = {(__bf16)pa[0], (__bf16)pa[1], (__bf16)pa[2], (__bf16)pa[3], (__bf16)pb[0], (__bf16)pb[1], (__bf16)pb[2], (__bf16)pb[3]};
+                lsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, lsum, 0, 0, 0);
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
                     const unsigned char* va = vimg + (32 * ks + 4 * g + q4) * 64 + 8 * p4 + cb * 32;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * D7_WAVES, 6) void na2d_dense7_kernel(const __b
                 }
             }
             if (qvalid) {
-                const float inv = 1.0f / sum;
+                const float inv = 1.0f / lsum[0];
                 // the output row of a token is a third of its qkv row: byte offset trow / 3
                 unsigned char* dst = reinterpret_cast<unsigned char*>(out) + (trow / 3u + (uint32_t)h * (HD7 * 2) + 8 * g);
 #pragma unroll

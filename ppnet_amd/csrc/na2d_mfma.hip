@@ -191,16 +191,17 @@ __global__ __launch_bounds__(RT == 16 ? 512 : 256) void na2d_mfma_kernel(const _
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < HR; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(sacc[t][r] - mx); sacc[t][r] = e; sum += e; }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+            for (int r = 0; r < 4; ++r) sacc[t][r] = __builtin_amdgcn_exp2f(sacc[t][r] - mx);
 
         // O^T = V^T . P^T over 5 k-steps of 32 slots = key tiles (2ks, 2ks+1)
-        f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        // The softmax denominator comes out of the matrix pipe too: a third product per k-step with an all-ones A operand sums the
+        // (bfloat16-rounded, as the numerator uses them) probabilities of each query over the step's 32 key slots into every row of
+        // its column — 5 MFMAs on an idle pipe instead of 40 adds and two cross-lane exchanges on the VALU, which is this kernel's limit.
+        f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, lacc = {0.f, 0.f, 0.f, 0.f};
+        const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
         const unsigned char* vb = Vimg + ((ro * PC) + co + 4 * g + q4) * KB + 8 * p4;
         s16x4 vlo[HR / 2][2], vhi[HR / 2][2];
 #pragma unroll
@@ -222,9 +223,10 @@ __global__ __launch_bounds__(RT == 16 ? 512 : 256) void na2d_mfma_kernel(const _
                 const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 oacc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[cb], 0, 0, 0);
             }
+            lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, lacc, 0, 0, 0);
         }
         if (qvalid) {
-            const float inv = 1.0f / sum;
+            const float inv = 1.0f / lacc[0];
             const int y = gi + u * dil, x = gj + v * dil;
             __bf16* dst = out + ((size_t)(b * Hr + y) * Wr + x) * ((size_t)heads * MHD) + (size_t)h * MHD;
 #pragma unroll
@@ -269,6 +271,7 @@ int na2d_mfma_launch(const void* qkv, const void* pad_kv, const float* rpb, void
     int best = 16;
     if (util(8) > util(best) + 0.05) best = 8;
     if (util(4) > util(best) + 0.05) best = 4;
+    if (const char* f = getenv("PPNET_NA_RT")) { const int v = atoi(f); if (v == 4 || v == 8 || v == 16) best = v; }   // A/B: force the region size
     if (best == 4) return launch_rt<4>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, zero, stream);
     if (best == 8) return launch_rt<8>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, zero, stream);
     return launch_rt<16>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, zero, stream);
