@@ -101,6 +101,7 @@ __global__ __launch_bounds__(NT, PPN_PATHS_WAVES_PER_EU) void edage_paths_kernel
     __shared__ double red_v[NW];
     __shared__ int red_i[NW];
     __shared__ double bc[16];                     // broadcast scalars
+    __shared__ double at2[PPN_SEGS][2];           // atan of each segment's start / end gradient
 
     const int p = blockIdx.x;
     const int tid = threadIdx.x;
@@ -162,29 +163,50 @@ __global__ __launch_bounds__(NT, PPN_PATHS_WAVES_PER_EU) void edage_paths_kernel
         S.t0[s][0] = E; S.t0[s][1] = yE;
         S.grad[s][0] = horner3(S.pder[s], 0.0);
         S.grad[s][1] = horner3(S.pder[s], E);
-        // PathSeg.length (PathSeg.py:49-58): 100-sample polyline, sequential sum
-        double len = 0.0, xp = 0.0, yp = 0.0;
-        for (int j = 0; j < 100; ++j) {
-            const double x = ((double)j / 100.0) * (E - 0.0);
-            const double y = horner4(poly, x);
-            if (j) len = len + dist2d(x, y, xp, yp);
-            xp = x; yp = y;
+    }
+    __syncthreads();
+    // PathSeg.length (PathSeg.py:49-58): the 100-sample polyline of every segment.  Its 100 pieces (99 between samples + the one
+    // to the end point) are independent — each a Horner pair and a double square root — so all 1 000 are computed in parallel into
+    // the (not yet written) path-point area, and only the SUM stays sequential, in the reference's order: as ten 100-iteration
+    // chains on ten lanes this loop was a tenth of the kernel's latency.
+    {
+        double* dl = reinterpret_cast<double*>(paths_lds);           // [PPN_SEGS][100]; slot 0 = the closing piece
+        for (int q = tid; q < PPN_SEGS * 100; q += NT) {
+            const int s = q / 100, j = q - s * 100;
+            const double E = S.endpoint[s];
+            const int jp = j ? j - 1 : 99;
+            const double xp = ((double)jp / 100.0) * (E - 0.0), yp = horner4(S.poly[s], xp);
+            double x = E, y = S.t0[s][1];
+            if (j) { x = ((double)j / 100.0) * (E - 0.0); y = horner4(S.poly[s], x); }
+            dl[q] = dist2d(x, y, xp, yp);
         }
-        len = len + dist2d(E, yE, xp, yp);
-        if (O.seg_length) O.seg_length[(size_t)p * PPN_SEGS + s] = len;
+        __syncthreads();
+        if (tid < PPN_SEGS) {
+            double len = 0.0;
+            for (int j = 1; j < 100; ++j) len = len + dl[tid * 100 + j];
+            len = len + dl[tid * 100];
+            if (O.seg_length) O.seg_length[(size_t)p * PPN_SEGS + tid] = len;
+        }
     }
     __syncthreads();
 
     PPN_PSTAMP(0);
     // ------------------------------------------------------------------ A2: chaining (serial, tiny)
+    // the arctangents, cosines and sines are per segment (ten lanes at once); only the two running sums are serial
+    if (tid < PPN_SEGS) { at2[tid][0] = atan(S.grad[tid][0]); at2[tid][1] = atan(S.grad[tid][1]); }
+    __syncthreads();
     if (tid == 0) {
         double a = 0.0;
         S.ang[0] = 0.0;
         for (int i = 1; i < PPN_SEGS; ++i) {                     // angle_abs, Path.py:276-289
-            a = a + (atan(S.grad[i - 1][1]) - atan(S.grad[i][0]));
+            a = a + (at2[i - 1][1] - at2[i][0]);
             S.ang[i] = a;
         }
-        for (int i = 0; i < PPN_SEGS; ++i) { S.cs[i] = cos(S.ang[i]); S.sn[i] = sin(S.ang[i]); }
+    }
+    __syncthreads();
+    if (tid < PPN_SEGS) { S.cs[tid] = cos(S.ang[tid]); S.sn[tid] = sin(S.ang[tid]); }
+    __syncthreads();
+    if (tid == 0) {
         double tx = 0.0, ty = 0.0;                               // translation_seg, Path.py:291-299
         for (int i = 0; i < PPN_SEGS; ++i) {
             S.trans[i][0] = tx; S.trans[i][1] = ty;
