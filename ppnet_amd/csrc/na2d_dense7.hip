@@ -31,10 +31,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int HD7 = 32, D7_WAVES = 8;
 }  // namespace
 
-// T[h][u * G + v][slot]: rpb[h][kr - u + 6][kc - v + 6] * log2 e for key slot = kr * G + kc inside the query's window
+// T[h][u * G + v][slot]: rpb[h][kr - u + 6][kc - v + 6] / scale (the units of the raw product: the table is the logits' initial
+// accumulator) for key slot = kr * G + kc inside the query's window
 // (start clamp(u - 3, 0, G - 7) per axis: the whole group for G = 7), -1e30 outside it and on slots >= G * G
 template <int G>
-__global__ __launch_bounds__(256) void na2d_dense_table_kernel(const float* __restrict__ rpb, float* __restrict__ table, int heads) {
+__global__ __launch_bounds__(256) void na2d_dense_table_kernel(const float* __restrict__ rpb, float* __restrict__ table, int heads, float inv_scale) {
     constexpr int NK = G * G;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= heads * NK * 64) return;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void na2d_dense_table_kernel(const float* __re
     if (slot < NK) {
         const int u = qp / G, w = qp - u * G, kr = slot / G, kc = slot - kr * G;
         const int wu = min(max(u - 3, 0), G - 7), ww = min(max(w - 3, 0), G - 7);
-        if (kr >= wu && kr < wu + 7 && kc >= ww && kc < ww + 7) v = rpb[(size_t)h * 169 + (kr - u + 6) * 13 + (kc - w + 6)] * 1.4426950408889634f;
+        if (kr >= wu && kr < wu + 7 && kc >= ww && kc < ww + 7) v = rpb[(size_t)h * 169 + (kr - u + 6) * 13 + (kc - w + 6)] * inv_scale;
     }
     table[idx] = v;
 }
@@ -118,22 +119,22 @@ __global__ __launch_bounds__(64 * D7_WAVES, 6) void na2d_dense7_kernel(const __b
             const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qkvb + (trow + (uint32_t)h * (HD7 * 2) + 16 * g));
             // bias / window rows of this query's position in the group, from LDS
             const float* tb = tl + (u * G7 + v) * TP + 4 * g;
+            // bias + window mask are the MFMA's initial accumulator (raw-product units): S' = K Q^T + T out of the matrix pipe
             f32x4 s[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) s[t] = *reinterpret_cast<const f32x4*>(tb + 16 * t);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, s[t], 0, 0, 0);
             float mx = -3.0e38f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(tb + 16 * t);             // LDS: read where it is used
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { s[t][e] = __builtin_fmaf(s[t][e], sl2, bias[e]); mx = fmaxf(mx, s[t][e]); }
-            }
+            for (int t = 0; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float nm = -mx * sl2;                                      // p = 2^((S' - max) * scale * log2 e)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s[t][e] = __builtin_amdgcn_exp2f(s[t][e] - mx);
+                for (int e = 0; e < 4; ++e) s[t][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][e], sl2, nm));
             if (qt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the V DMAs of this item have landed (same wave: no barrier)
             // O^T = V^T . P^T: k slot (g, e) of step ks is key 4g + (e & 3) of tile 2 ks + (e >> 2) — the S^T registers in place
             // the denominator: an all-ones A operand sums each query's (bfloat16-rounded) probabilities in the matrix pipe
@@ -175,7 +176,7 @@ static int launch_dense_groups(const void* qkv, const void* pad_kv, const float*
     const int n = heads * G * G * 64;
     hipError_t e = hipMallocAsync((void**)&table, (size_t)n * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(na2d_dense_table_kernel<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rpb, table, heads);
+    hipLaunchKernelGGL(na2d_dense_table_kernel<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rpb, table, heads, 1.0f / scale);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;

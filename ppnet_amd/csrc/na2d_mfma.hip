@@ -42,7 +42,7 @@ __device__ __forceinline__ int clampm(int v, int lo, int hi) { return v < lo ? l
 // dilation groups).  The halo is staged once per tile for K and V (rows of 64 B, HROWS x PC slots; the PC - HCOLS slack columns
 // and everything outside the image are zero) and every block reads its 10 x 16 window of it.
 template <int RT>
-__global__ __launch_bounds__(RT == 16 ? 512 : 256) void na2d_mfma_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pad_kv,
+__global__ __launch_bounds__(RT == 16 ? 512 : 256, RT == 16 ? 4 : 2) void na2d_mfma_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pad_kv,
                                                            const float* __restrict__ rpb, __bf16* __restrict__ out, int B, int H, int W, int Hr,
                                                            int Wr, int heads, int dil, float scale, int tiles_y, int tiles_x, int total_tiles,
                                                            const __bf16* __restrict__ zero) {
@@ -54,11 +54,14 @@ __global__ __launch_bounds__(RT == 16 ? 512 : 256) void na2d_mfma_kernel(const _
     constexpr int PIECES = HROWS * PC * 4;
     constexpr int ITER = (PIECES + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char nl[];
-    float* BT = reinterpret_cast<float*>(nl);                              // [16][22]: rpb[h] * log2 e, zero outside the 13 x 13 table
+    float* BT = reinterpret_cast<float*>(nl);                              // [16][22]: rpb[h] / scale, zero outside the 13 x 13 table
+    // [16][22]: the same inside the centred 7 x 7 window, -1e30 elsewhere — bias AND window mask of a query whose window is not
+    // clamped by the image border.  Both in the units of the raw product: the logit is (q.k + table) * scale * log2 e
+    float* BTM = BT + BT_ROWS * BT_COLS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sub = TPW == 4 ? wave : 0;                                   // which tile of the workgroup
     const int tid = TPW == 4 ? lane : (int)threadIdx.x;                    // thread within the tile's staging group
-    unsigned char* Kimg = nl + BT_ROWS * BT_COLS * 4 + sub * 2 * IMG;
+    unsigned char* Kimg = nl + 2 * BT_ROWS * BT_COLS * 4 + sub * 2 * IMG;
     unsigned char* Vimg = Kimg + IMG;
     // XCD-aware order: workgroups w and w + 8 share an L2; give each XCD a contiguous run of (tile, head) pairs with the head
     // fastest — the heads of a token share its 128-byte lines (two heads per line of q, k and v), neighbouring tiles share halos
@@ -71,7 +74,8 @@ __global__ __launch_bounds__(RT == 16 ? 512 : 256) void na2d_mfma_kernel(const _
     wg /= heads;
     for (int t = threadIdx.x; t < BT_ROWS * BT_COLS; t += NTHR) {
         const int a = t / BT_COLS, b = t - a * BT_COLS;
-        BT[t] = (a < 13 && b < 13) ? rpb[(size_t)h * 169 + a * 13 + b] * 1.4426950408889634f : 0.f;    // in base-2 units
+        BT[t] = (a < 13 && b < 13) ? rpb[(size_t)h * 169 + a * 13 + b] / scale : 0.f;
+        BTM[t] = (a >= MN && a <= 3 * MN && b >= MN && b <= 3 * MN) ? rpb[(size_t)h * 169 + a * 13 + b] / scale : -1.0e30f;
     }
     const int gtile = min(wg * TPW + sub, total_tiles - 1);                // surplus waves redo the last tile and store nothing
     const bool live = wg * TPW + sub < total_tiles;
@@ -157,44 +161,50 @@ __global__ __launch_bounds__(RT == 16 ? 512 : 256) void na2d_mfma_kernel(const _
         // 8g .. 8g+7; the 40 bias values of this lane), then S^T: key tile t = halo row ro + t, slots co .. co + 15
         f32x4 sacc[HR];
         bf16x8 kf[HR];
-        float bv[HR][4];
         const unsigned char* kb = Kimg + ((ro * PC) + co + j) * KB + g * 16;
-        const float* bt = BT + (r0 - uc + MK - 1) * BT_COLS + (c0 + 4 * g - vc + MK - 1);
+        // The relative position bias enters as the MFMA's INITIAL ACCUMULATOR, in the units of the raw product (rpb / scale; the logit
+        // is (q.k + b) * scale * log2 e): S' = K Q^T + b comes out of the matrix pipe, no multiply-add per logit.  A block none of whose
+        // 16 queries has its window clamped by the border (wave-uniform; 3/4 of the blocks of a 64 x 64 map) takes the table whose
+        // entries outside the centred 7 x 7 window are -1e30: bias and window mask are then one function of the key's offset from the
+        // query and the row / column window tests and selects — a quarter of this kernel's VALU work — do not exist for it.
+        const bool interior = ti0 >= MN && ti0 + TQ - 1 + MN <= hs - 1 && tj0 >= MN && tj0 + TQ - 1 + MN <= ws - 1 &&
+                              ti0 + TQ <= hq && tj0 + TQ <= wq;
+        const float* bt = (interior ? BTM : BT) + (r0 - uc + MK - 1) * BT_COLS + (c0 + 4 * g - vc + MK - 1);
 #pragma unroll
         for (int t = 0; t < HR; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(kb + t * PC * KB);
 #pragma unroll
-        for (int t = 0; t < HR; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[t][r] = bt[t * BT_COLS + r];
+        for (int t = 0; t < HR; ++t) sacc[t] = f32x4{bt[t * BT_COLS], bt[t * BT_COLS + 1], bt[t * BT_COLS + 2], bt[t * BT_COLS + 3]};
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < HR; ++t) sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        // mask, bias, max.  Lane (j, g) holds, per tile t, keys (row r0 + t, column c0 + 4g + r), r = 0 .. 3, of query j
-        uint32_t rowmask = 0;
+        for (int t = 0; t < HR; ++t) sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, sacc[t], 0, 0, 0);
+        if (!interior) {
+            // window mask.  Lane (j, g) holds, per tile t, keys (row r0 + t, column c0 + 4g + r), r = 0 .. 3, of query j
+            uint32_t rowmask = 0;
 #pragma unroll
-        for (int t = 0; t < HR; ++t) rowmask |= (uint32_t)((r0 + t >= wi) && (r0 + t <= wi + MK - 1)) << t;
-        uint32_t csel[4];
+            for (int t = 0; t < HR; ++t) rowmask |= (uint32_t)((r0 + t >= wi) && (r0 + t <= wi + MK - 1)) << t;
+            uint32_t csel[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int cx = c0 + 4 * g + r; csel[r] = (cx >= wj && cx <= wj + MK - 1) ? 0xffffffffu : 0u; }
-        float mx = NEG;
+            for (int r = 0; r < 4; ++r) { const int cx = c0 + 4 * g + r; csel[r] = (cx >= wj && cx <= wj + MK - 1) ? 0xffffffffu : 0u; }
 #pragma unroll
-        for (int t = 0; t < HR; ++t) {
-            const uint32_t rsel = 0u - ((rowmask >> t) & 1u);              // all ones when halo row t is in this query's window
+            for (int t = 0; t < HR; ++t) {
+                const uint32_t rsel = 0u - ((rowmask >> t) & 1u);          // all ones when halo row t is in this query's window
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float x = __builtin_fmaf(sacc[t][r], sl2, bv[t][r]);  // logit in base-2 units (the bias table is pre-scaled)
-                const uint32_t m = rsel & csel[r];
-                const float xm = __uint_as_float((__float_as_uint(x) & m) | (__float_as_uint(NEG) & ~m));
-                sacc[t][r] = xm;
-                mx = fmaxf(mx, xm);
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t m = rsel & csel[r];
+                    sacc[t][r] = __uint_as_float((__float_as_uint(sacc[t][r]) & m) | (__float_as_uint(NEG) & ~m));
+                }
             }
         }
+        float mx = NEG;
+#pragma unroll
+        for (int t = 0; t < HR; ++t) mx = fmaxf(mx, fmaxf(fmaxf(sacc[t][0], sacc[t][1]), fmaxf(sacc[t][2], sacc[t][3])));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nm = -mx * sl2;                                        // p = 2^((S' - max) * scale * log2 e): one multiply-add per logit
 #pragma unroll
         for (int t = 0; t < HR; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sacc[t][r] = __builtin_amdgcn_exp2f(sacc[t][r] - mx);
+            for (int r = 0; r < 4; ++r) sacc[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[t][r], sl2, nm));
 
         // O^T = V^T . P^T over 5 k-steps of 32 slots = key tiles (2ks, 2ks+1)
         // The softmax denominator comes out of the matrix pipe too: a third product per k-step with an all-ones A operand sums the
@@ -246,7 +256,7 @@ static int launch_rt(const void* qkv, const void* pad_kv, const float* rpb, void
     const int tiles_y = (hq + RT - 1) / RT, tiles_x = (wq + RT - 1) / RT;
     const long long total = (long long)tiles_y * tiles_x * B * dil * dil;
     if (total >= (1LL << 31) - 8) return -1;
-    const size_t lds = (size_t)BT_ROWS * BT_COLS * 4 + (size_t)TPW * 2 * (RT + 6) * (RT + 12) * KB;
+    const size_t lds = (size_t)2 * BT_ROWS * BT_COLS * 4 + (size_t)TPW * 2 * (RT + 6) * (RT + 12) * KB;
     static std::atomic<int> attr{0};
     if (!attr.load()) {
         const hipError_t e = hipFuncSetAttribute((const void*)na2d_mfma_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -11,6 +11,9 @@ shapes = []   # (side, C, heads, dilation)
 for side, C, heads, dils in ((64, 128, 4, (1, 16)), (32, 256, 8, (1, 4, 8)), (16, 512, 16, (1, 2, 3, 4)), (8, 1024, 32, (1, 2))):
     for d in dils:
         shapes.append((side, C, heads, d))
+if os.environ.get("NA_SHAPE"):                               # "side,dilation": one shape only (counter passes)
+    want = tuple(int(v) for v in os.environ["NA_SHAPE"].split(","))
+    shapes = [sh for sh in shapes if (sh[0], sh[3]) == want]
 for side, C, heads, d in shapes:
     pad = max(side, 7 * d)
     qkv = torch.randn(B, side, side, 3 * C, device=dev, dtype=torch.bfloat16)     # real tokens; the pad is virtual (as the module runs it)
