@@ -133,7 +133,9 @@ __global__ __launch_bounds__(RT == 16 ? 512 : 256, RT == 16 ? 4 : 2) void na2d_m
             const int p = it * NT + tid;
             if (p < PIECES) {
                 *reinterpret_cast<uint4*>(Kimg + (p >> 2) * KB + chunk * 16) = kq[it];
-                *reinterpret_cast<uint4*>(Vimg + (p >> 2) * KB + chunk * 16) = vq[it];
+                // V rows are stored with their 32-byte halves swapped on every other group of 4 slots: the transposed reads below
+                // take 8 bytes per lane from 16 slots at a 64-byte pitch, and slots s and s + 4 would meet in the same banks
+                *reinterpret_cast<uint4*>(Vimg + (p >> 2) * KB + ((chunk ^ (((p >> 4) & 1) << 1)) * 16)) = vq[it];
             }
         }
     }
@@ -212,15 +214,18 @@ __global__ __launch_bounds__(RT == 16 ? 512 : 256, RT == 16 ? 4 : 2) void na2d_m
         // its column — 5 MFMAs on an idle pipe instead of 40 adds and two cross-lane exchanges on the VALU, which is this kernel's limit.
         f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, lacc = {0.f, 0.f, 0.f, 0.f};
         const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
-        const unsigned char* vb = Vimg + ((ro * PC) + co + 4 * g + q4) * KB + 8 * p4;
+        const int vslot = (ro * PC) + co + 4 * g + q4;
+        const int vsw = (vslot >> 2) & 1;                                  // this lane's slots of the even halo rows are stored half-swapped
+        constexpr int VFLIP = (PC >> 2) & 1;                               // ... and those of the odd rows the other way round (PC / 4 odd)
+        const unsigned char* vb = Vimg + vslot * KB + 8 * p4;
+        const unsigned char* vbc[2] = {vb + vsw * 32, vb + (vsw ^ 1) * 32};
         s16x4 vlo[HR / 2][2], vhi[HR / 2][2];
 #pragma unroll
         for (int ks = 0; ks < HR / 2; ++ks)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
-                const unsigned char* va = vb + (2 * ks) * PC * KB + cb * 32;
-                vlo[ks][cb] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va));
-                vhi[ks][cb] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(va + PC * KB));
+                vlo[ks][cb] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vbc[cb] + (2 * ks) * PC * KB));
+                vhi[ks][cb] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vbc[cb ^ VFLIP] + (2 * ks + 1) * PC * KB));
             }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
