@@ -24,8 +24,9 @@ for B in [int(a) for a in sys.argv[1:]] or [1, 4, 16, 64, 256]:
     obs, n_obs = mb.obstacles[:B].contiguous(), mb.n_obstacles[:B, 0].contiguous()
     ridge = ridge_all[:B].contiguous()
 
-    def eager():
-        return model.plan_tail(ridge if True else model.heatmap(model.segment_u8(g)), init, end, obs, n_obs), model.heatmap(model.segment_u8(g))
+    def eager():                                        # the captured body: both networks on the grids, the tail on the ridge maps
+        heat = model.heatmap(model.segment_u8(g))
+        return model.plan_tail(ridge, init, end, obs, n_obs), heat
     cp = model.capture(g, init, end, obs, n_obs, tail_heat=ridge)
     n = 20 if B <= 64 else 5
     out = []
