@@ -15,6 +15,11 @@
 #include <cstdlib>
 #include "ppn_device.h"
 #include "ppn_kernels.h"
+// The library is built with -ffp-contract=off because the generator kernels promise unfused IEEE double arithmetic (the parity
+// contract with the oracle).  This file holds network arithmetic checked against float32 / float64 references to a tolerance:
+// here a * b + c is one v_fma (otherwise every multiply-add of the LayerNorm, the GELU polynomial and the per-token linear
+// phases is two instructions — these kernels are VALU-bound).
+#pragma clang fp contract(fast)
 
 namespace ppn {
 

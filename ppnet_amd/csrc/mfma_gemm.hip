@@ -1,6 +1,11 @@
 // mfma_gemm.hip — launchers of the bf16 MFMA GEMM core (mfma_gemm.h): the implicit-GEMM 3x3 convolutions of the SETR-UP head
 // and the NAT downsamplers (reference SegNet/mmseg/decode_heads/setr_up_head.py:53-66, SegNet/nat.py:48-59), and the dense
 // projection form (SegNet/nat.py:62-85,111-120).
+// The library is built with -ffp-contract=off because the generator kernels promise unfused IEEE double arithmetic (the parity
+// contract with the oracle).  This file holds network arithmetic checked against float32 / float64 references to a tolerance:
+// here a * b + c is one v_fma (otherwise every multiply-add of the LayerNorm, the GELU polynomial and the per-token linear
+// phases is two instructions — these kernels are VALU-bound).
+#pragma clang fp contract(fast)
 #include "ppn_kernels.h"
 #include "mfma_gemm.h"
 
