@@ -392,11 +392,15 @@ int ppn_tokenizer_codes_bf16(const uint8_t* grid, const void* lut, const void* w
  *   ppn_nat128_ln_qkv_bf16:  qkv[tokens][384] = LN(s + offset) . w[384][128]^T + bias     (norm1 -> attn.qkv; offset, bias may be NULL)
  *   ppn_nat128_ln_mlp_bf16:  s[tokens][128] += GELU(LN(s + offset) . w1[256][128]^T + b1) . w2[128][256]^T   in place
  *                            (norm2 -> mlp.fc1 -> erf GELU -> mlp.fc2 -> residual; fc2's bias is carried by the caller's offset)
+ *   ppn_nat128_ln_mlp_add_bf16: the same with final_add [128] float32 (may be NULL) added to the result — the last layer of a level
+ *                            gives the residual stream its accumulated constant back here instead of in a separate pass over the tensor
  * offset [128] float32 is the constant part of the residual stream carried outside the tensor (ppn_layernorm_offset). */
 int ppn_nat128_ln_qkv_bf16(const void* s, const float* offset, const void* ln_w, const void* ln_b, const void* w, const void* bias, void* qkv,
                            int64_t tokens, float eps, void* stream);
 int ppn_nat128_ln_mlp_bf16(void* s, const float* offset, const void* ln_w, const void* ln_b, const void* w1, const void* b1, const void* w2,
                            int64_t tokens, float eps, void* stream);
+int ppn_nat128_ln_mlp_add_bf16(void* s, const float* offset, const void* ln_w, const void* ln_b, const void* w1, const void* b1, const void* w2,
+                               const float* final_add, int64_t tokens, float eps, void* stream);
 /* Dense projection c[M][N] = epilogue(a[M][K] . w[N][K]^T) on bfloat16 (torch.nn.Linear layout; SegNet/nat.py:62-85,111-120).
  * epilogue: 0 = + bias[n]; 1 = gelu(+ bias[n]) (erf form); 2 = c += (the residual stream accumulates, bias unused).
  * K % 64 == 0, K >= 128, N % 8 == 0.  persistent_blocks: 0 = one tile per workgroup; else the number of workgroups (a multiple

@@ -540,13 +540,18 @@ int ppn_nat128_ln_qkv_bf16(const void* s, const float* offset, const void* ln_w,
     return PPN_OK;
 }
 
-int ppn_nat128_ln_mlp_bf16(void* s, const float* offset, const void* ln_w, const void* ln_b, const void* w1, const void* b1, const void* w2,
-                           int64_t tokens, float eps, void* stream) {
+int ppn_nat128_ln_mlp_add_bf16(void* s, const float* offset, const void* ln_w, const void* ln_b, const void* w1, const void* b1, const void* w2,
+                               const float* final_add, int64_t tokens, float eps, void* stream) {
     if (!s || !ln_w || !ln_b || !w1 || !b1 || !w2 || tokens <= 0) return PPN_E_INVALID;
     if (tokens % 16) return PPN_E_UNSUPPORTED;
-    const int e = ppn::nat128_ln_mlp_launch(s, offset, ln_w, ln_b, w1, b1, w2, tokens, eps, (hipStream_t)stream);
+    const int e = ppn::nat128_ln_mlp_launch(s, offset, ln_w, ln_b, w1, b1, w2, final_add, tokens, eps, (hipStream_t)stream);
     if (e != 0) return hip_fail((hipError_t)e);
     return PPN_OK;
+}
+
+int ppn_nat128_ln_mlp_bf16(void* s, const float* offset, const void* ln_w, const void* ln_b, const void* w1, const void* b1, const void* w2,
+                           int64_t tokens, float eps, void* stream) {
+    return ppn_nat128_ln_mlp_add_bf16(s, offset, ln_w, ln_b, w1, b1, w2, nullptr, tokens, eps, stream);
 }
 
 int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int32_t N, int32_t K, int32_t epilogue,

@@ -162,17 +162,20 @@ __global__ __launch_bounds__(NAT128_THREADS, 1) void nat128_ln_qkv_kernel(const 
 
 // ---- LN -> fc1 -> GELU -> fc2 -> residual --------------------------------------------------------------------------
 constexpr int MLP_H = 256;
-constexpr int MLP_LDS = MLP_H * 256 + C128 * 512 + MLP_H * 4 + 3 * 128 * 4;
+constexpr int MLP_LDS = MLP_H * 256 + C128 * 512 + MLP_H * 4 + 3 * 128 * 4 + C128 * 4;
 
 __global__ __launch_bounds__(NAT128_THREADS, 1) void nat128_ln_mlp_kernel(__hip_bfloat16* __restrict__ s, const float* __restrict__ off,
                                                                           const __hip_bfloat16* __restrict__ lnw, const __hip_bfloat16* __restrict__ lnb,
                                                                           const __hip_bfloat16* __restrict__ w1, const __hip_bfloat16* __restrict__ b1,
-                                                                          const __hip_bfloat16* __restrict__ w2, long long groups, float eps) {
+                                                                          const __hip_bfloat16* __restrict__ w2, const float* __restrict__ add,
+                                                                          long long groups, float eps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* w1l = lds;                                  // [256 hidden][16 chunks]
     unsigned char* w2l = lds + MLP_H * 256;                    // [128 rows = (tile, row)][32 chunks]
     float* b1l = reinterpret_cast<float*>(w2l + C128 * 512);
     float* ln = b1l + MLP_H;
+    float* addl = ln + 3 * 128;                                // [tile][row]: the per-channel constant the result starts from (or zeros)
+    for (int i = threadIdx.x; i < C128; i += NAT128_THREADS) addl[i] = add ? add[out_channel(i >> 4, i & 15)] : 0.0f;
     stage_k128(w1l, w1, MLP_H, [](int r) { return r; });
     // fc2's k-slot (ks2, g, e) is hidden unit (2 ks2 + (e >> 2)) * 16 + 4g + (e & 3) — the order GELU(fc1) comes out of the
     // matrix pipe in: chunk ks2 * 4 + g of a row is two 8-byte pieces of the source row
@@ -191,9 +194,9 @@ __global__ __launch_bounds__(NAT128_THREADS, 1) void nat128_ln_mlp_kernel(__hip_
         const long long tok0 = grp * 16;
         bf16x8 yf[4];
         ln_tokens(s, tok0, lane, ln, eps, yf);
-        f32x4 acc[8];
+        f32x4 acc[8];                                                // starts from `add` (the level's accumulated biases, last layer) or 0
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 8; ++t) acc[t] = *reinterpret_cast<const f32x4*>(addl + t * 16 + 4 * g);
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             bf16x8 hf[4];
@@ -257,8 +260,8 @@ int nat128_ln_qkv_launch(const void* s, const float* off, const void* lnw, const
     return (int)hipGetLastError();
 }
 
-int nat128_ln_mlp_launch(void* s, const float* off, const void* lnw, const void* lnb, const void* w1, const void* b1, const void* w2, long long tokens,
-                         float eps, hipStream_t stream) {
+int nat128_ln_mlp_launch(void* s, const float* off, const void* lnw, const void* lnb, const void* w1, const void* b1, const void* w2, const float* add,
+                         long long tokens, float eps, hipStream_t stream) {
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)nat128_ln_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS) != hipSuccess) return (int)hipGetLastError();
@@ -267,7 +270,7 @@ int nat128_ln_mlp_launch(void* s, const float* off, const void* lnw, const void*
     const long long groups = tokens / 16;
     hipLaunchKernelGGL(nat128_ln_mlp_kernel, dim3(blocks_for(groups)), dim3(NAT128_THREADS), MLP_LDS, stream, (__hip_bfloat16*)s, off,
                        (const __hip_bfloat16*)lnw, (const __hip_bfloat16*)lnb, (const __hip_bfloat16*)w1, (const __hip_bfloat16*)b1, (const __hip_bfloat16*)w2,
-                       groups, eps);
+                       add, groups, eps);
     return (int)hipGetLastError();
 }
 

@@ -102,8 +102,8 @@ int tokenizer_fused_launch(const uint8_t* grid, const void* lut, const void* w2p
 int tokenizer_codes_launch(const uint8_t* grid, const void* lut, void* out, int B, int H, int W, hipStream_t stream);
 int nat128_ln_qkv_launch(const void* s, const float* off, const void* lnw, const void* lnb, const void* w, const void* bias, void* qkv, long long tokens,
                          float eps, hipStream_t stream);
-int nat128_ln_mlp_launch(void* s, const float* off, const void* lnw, const void* lnb, const void* w1, const void* b1, const void* w2, long long tokens,
-                         float eps, hipStream_t stream);
+int nat128_ln_mlp_launch(void* s, const float* off, const void* lnw, const void* lnb, const void* w1, const void* b1, const void* w2, const float* add,
+                         long long tokens, float eps, hipStream_t stream);
 int gennet_trunk_launch(const void* x, void* y, const float* params, int B, int N, int n_blocks, hipStream_t stream);
 int gemm_mfma_launch(const void* a, const void* w, const float* bias, void* c, long long M, int N, int K, int epi, int persistent,
                      hipStream_t stream);

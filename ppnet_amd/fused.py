@@ -391,18 +391,21 @@ def nat128_ln_qkv(s, offset, ln, qkv_linear):
     return out
 
 
-def nat128_ln_mlp_(s, offset, ln, fc1, fc2):
-    """s += fc2.weight @ gelu(fc1(ln(s + offset))) in place, ONE kernel (ppn_nat128_ln_mlp_bf16): the hidden activations
-    never reach HBM.  fc2's bias is NOT added (the folded layer carries it in the next offset)."""
+def nat128_ln_mlp_(s, offset, ln, fc1, fc2, final_add=None):
+    """s += fc2.weight @ gelu(fc1(ln(s + offset))) (+ final_add) in place, ONE kernel (ppn_nat128_ln_mlp_add_bf16): the hidden
+    activations never reach HBM.  fc2's bias is NOT added (the folded layer carries it in the next offset); final_add [128]
+    float32: a per-channel constant added to the result (the level's accumulated biases, on its last layer)."""
     lw, lb = _nat128_args(s, offset, ln)
     w1, w2 = fc1.weight.detach(), fc2.weight.detach()
     assert w1.shape == (256, 128) and w2.shape == (128, 256) and w1.dtype == w2.dtype == torch.bfloat16
     assert w1.is_contiguous() and w2.is_contiguous()
     with torch.cuda.device(s.device):
-        rc = L.lib.ppn_nat128_ln_mlp_bf16(_p(s), _p(offset) if offset is not None else None, _p(lw), _p(lb), _p(w1), _p(fc1.bias.detach()),
-                                          _p(w2), s.numel() // 128, float(ln.eps),
-                                          ctypes.c_void_p(torch.cuda.current_stream(s.device).cuda_stream))
-    L.check(rc, "ppn_nat128_ln_mlp_bf16")
+        if final_add is not None:
+            assert final_add.dtype == torch.float32 and final_add.is_contiguous() and final_add.numel() == 128 and final_add.device == s.device
+        rc = L.lib.ppn_nat128_ln_mlp_add_bf16(_p(s), _p(offset) if offset is not None else None, _p(lw), _p(lb), _p(w1), _p(fc1.bias.detach()),
+                                              _p(w2), _p(final_add), s.numel() // 128, float(ln.eps),
+                                              ctypes.c_void_p(torch.cuda.current_stream(s.device).cuda_stream))
+    L.check(rc, "ppn_nat128_ln_mlp_add_bf16")
     return s
 
 

@@ -51,9 +51,12 @@ class PPNet(torch.nn.Module):
         the GEMM / conv / attention kernels, fp32 statistics inside LayerNorm); amp_dtype=bfloat16 with
         weights_dtype=None keeps fp32 weights under autocast; both None = fp32 everywhere."""
         super().__init__()
-        # exhaustive MIOpen search for the few convolution shapes of the two networks (a one-off at the first batch):
-        # measured 64 -> 57 ms per 256-problem batch against the default heuristic pick
-        torch.backends.cudnn.benchmark = True
+        # float32 weights keep the library convolutions on the path: exhaustive MIOpen search for their few shapes (a one-off at the
+        # first batch; measured 64 -> 57 ms per 256-problem batch against the heuristic pick).  The bfloat16 default runs no library
+        # convolution at all, and the flag is process-global (it would also send a later training step's backward convolutions through
+        # the search), so it is not touched there.
+        if weights_dtype is None:
+            torch.backends.cudnn.benchmark = True
         _use_tuned_gemms()
         self.resolution = resolution
         self.segnet = segnet if segnet is not None else SegNet()

@@ -143,23 +143,26 @@ class NATLayer(nn.Module):
     folded = False        # set by NATBlock.fold(): LayerScale in the projection weights, biases carried as offsets
     _c = _c_dev = None
 
-    def _forward_folded(self, s, y, next_norm):
-        """s: the residual stream minus the level's accumulated projection biases (see _fold_doc); y = norm1(s + c_in)."""
+    def _forward_folded(self, s, y, next_norm, restore=False):
+        """s: the residual stream minus the level's accumulated projection biases (see _fold_doc); y = norm1(s + c_in).
+        restore (the level's last layer): the returned stream is the TRUE one, s + c_out — where the layer's own kernel can add the
+        constant in its epilogue (the 128-channel streaming form) it does, and reports so by the third return value."""
         C = s.shape[-1]
         c_in, c_mid, c_out = self.offsets(s.device)
         if self._streams_c128(s):
             # 128-channel level: LN -> qkv and LN -> MLP -> residual are one token-streaming kernel each (weights in LDS)
             qkv = fused.nat128_ln_qkv(s, c_in, self.norm1, self.attn.qkv)
             s.view(-1, C).addmm_(self.attn.attend(s, qkv=qkv).view(-1, C), self.attn.proj.weight.t())
-            fused.nat128_ln_mlp_(s, c_mid, self.norm2, self.mlp.fc1, self.mlp.fc2)
-            return s, (fused.layer_norm(s, next_norm, offset=c_out) if next_norm is not None else None)
+            fused.nat128_ln_mlp_(s, c_mid, self.norm2, self.mlp.fc1, self.mlp.fc2, final_add=c_out if restore else None)
+            off = None if restore else c_out
+            return s, (fused.layer_norm(s, next_norm, offset=off) if next_norm is not None else None), restore
         if y is None:
             y = fused.layer_norm(s, self.norm1, offset=c_in)
         s2 = s.view(-1, C)
         s2.addmm_(self.attn.attend(y).view(-1, C), self.attn.proj.weight.t())          # s += o W'^T  (bias in c_mid)
         y2 = fused.layer_norm(s, self.norm2, offset=c_mid)
         s2.addmm_(self.mlp.hidden(y2), self.mlp.fc2.weight.t())                        # s += h W2'^T (bias in c_out)
-        return s, (fused.layer_norm(s, next_norm, offset=c_out) if next_norm is not None else None)
+        return s, (fused.layer_norm(s, next_norm, offset=c_out) if next_norm is not None else None), False
 
     def _streams_c128(self, s):
         return (s.shape[-1] == 128 and s.is_cuda and s.dtype == torch.bfloat16 and (s.numel() // 128) % 16 == 0
@@ -180,7 +183,7 @@ class NATLayer(nn.Module):
         Residual add, LayerScale and the following LayerNorm are one fused kernel each (DropPath is the identity
         at inference, nat.py:140-153)."""
         if self.folded:
-            return self._forward_folded(x, y, next_norm)
+            return self._forward_folded(x, y, next_norm)[:2]
         hw = (x.shape[1], x.shape[2])
         if y is None:
             y = fused.layer_norm(x, self.norm1)
@@ -223,12 +226,14 @@ class NATBlock(nn.Module):
             if i + 1 < n:
                 nxt = self.blocks[i + 1]
                 x, y = blk(x, y, None if (nxt.folded and nxt._streams_c128(x)) else nxt.norm1, None)
+            elif blk.folded:
+                # x is s = x_true - c: the true stream is read itself by the downsampler (or returned when there is no output norm)
+                want = self.downsample is not None or out_norm is None
+                x, y, restored = blk._forward_folded(x, y, out_norm, restore=want)
+                if want and not restored:
+                    x = fused.bias_act_(x.permute(0, 3, 1, 2), blk.offsets(x.device)[2], 1.0).permute(0, 2, 3, 1)
             else:
                 x, y = blk(x, y, out_norm, None)
-        if self.blocks[0].folded:                      # x is s = x_true - c: give the true stream back where it is read itself
-            c = self.blocks[-1].offsets(x.device)[2]
-            if self.downsample is not None or out_norm is None:
-                x = fused.bias_act_(x.permute(0, 3, 1, 2), c, 1.0).permute(0, 2, 3, 1)
         xo = y if out_norm is not None else x
         return (x, xo) if self.downsample is None else (self.downsample(x), xo)
 

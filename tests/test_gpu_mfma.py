@@ -186,6 +186,12 @@ def test_nat128_streaming_kernels_vs_float64(tokens):
     for got, want, name in ((got_qkv, want_qkv, "qkv"), (s2, want_s, "mlp")):
         err = (got.double() - want).abs()
         assert float(err.max()) < 0.06 and float(err.mean()) < 6e-3, (name, float(err.max()), float(err.mean()))
+    # the last layer of a level: a per-channel constant added in the epilogue (ppn_nat128_ln_mlp_add_bf16)
+    add = (0.7 * torch.randn(128, generator=g)).cuda()
+    s3 = s.clone()
+    fused.nat128_ln_mlp_(s3, off, ln, fc1, fc2, final_add=add)
+    err = (s3.double() - (want_s + d(add))).abs()
+    assert float(err.max()) < 0.06 and float(err.mean()) < 6e-3, ("mlp + add", float(err.max()), float(err.mean()))
     # no offset / no bias forms
     got0 = fused.nat128_ln_qkv(s, None, ln, qkv)
     y0 = torch.nn.functional.layer_norm(d(s), (128,), d(ln.weight), d(ln.bias), ln.eps)
