@@ -78,10 +78,13 @@ def test_resize_matches_pillow(dev):
     from PIL import Image
     from ppnet_amd import plan
     rng = np.random.RandomState(1)
-    for (h, w, oh, ow) in [(224, 224, 112, 112), (256, 256, 128, 128), (64, 96, 16, 48), (50, 70, 25, 35), (33, 47, 11, 15)]:
-        a = rng.randint(0, 256, size=(3, h, w)).astype(np.uint8)
+    # rate 2 (the pipeline's), 3, 4 (9 taps: the kernel's per-output fallback), 8 (the reference's default), up-sampling, and a batch
+    # longer than the 16 lines / images a thread walks with one set of weights
+    for (h, w, oh, ow, n) in [(224, 224, 112, 112, 3), (256, 256, 128, 128, 3), (64, 96, 16, 48, 3), (50, 70, 25, 35, 3), (33, 47, 11, 15, 3),
+                              (256, 256, 32, 32, 2), (24, 40, 48, 60, 2), (32, 32, 16, 16, 37)]:
+        a = rng.randint(0, 256, size=(n, h, w)).astype(np.uint8)
         got = plan.resize_bilinear_u8(torch.tensor(a, device=dev), oh, ow).cpu().numpy()
-        for i in range(3):
+        for i in range(n):
             want = np.asarray(Image.fromarray(a[i], mode="L").resize((ow, oh), Image.BILINEAR))
             assert np.array_equal(got[i], want)
 
