@@ -59,10 +59,36 @@ def _cpu_sample(args):
     return t1 - t0, t2 - t1, n_paths, len(maps)
 
 
+def usable_cores():
+    """Host cores this process may actually run on: the scheduler affinity mask, cut to the cgroup CPU quota when one is set
+    (a one-GPU box is a 16-core share of a 256-core host: os.cpu_count() alone overstates it)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(q / int(f.read().split()[0]) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline():
     """The CPU oracle (a NumPy port of the reference's algorithm) on a bounded sample of the same workload:
-    (a) one host core: 20 target paths x 100 placements at R=256, K=20 (~15 s); (b) all host cores: one worker process
-    per core (at most 32), 2 target paths x 100 placements each, wall-clock over the pool.  Reported, not a target."""
+    (a) one host core: 20 target paths x 100 placements at R=256, K=20 (~15 s); (b) all usable host cores (usable_cores():
+    affinity mask and cgroup quota; BENCH_CPU_WORKERS overrides): one worker process per core, 2 target paths x 100 placements
+    each, wall-clock over the pool, also stated per core.  Reported, not a target."""
     import multiprocessing as mp
     n_paths, placements = 20, 100
     ta, tb, _, n_maps = _cpu_sample((0, n_paths, placements))
@@ -71,10 +97,10 @@ def cpu_baseline():
     out = {"value": round(1.0 / per_inst, 3), "unit": "instances/s", "cores": 1, "kind": "port",
            "sample": f"oracle/edage_np.py: {n_paths} paths ({ta / n_paths * 1e3:.0f} ms each) + {n_maps} maps "
                      f"({tb / n_maps * 1e3:.1f} ms each) at R={R}, K={K}; stage A amortised over {PLACEMENTS} placements",
-           "host_cores": os.cpu_count()}
+           "host_cores": os.cpu_count(), "usable_cores": usable_cores()}
     try:
         from concurrent.futures import ProcessPoolExecutor
-        workers = max(1, min(32, os.cpu_count() or 1))
+        workers = max(1, int(os.environ.get("BENCH_CPU_WORKERS", "0")) or usable_cores())
         # spawn: the parent holds a HIP context and must never be forked; an executor (not mp.Pool) so that a worker that
         # dies raises instead of being respawned for ever; 2 paths per 200 maps = the GPU step's 1 path per PLACEMENTS maps
         with ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) as ex:
@@ -84,6 +110,7 @@ def cpu_baseline():
             wall = time.perf_counter() - t0
         inst = sum(p[3] for p in parts)
         out["all_cores"] = {"value": round(inst / wall, 2), "unit": "instances/s", "cores": workers,
+                            "per_core": round(inst / wall / workers, 2),
                             "sample": f"{workers} worker processes x (2 paths + {2 * placements} maps), {wall:.1f} s wall"}
     except Exception as e:                               # a reported extra: never fail the bench line over it
         out["all_cores"] = {"value": None, "error": repr(e)[:200]}
@@ -357,6 +384,8 @@ def main():
     ready = [None] * NPB          # paths of buffer b are complete
     consumed = [None] * NPB       # the maps kernel reading buffer b has finished
     launched = [-1]               # newest batch whose stage A has been launched
+    stage_a_evs = []              # (start, end) events around the sampled stage-A launches of the timed region, on their own streams
+    stage_a_on = [False]
 
     def launch_paths(it):
         """Stage A of path group `it` (the paths of steps it*GROUP .. it*GROUP + GROUP - 1)."""
@@ -365,6 +394,10 @@ def main():
         with torch.cuda.stream(sp):
             if consumed[b] is not None:
                 sp.wait_event(consumed[b])
+            ea = None
+            if stage_a_on[0] and it % TIMED_EVERY == 0:
+                ea = torch.cuda.Event(enable_timing=True)
+                ea.record(sp)
             if GROUP == 1:
                 first_path, _, _ = shard.local_ids(PATHS * world, PLACEMENTS, rank, world, batch_index=it)
                 edage.generate_paths(PATHS, R, MAP_SIZE, CLEARANCE, seed=SEED, first_path_id=first_path, device=dev, out=pbs[b])
@@ -374,8 +407,10 @@ def main():
                 # GROUP times as large — same streams for any N, every id used once
                 first_path, _, _ = shard.local_ids(PATHS * GROUP * world, PLACEMENTS, rank, world, batch_index=it)
                 edage.generate_paths(PATHS * GROUP, R, MAP_SIZE, CLEARANCE, seed=SEED, first_path_id=first_path, device=dev, out=pbs[b])
-            ready[b] = torch.cuda.Event()
+            ready[b] = torch.cuda.Event(enable_timing=ea is not None)
             ready[b].record(sp)
+            if ea is not None:
+                stage_a_evs.append((ea, ready[b]))
         launched[0] = it
     n_local = PATHS * PLACEMENTS
 
@@ -422,11 +457,27 @@ def main():
 
     for it in range(args.warmup):
         step(it)
+    # Clock-warm phase (untimed, reported): the identical step loop for a fixed wall time, independent of --warmup.  A step is
+    # 0.17-0.2 ms and the chip needs ~0.1 s of load to leave its idle clocks; without this a `--steps 20 --warmup 5` run (4 ms)
+    # measures the idle-clock kernel (profiles/r02_steps_sweep.txt).  The timed region below is exactly --steps steps.
+    warm_target_s = float(os.environ.get("BENCH_CLOCK_WARM_MS", "150")) * 1e-3
+    warm_steps = 0
+    torch.cuda.synchronize()
+    tw = time.perf_counter()
+    while time.perf_counter() - tw < warm_target_s:
+        for _ in range(25 * GROUP):
+            step(args.warmup + warm_steps)
+            warm_steps += 1
+        torch.cuda.synchronize()
+    clock_warm_ms = (time.perf_counter() - tw) * 1e3
+    first = args.warmup + warm_steps
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    stage_a_on[0] = True
     t0 = time.perf_counter()
-    evs = [step(args.warmup + it) for it in range(args.steps)]
+    evs = [step(first + it) for it in range(args.steps)]
+    stage_a_on[0] = False
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -438,7 +489,8 @@ def main():
 
     timed = [(a, b) for a, b in evs if a is not None]
     maps_kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / len(timed)
-    mb = mbs[(args.warmup + args.steps - 1) % NMB]     # the newest batch
+    mb = mbs[(first + args.steps - 1) % NMB]     # the newest batch
+    stage_a_ms = sum(a.elapsed_time(b) for a, b in stage_a_evs) / len(stage_a_evs) if stage_a_evs else None
     k_tot = float(mb.n_obstacles[:, 0].double().mean().item())
     k_pocket = float(pbs[0].n_obstacles.double().mean().item())
     placed = float(((mb.flags & 2) == 0).double().mean().item())
@@ -447,7 +499,7 @@ def main():
 
     ppnet = None
     if not args.no_ppnet:
-        last = args.warmup + args.steps - 1
+        last = first + args.steps - 1
         ppnet = ppnet_leg(torch, dev, pviews[(last // GROUP) % NPB][last % GROUP], mb, args.ppnet_batch, args.ppnet_steps, world, rank,
                           cpu_leg=(world == 1 and not args.no_cpu_baseline))
     if rank == 0:
@@ -460,6 +512,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "clock_warm_ms": round(clock_warm_ms, 1), "clock_warm_steps": warm_steps,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -474,6 +527,14 @@ def main():
                          "kernel_ms": round(maps_kernel_ms, 4), "timed_launches": len(timed), "units_per_launch": n_local,
                          "algorithmic_bytes_per_map": round(algorithmic_bytes_per_map(k_tot, k_pocket), 1),
                          "survey_bytes_per_map": round(2 * R * R + 16384 + 12.0 * k_tot, 1)},
+            # stage A paths/s, stage B maps/s (each kernel's own launch time by events on its stream, while
+            # the other stage runs beside it) and the end-to-end figure (`value`)
+            "stage_a": {"kernel": "edage_paths_kernel", "kernel_ms": round(stage_a_ms, 4) if stage_a_ms else None,
+                        "paths_per_launch": PATHS * GROUP, "timed_launches": len(stage_a_evs),
+                        "paths_per_s": round(PATHS * GROUP / (stage_a_ms * 1e-3), 1) if stage_a_ms else None,
+                        "note": "a latency chain, one workgroup per path, in flight beside stage B on its own streams"},
+            "stage_b": {"kernel": "edage_maps_kernel_t<3>", "kernel_ms": round(maps_kernel_ms, 4),
+                        "maps_per_s": round(n_local / (maps_kernel_ms * 1e-3), 1)},
             "placement_success": round(placed, 4),
             "mean_obstacles_per_map": round(k_tot, 2),
         }

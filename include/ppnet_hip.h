@@ -126,6 +126,17 @@ int ppn_edage_paths_ex(int32_t n_paths, uint64_t first_path_id, int32_t R, doubl
                        const double* draws, const float* pocket_draws, int32_t pocket_stride,
                        const int8_t* force_straight, const ppn_paths_t* out, void* stream);
 
+/* Same, with the hull's first vertex supplied by the caller: hull_start[n] int32 = index into the canonical vertex cycle
+ * (lexicographically smallest lattice point first, counter-clockwise) at which the cycle is to begin, -1 = canonical; may be
+ * NULL.  scipy.spatial.ConvexHull (Qhull, Path.py:392-393) returns the same cycle from an implementation-defined start, and
+ * Path.search_isle / Path.set_obstacles (Path.py:463-537) walk the hull edges — and draw torch.rand — in that order: a caller
+ * that replays the reference's random streams computes Qhull's start on the host and passes it here (dropin/Path.py). */
+int ppn_edage_paths_ex2(int32_t n_paths, uint64_t first_path_id, int32_t R, double map_size,
+                        double clearance, uint64_t seed,
+                        const double* draws, const float* pocket_draws, int32_t pocket_stride,
+                        const int8_t* force_straight, const int32_t* hull_start,
+                        const ppn_paths_t* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Stage B — maps.  Replaces the body of MapGenerate.generate (MapGenerate.py:48-124) incl.
  * Path.boundary_check (Path.py:100-111), generate_map_randomly (MapGenerate.py:126-151), the

@@ -47,7 +47,7 @@ class MapsStruct(C.Structure):
 
 
 EXPORTS = ("ppn_version", "ppn_error_string", "ppn_last_hip_error", "ppn_polyfit_table", "ppn_edage_paths",
-           "ppn_edage_paths_ex", "ppn_edage_maps", "ppn_edage_maps_place", "ppn_edage_maps_raster",
+           "ppn_edage_paths_ex", "ppn_edage_paths_ex2", "ppn_edage_maps", "ppn_edage_maps_place", "ppn_edage_maps_raster",
            "ppn_label_masks", "ppn_boundary_check", "ppn_boundary_check_ex",
            "ppn_obstacle_filter", "ppn_paint_markers", "ppn_disc_raster", "ppn_collision_segments", "ppn_collision_segments_bound",
            "ppn_extract_paths", "ppn_resize_bilinear_u8", "ppn_philox_doubles", "ppn_na2d_fwd", "ppn_na2d_fwd_padded", "ppn_na2d_fwd_vpad", "ppn_na2d_bwd", "ppn_residual_layernorm", "ppn_residual_layernorm_padded", "ppn_layernorm_offset", "ppn_upsample2x_nhwc", "ppn_upsample2x_nhwc_bias", "ppn_bias_act_nhwc", "ppn_seg_labels_2class", "ppn_grid_to_image", "ppn_conv3x3_c1_nhwc", "ppn_conv3x3_to1_nhwc",
@@ -71,6 +71,8 @@ def _load():
                                     _p, _p, C.c_int32, C.POINTER(PathsStruct), _p]
     lib.ppn_edage_paths_ex.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.c_double, C.c_double, C.c_uint64,
                                        _p, _p, C.c_int32, _p, C.POINTER(PathsStruct), _p]
+    lib.ppn_edage_paths_ex2.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.c_double, C.c_double, C.c_uint64,
+                                        _p, _p, C.c_int32, _p, _p, C.POINTER(PathsStruct), _p]
     lib.ppn_boundary_check_ex.argtypes = [_p, C.c_int32, _p, _p, C.c_int32, C.c_int32, _p, _p, _p]
     lib.ppn_obstacle_filter.argtypes = [_p, _p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
                                         _p, _p, _p, _p]

@@ -115,6 +115,13 @@ int ppn_edage_paths(int32_t n_paths, uint64_t first_path_id, int32_t R, double m
 int ppn_edage_paths_ex(int32_t n_paths, uint64_t first_path_id, int32_t R, double map_size, double clearance,
                        uint64_t seed, const double* draws, const float* pocket_draws, int32_t pocket_stride,
                        const int8_t* force_straight, const ppn_paths_t* out, void* stream) {
+    return ppn_edage_paths_ex2(n_paths, first_path_id, R, map_size, clearance, seed, draws, pocket_draws, pocket_stride,
+                               force_straight, nullptr, out, stream);
+}
+
+int ppn_edage_paths_ex2(int32_t n_paths, uint64_t first_path_id, int32_t R, double map_size, double clearance,
+                        uint64_t seed, const double* draws, const float* pocket_draws, int32_t pocket_stride,
+                        const int8_t* force_straight, const int32_t* hull_start, const ppn_paths_t* out, void* stream) {
     if (n_paths < 0 || bad_R(R) || !out || !(map_size > 0.0) || !(clearance > 0.0)) return PPN_E_INVALID;
     if (pocket_draws && pocket_stride <= 0) return PPN_E_INVALID;
     if (n_paths == 0) return PPN_OK;                           // an empty batch has no buffers to validate
@@ -137,6 +144,7 @@ int ppn_edage_paths_ex(int32_t n_paths, uint64_t first_path_id, int32_t R, doubl
     prm.pocket = pocket_draws;
     prm.pocket_stride = pocket_stride;
     prm.force_straight = force_straight;
+    prm.hull_start = hull_start;
     int rc = polyfit_table_device(&prm.W);
     if (rc != PPN_OK) return rc;
     const size_t lds = (size_t)PPN_PATH_POINTS * 24 + (size_t)(2 * R) * (2 * R) / 8;      // path points + lattice + canvas bits

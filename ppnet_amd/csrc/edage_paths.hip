@@ -417,6 +417,20 @@ __global__ __launch_bounds__(NT, PPN_PATHS_WAVES_PER_EU) void edage_paths_kernel
     const int hn = hull_meta[0];
     flags |= (uint32_t)hull_meta[1];
     __syncthreads();
+    // Reference vertex order (replay mode): Qhull starts the same CCW cycle at an implementation-defined vertex (Path.py:392-393),
+    // and search_isle / set_obstacles walk the edges — and consume torch.rand — in that order (Path.py:463-537).  The caller names
+    // the start as an index into the canonical cycle; everything downstream (ConvexHull, isles, pocket obstacles) follows.
+    {
+        const int hs_raw = prm.hull_start ? prm.hull_start[p] : -1;
+        const int hs = (hs_raw > 0 && hn > 0) ? hs_raw % hn : 0;                 // block-uniform
+        if (hs) {
+            int vx = 0, vy = 0;
+            if (tid < hn) { const int src = (tid + hs) % hn; vx = hull_i[src][0]; vy = hull_i[src][1]; }
+            __syncthreads();
+            if (tid < hn) { hull_i[tid][0] = vx; hull_i[tid][1] = vy; }
+            __syncthreads();
+        }
+    }
 
     PPN_PSTAMP(4);
     // ------------------------------------------------------------------ A6: normalisation

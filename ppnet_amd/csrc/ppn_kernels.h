@@ -23,6 +23,7 @@ struct PathsParams {
     int pocket_stride;
     const double* W;           // [4][1000] least-squares operator (device)
     const int8_t* force_straight;  // [n] or null
+    const int32_t* hull_start;     // [n] or null: first hull vertex as an index into the canonical cycle (-1 / null = canonical)
 };
 
 struct MapsParams {

@@ -42,6 +42,23 @@ def plot_obstacles(size: tuple, obstacles, resolution: tuple = (224, 224)):
     return (g == L.GRID_FREE).to(torch.float32).unsqueeze(0).expand(3, R, R).contiguous()
 
 
+def _qhull_start(pb, R, map_size):
+    """Index, in the stage-A kernel's canonical hull cycle (pb.hull_raw[0]: lexicographically smallest lattice point first,
+    counter-clockwise), of the vertex scipy.spatial.ConvexHull lists first for the same lattice points — Path.convexhull's
+    input and call (Path.py:388-395).  0 when Qhull's vertex set is not the kernel's (never seen; the canonical order then stays)."""
+    from scipy.spatial import ConvexHull
+    world = pb.pathpoint_world[0].cpu().numpy()
+    pts = np.round(world / (map_size / R) + R).astype(np.int64)               # coord_euclidean2image, Path.py:378-386
+    hn = int(pb.hull_n[0])
+    canon = np.rint(pb.hull_raw[0, :hn].cpu().numpy()).astype(np.int64)
+    try:
+        first = pts[ConvexHull(pts).vertices[0]]
+    except Exception:                                                          # degenerate input: Qhull raises, so does the reference
+        return 0
+    k = np.where((canon == first).all(axis=1))[0]
+    return int(k[0]) if len(k) == 1 else 0
+
+
 class Path:
     def __init__(self, seg_num=3, poly_order=3, dim=2, clearance=1, is_straight=True):
         self.device = torch.device(rng.device())
@@ -100,6 +117,7 @@ class Path:
             self._torch_state = torch.get_rng_state()
         force = torch.tensor([1 if self.is_straight else 0], dtype=torch.int8, device=self.device)
         n = 3 * L.POCKET_TRY_CAP
+        hull_start = None          # replay mode: Qhull's first vertex as an index into the kernel's canonical cycle, once known
         while True:
             pocket = None
             if mt_pocket:
@@ -107,10 +125,16 @@ class Path:
                 pocket = torch.tensor([[torch.rand(1).item() for _ in range(n)]], dtype=torch.float32, device=self.device)
             pb = edage.generate_paths(1, R, map_size, self.Clearance, seed=rng.seed(), first_path_id=self._path_id,
                                       device=self.device, draws=self._draws, pocket_draws=pocket, debug=True,
-                                      force_straight=force)
+                                      force_straight=force, hull_start=hull_start)
             torch.cuda.synchronize(self.device)
             if pocket is None:
                 return pb
+            if hull_start is None and not self.is_straight:
+                # set_obstacles consumes torch.rand isle by isle in the order of Qhull's vertex list (Path.py:388-395,463-537)
+                hs = _qhull_start(pb, R, map_size)
+                hull_start = torch.tensor([hs], dtype=torch.int32, device=self.device)
+                if hs > 0:
+                    continue                                     # same draws, the reference's vertex order
             used = int(pb.pocket_draws_used[0])
             if used <= n and not (int(pb.flags[0]) & L.FLAG_POCKET_DRAWS):
                 break

@@ -111,9 +111,11 @@ class MapsBatch:
 
 
 def generate_paths(n_paths, resolution=224, map_size=50, clearance=1, seed=0, first_path_id=0, device="cuda:0",
-                   draws=None, pocket_draws=None, debug=False, out=None, force_straight=None):
+                   draws=None, pocket_draws=None, debug=False, out=None, force_straight=None, hull_start=None):
     """Stage A for `n_paths` paths. draws / pocket_draws: optional device tensors that replace the
-    Philox streams ([n, 10021] float64 in the fixed layout; [n, stride] float32 in torch.rand order)."""
+    Philox streams ([n, 10021] float64 in the fixed layout; [n, stride] float32 in torch.rand order).
+    hull_start: optional int32 [n], the hull's first vertex as an index into the canonical cycle (-1 = canonical): the
+    reference's Qhull order, for callers that replay its torch.rand stream isle by isle (ppn_edage_paths_ex2)."""
     device = torch.device(device)
     pb = out if out is not None else PathsBatch(n_paths, resolution, map_size, clearance, device, debug=debug)
     stride = 0
@@ -124,10 +126,12 @@ def generate_paths(n_paths, resolution=224, map_size=50, clearance=1, seed=0, fi
         stride = pocket_draws.shape[1]
     if force_straight is not None:
         assert force_straight.dtype == torch.int8 and force_straight.is_contiguous() and force_straight.shape[0] == n_paths
+    if hull_start is not None:
+        assert hull_start.dtype == torch.int32 and hull_start.is_contiguous() and hull_start.shape[0] == n_paths and hull_start.is_cuda
     with torch.cuda.device(device):
-        rc = L.lib.ppn_edage_paths_ex(n_paths, first_path_id, resolution, float(map_size), float(clearance), seed,
-                                      _ptr(draws), _ptr(pocket_draws), stride, _ptr(force_straight),
-                                      C.byref(pb.struct), _stream_ptr(device))
+        rc = L.lib.ppn_edage_paths_ex2(n_paths, first_path_id, resolution, float(map_size), float(clearance), seed,
+                                       _ptr(draws), _ptr(pocket_draws), stride, _ptr(force_straight), _ptr(hull_start),
+                                       C.byref(pb.struct), _stream_ptr(device))
     L.check(rc, "ppn_edage_paths")
     return pb
 

@@ -5,8 +5,9 @@
     feeds the draws to the kernels, so `np.random.seed(s); torch.manual_seed(s)` scripts keep their meaning.
     The torch stream also advances by the one draw torchvision 0.12's `RandomRotation` takes per path
     (Path.py:160-161) and per placed map (MapGenerate.py:103-104).
-    One deviation: pocket obstacles consume `torch.rand` isle by isle in the hull's canonical vertex order
-    (lexicographically smallest vertex first); Qhull's start vertex is implementation-defined.
+    Pocket obstacles consume `torch.rand` isle by isle in the order of Qhull's vertex list (Path.py:388-395,463-537): Path
+    computes Qhull's first vertex with scipy on the host and hands it to the kernel (`hull_start`, ppn_edage_paths_ex2), so
+    the obstacles and the torch stream position are the reference's.
 "philox": every draw is Philox4x32-10 keyed by (seed, stream, instance id, index) and generated on the
     device — the throughput mode, independent of launch order and of the number of GPUs.
 """

@@ -27,8 +27,9 @@ def dropin(monkeypatch, tmp_path):
 
 def test_config1_mt19937_replay_matches_reference(dropin, golden_dir):
     """BASELINE config 1 through the reference's own call sequence: np.random.seed(0); torch.manual_seed(0);
-    MapGenerate(10, 64, 50, 5, 20, 3).generate(100).  Labels, accepted placements and the numpy stream
-    position match the reference; obstacle lists match wherever the pocket-obstacle isle order does."""
+    MapGenerate(10, 64, 50, 5, 20, 3).generate(100).  Labels, accepted placements, the pocket obstacles of every target path,
+    the FULL obstacle list of all 100 problems and the positions of both global streams (numpy's and torch's) match the reference:
+    in replay mode Path computes Qhull's first hull vertex with scipy and the kernel walks the isles in that order."""
     import torch
     from ppnet_amd import rng
     rng.set_mode("mt19937")
@@ -43,12 +44,12 @@ def test_config1_mt19937_replay_matches_reference(dropin, golden_dir):
         assert np.abs(np.asarray(tp.PathPoint) - g[f"p{j}/pathpoint_image"]).max() < 1e-7
         assert np.abs(tp.SegPointImage - g[f"p{j}/segpoint_image"]).max() < 1e-7
         assert abs(tp.Rotation - g[f"p{j}/rotation"][0]) < 1e-9
-        # pocket obstacles: torch.rand is consumed isle by isle in canonical hull order (ppnet_amd/rng.py), Qhull's
-        # start vertex differs on some paths -> same law, different values; every obstacle keeps its clearance
-        pp = np.asarray(tp.PathPoint)[1::2]
-        for o in tp.obstacles:
-            d = np.sqrt(((pp - np.array([o[1], o[0]])) ** 2).sum(1)).min()
-            assert d >= o[2] + 3 / 50 * 64 - 1e-4
+        # pocket obstacles: torch.rand consumed isle by isle in Qhull's vertex order (ppn_edage_paths_ex2's hull_start) -> the
+        # reference's values (they pass through float32: 1e-4 px)
+        assert np.abs(np.asarray(tp.ConvexHull) - g[f"p{j}/hull_norm"]).max() < 1e-6
+        ref_o = g[f"p{j}/obstacles"].reshape(-1, 3)
+        assert len(tp.obstacles) == len(ref_o)
+        assert np.abs(np.array(tp.obstacles).reshape(-1, 3) - ref_o).max(initial=0) < 1e-4
     mg.generate(map_num=100, folder_path=str(dropin / "out"), round_index=0)
     assert len(mg.MapLabel) == 100
     assert np.abs(np.array([np.ravel(l[1])[0] for l in mg.MapLabel]) - g["angle"]).max() < 1e-12
@@ -59,7 +60,8 @@ def test_config1_mt19937_replay_matches_reference(dropin, golden_dir):
     problems = [json.loads(l) for l in open("unsolved_problems.txt")]
     assert [p["Index"] for p in problems] == g["problem_index"].tolist()
     assert np.abs(np.array([p["Length"] for p in problems]) - g["problem_length"]).max() < 1e-7
-    # random obstacles (same draws, same filter) are the leading entries of every list
+    assert np.array_equal(np.array([torch.rand(1).item() for _ in range(4)], np.float32), g["torch_next_draws"])   # and torch's
+    # the full obstacle list of every problem: kept random obstacles (same draws, same filter: 1e-7), then the placed pocket ones
     n_ref = g["n_obs"]
     off = np.concatenate([[0], np.cumsum(n_ref)])
     for m, p in enumerate(problems):
@@ -68,8 +70,9 @@ def test_config1_mt19937_replay_matches_reference(dropin, golden_dir):
         ref = g["obstacles"][off[m]:off[m + 1]]
         got = np.array(p["Obstacles"]).reshape(-1, 3)
         n_rand = len(ref) - n_pocket
-        assert len(got) >= n_rand
+        assert len(got) == len(ref), (m, len(got), len(ref))
         assert np.abs(got[:n_rand] - ref[:n_rand]).max(initial=0) < 1e-7
+        assert np.abs(got[n_rand:] - ref[n_rand:]).max(initial=0) < 1e-4
     assert os.path.exists(dropin / "out" / "0.jpg") and os.path.exists(dropin / "out" / "99.jpg")
     assert os.path.exists(dropin / "out" / "data" / "9.jpg")
 

@@ -59,7 +59,14 @@ def test_paths_fed_draws_vs_reference_golden(dev, golden_dir, name):
     draws = torch.tensor(fixed_layout(G("draws"), st)[None, :], dtype=torch.float64, device=dev)
     # the recorded torch stream starts at path_obstacles: its first draw is RandomRotation's (Path.py:160-161)
     pocket = torch.tensor(G("torch_draws")[None, int(G("n_rotation_draws")[0]):], dtype=torch.float32, device=dev)
-    pb = edage.generate_paths(1, R, 50, c, draws=draws, pocket_draws=pocket, device=dev, debug=True)
+    # Qhull's first vertex as an index into the canonical cycle (lexicographically smallest vertex first), as dropin/Path.py
+    # computes it with scipy on the host in replay mode: the kernel then lists the hull — and walks the isles, and consumes the
+    # torch.rand stream — in the reference's order (ppn_edage_paths_ex2)
+    ref_hull = np.rint(G("hull_raw")).astype(np.int64)
+    lex = min(range(len(ref_hull)), key=lambda i: (ref_hull[i, 0], ref_hull[i, 1]))
+    hs = (len(ref_hull) - lex) % len(ref_hull)
+    hull_start = torch.tensor([hs], dtype=torch.int32, device=dev)
+    pb = edage.generate_paths(1, R, 50, c, draws=draws, pocket_draws=pocket, device=dev, debug=True, hull_start=hull_start)
     torch.cuda.synchronize()
     assert int(pb.straight[0]) == int(st)
     _close(_np(pb.seg_poly[0]), G("seg_poly"), 1e-9)
@@ -75,24 +82,27 @@ def test_paths_fed_draws_vs_reference_golden(dev, golden_dir, name):
     # exact: corridor canvas pixel set
     canvas = bits_to_mask(_np(pb.canvas_bits[0]), 2 * R, 2 * R)
     assert np.array_equal(np.argwhere(canvas), G("canvas_nz"))
-    # exact: hull vertex cycle (Qhull's start vertex is implementation-defined)
+    # exact: hull vertex list in the reference's (Qhull's) order
     hn = int(pb.hull_n[0])
-    assert cyclic_equal(_np(pb.hull_raw[0])[:hn], G("hull_raw"))
+    assert np.array_equal(_np(pb.hull_raw[0])[:hn], G("hull_raw"))
     _close(_np(pb.rotation[0]), G("rotation")[0])
     _close(_np(pb.trans_rc[0]), G("translation")[::-1])
     _close(_np(pb.segpoint_image[0]), G("segpoint_image"))
     _close(_np(pb.pathpoint_image[0]), G("pathpoint_image"))
-    k = int(np.where(np.abs(G("hull_norm") - _np(pb.hull[0])[0]).max(1) < 1e-6)[0][0])
-    _close(np.roll(G("hull_norm"), -k, axis=0), _np(pb.hull[0])[:hn])
-    # exact: isle slice bounds (as a set: order follows the hull start)
+    _close(G("hull_norm"), _np(pb.hull[0])[:hn], 1e-6)
+    # exact: isle slice bounds, in the reference's order
     ni = int(pb.n_isles[0])
-    got = sorted(map(tuple, _np(pb.isles[0])[:ni].tolist()))
-    assert got == sorted(map(tuple, G("isle_bounds").tolist()))
+    assert _np(pb.isles[0])[:ni].tolist() == G("isle_bounds").tolist()
     assert int(pb.flags[0]) == 0
-    if k == 0 and not st:
-        # same isle order as the reference => same torch.rand consumption => same pocket obstacles
-        no = int(pb.n_obstacles[0])
-        _close(_np(pb.obstacles[0])[:no], G("obstacles"), POCKET_TOL)
+    # same isle order as the reference => same torch.rand consumption => same pocket obstacles, on every case
+    no = int(pb.n_obstacles[0])
+    assert no == len(G("obstacles"))
+    _close(_np(pb.obstacles[0])[:no], G("obstacles").reshape(-1, 3), POCKET_TOL)
+    # and without hull_start the canonical order: the same cycle from the lexicographically smallest vertex
+    pc = edage.generate_paths(1, R, 50, c, draws=draws, pocket_draws=pocket, device=dev, debug=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(np.roll(_np(pc.hull_raw[0])[:hn], -hs, axis=0), G("hull_raw"))
+    assert sorted(map(tuple, _np(pc.isles[0])[:int(pc.n_isles[0])].tolist())) == sorted(map(tuple, G("isle_bounds").tolist()))
 
 
 def test_boundary_check_vs_reference_golden(dev, golden_dir):
