@@ -212,8 +212,10 @@ int ppn_paint_markers(uint8_t* grid, int32_t n, int32_t R, const double* init, c
                       void* stream);
 
 /* Obstacle raster rule standing in for plot_obstacles (Path.py:36-49): n_maps grids of R x R,
- * grid = PPN_GRID_OBST where the pixel centre lies in a disc, else PPN_GRID_FREE.
- * obstacles [n_maps][stride][3], counts[n_maps]. */
+ * grid = PPN_GRID_OBST where the data point the pixel centre shows in the reference's cropped matplotlib figure
+ * (X = (j + 0.5) * 444 / 446.4 + R / 446.4, Y = (i + 0.5) * 330 / 332.64 + 1.16 * R / 332.64) lies in the ellipse a stroked
+ * circle (cx, cy, r) inks (semi-axes r + 0.625 R / 446.4 and r + 0.625 R / 332.64), else PPN_GRID_FREE; unfused IEEE double,
+ * bit-exact against oracle/edage_np.py disc_raster.  obstacles [n_maps][stride][3] = (col, row, r), counts[n_maps]. */
 int ppn_disc_raster(const double* obstacles, const int32_t* counts, int32_t stride,
                     int32_t n_maps, int32_t R, uint8_t* grid, void* stream);
 

@@ -12,7 +12,7 @@ third-party code that is absent here and not integer-reproducible —
   * torchvision rotate/affine of the corridor mask (Path.py:160-161,175; MapGenerate.py:103-106)
     -> restated as an explicit nearest-neighbour inverse map (`rotate_nearest`, `translate_nearest`)
   * matplotlib->JPEG->PIL('1')->crop->Resize obstacle raster (Path.py:36-49)
-    -> restated as "pixel centre inside disc" (`disc_raster`).
+    -> restated as "the data point the pixel centre shows lies inside the inked ellipse" (`disc_raster`, `raster_geometry`).
 
 Conventions: a point is (row, col) = (world x, world y) as in the reference (Path.py:401
 `space[index[0], index[1]]`). Obstacles are [col, row, radius] (Path.py:495, MapGenerate.py:143).
@@ -425,17 +425,49 @@ def translate_nearest(img, tx, ty, out_h, out_w):
     return out
 
 
+def raster_geometry(R):
+    """Geometry of Path.plot_obstacles' raster (Path.py:36-49), in data units = pixels of the R x R map (the function is
+    called with size = (R, R), MapGenerate.py:151).  matplotlib's default figure is 6.4 x 4.8 in at dpi 90 = 576 x 432 px
+    with the axes at left 0.125, right 0.9, bottom 0.11, top 0.88: the axes box spans figure columns [72.0, 518.4]
+    (446.4 px) and rows [51.84, 384.48] (332.64 px) and shows data x in [0, R] left to right, data y in [0, R] top to
+    bottom.  The reference crops rows [53, 383) and columns [73, 517) — 330 x 444 px, slightly inside the axes box —
+    and resizes the crop to R x R, so the centre of output pixel (i, j) shows the data point
+        X = (j + 0.5) * AX + BX,   Y = (i + 0.5) * AY + BY
+    with AX = 444 / 446.4, BX = (73 - 72) / 446.4 * R, AY = 330 / 332.64, BY = (53 - 51.84) / 332.64 * R.  Each circle
+    is filled AND stroked in black with the default 1 pt line (1.25 figure px at dpi 90, half of it outside the rim):
+    the ink reaches SX = 0.625 / 446.4 * R data units beyond the radius horizontally and SY = 0.625 / 332.64 * R
+    vertically.  Returns (IAX, IAY, BX, BY, SX, SY) with IAX = 1 / AX = 446.4 / 444, IAY = 332.64 / 330; every value is
+    computed with exactly these double operations in this order here and in csrc/ppn_device.h."""
+    Rd = float(R)
+    return (446.4 / 444.0, 332.64 / 330.0, (73.0 - 72.0) / 446.4 * Rd, (53.0 - 51.84) / 332.64 * Rd,
+            0.625 / 446.4 * Rd, 0.625 / 332.64 * Rd)
+
+
+def raster_ellipse(cx, cy, r, R):
+    """A circle [cx = col, cy = row, r] as the reference's raster shows it, carried into the pixel-centre frame: the
+    axis-aligned ellipse centred (cxp, cyp) with semi-axes (ex, ey); also (ex * ey)^2."""
+    IAX, IAY, BX, BY, SX, SY = raster_geometry(R)
+    cxp, cyp = (cx - BX) * IAX, (cy - BY) * IAY
+    ex, ey = (r + SX) * IAX, (r + SY) * IAY
+    q = ex * ey
+    return cxp, cyp, ex, ey, q * q
+
+
 def disc_raster(obstacles, R):
-    """Obstacle raster rule replacing Path.plot_obstacles (Path.py:36-49): pixel (i,j) is an
-    obstacle iff its centre (j+0.5, i+0.5) lies in a closed disc [cx=col, cy=row, r].
-    Returns bool [R,R], True = obstacle."""
+    """Obstacle raster rule standing in for Path.plot_obstacles (Path.py:36-49; matplotlib -> JPEG -> PIL '1' -> crop ->
+    Resize is not integer-reproducible): pixel (i, j) is an obstacle iff its centre lies in the closed ellipse that a
+    stroked circle [cx = col, cy = row, r] covers in the pixel-centre frame (raster_geometry, raster_ellipse):
+        (((j + 0.5) - cxp) * ey)^2 + (((i + 0.5) - cyp) * ex)^2 <= (ex * ey)^2     (unfused IEEE double, in this order).
+    Against the reference's own run (tests/golden/g15): IoU 0.984-0.994, 0.3 % of the pixels differ, of both signs
+    (antialiasing, JPEG ringing and the dither of convert('1') are what is left).  Returns bool [R,R], True = obstacle."""
     occ = np.zeros([R, R], dtype=bool)
     yc = (np.arange(R) + 0.5)[:, None]
     xc = (np.arange(R) + 0.5)[None, :]
     for cx, cy, r in np.asarray(obstacles, dtype=np.float64).reshape(-1, 3):
-        dx = xc - cx
-        dy = yc - cy
-        occ |= (dx * dx + dy * dy) <= r * r
+        cxp, cyp, ex, ey, rhs = raster_ellipse(cx, cy, r, R)
+        a = (xc - cxp) * ey
+        b = (yc - cyp) * ex
+        occ |= (a * a + b * b) <= rhs
     return occ
 
 

@@ -61,6 +61,11 @@ __host__ __device__ constexpr int maps_tab_bytes(int K) {
     return rows > 1024 ? rows : 1024;
 }
 
+// The corridor-touch margin's rounding budget (see the clearance filter): five nearest-neighbour roundings of <= sqrt(2) / 2 px
+// (corridor canvas, path-point lattice, two mask rotations, one fractional mask translation) and the half-pixel offset between
+// the label frame and the pixel-centre frame: 6 * 0.7072 = 4.2432.
+#define PPN_TOUCH_ROUNDINGS 4.25
+
 // 8 occupancy bits -> 8 grid bytes: bit k set (= occupied) -> byte k 0x00, clear -> 0xFF.  Read-only device table (2 KB, L1 /
 // L2 resident): keeping it out of LDS leaves room for one more workgroup per CU.
 struct ByteLut {
@@ -74,12 +79,6 @@ struct ByteLut {
     }
 };
 __device__ const ByteLut g_byte_lut{};
-
-// exact predicate of the obstacle raster rule for pixel column j of a row at squared row offset dy2
-__device__ __forceinline__ bool disc_pred(int j, double cx, double dy2, double rr) {
-    const double dx = ((double)j + 0.5) - cx;
-    return dx * dx + dy2 <= rr;
-}
 
 // 4 mask bits -> 4 bytes (0x00 / 0xFF)
 __device__ __forceinline__ uint32_t expand4(uint32_t b) {
@@ -129,6 +128,9 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
     double (*cand)[3] = reinterpret_cast<double (*)[3]>(lds + regionP_bytes);
     double (*obs)[3] = reinterpret_cast<double (*)[3]>(lds + regionP_bytes + cand_bytes);
     float* poddf = reinterpret_cast<float*>(lds + regionP_bytes + cand_bytes + (size_t)(K + PPN_MAX_POCKET) * 24);
+    // [K+64][5] f64 per obstacle: its raster ellipse (cxp, cyp, ex, ey, (ex ey)^2) in the pixel-centre frame   (PHASE&2)
+    double (*oell)[5] = reinterpret_cast<double (*)[5]>(reinterpret_cast<unsigned char*>(poddf) + maps_tab_bytes(K) + ((PHASE & 2) ? 0 : MAPS_SCRATCH));
+    (void)oell;
     const uint64_t* lut = g_byte_lut.v;
     unsigned char* scratch = (PHASE & 2) ? lds : reinterpret_cast<unsigned char*>(poddf) + maps_tab_bytes(K);   // filter scratch: the occupancy mask's bytes when fused
     // regions that are dead when their second tenant arrives (barriers lie between):
@@ -312,10 +314,12 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
             //   0.5*c_px (ray reach from the centre line, Path.py:119-134) + max_step (next odd path point)
             //   + 4.3 px (five nearest-neighbour roundings of <= 0.71 px: canvas, point lattice, two rotations,
             //     one fractional translation; + the half-pixel offset between the label and the disc frames)
-            // of an odd path point, and a pixel of obstacle k lies >= md_k - r_k - 0.71 from every odd path point.
-            // So an obstacle with md_k - r_k > touch_margin cannot meet the corridor; if none can, the compose
-            // pass below is a no-op and is skipped (tests/test_gpu_edage.py checks this against a forced run).
-            const double touch_margin = 0.5 * c_px + P.max_step_px[pj] + 5.0;
+            // of an odd path point, and a pixel of obstacle k lies >= md_k - r_k - reach - 0.71 from every odd path point
+            // (reach: how far the reference's raster geometry — crop offset, stroke — can carry a disc beyond its radius,
+            // ppn_device.h raster_reach_max: a constant of the resolution).  So an obstacle with md_k - r_k > touch_margin
+            // cannot meet the corridor; if none can, the compose pass below is a no-op and is skipped
+            // (tests/test_gpu_edage.py checks this against a forced run).
+            const double touch_margin = 0.5 * c_px + P.max_step_px[pj] + PPN_TOUCH_ROUNDINGS + raster_reach_max(R);
             // Two levels.  Coarse: every 4th odd point (plus the last: NCOARSE = 126 points), in float, one lane per
             // obstacle, each wave a quarter of the 63 point pairs (8-byte same-address LDS reads broadcast; a 16-byte one
             // measured ~64 LDS cycles).  An odd point is at most 4 path steps from a coarse one, and the image-frame
@@ -460,16 +464,17 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
         __syncthreads();
 
         // ------------------------------------------------------------------ raster 1: exact row spans -> LDS bit mask.
-        // One wave per obstacle, one lane per row of its bounding box.  The pixel rule "centre inside the
-        // closed disc" is monotone in |dx| under IEEE rounding, so the columns of a row form an interval:
-        // estimate it with a float sqrt, then settle both ends with the exact double predicate.
+        // The pixel rule (ppn_device.h raster_ellipse / disc_pred: the pixel centre lies in the ellipse the reference's stroked
+        // circle covers in the pixel-centre frame) is monotone in |j + 0.5 - cxp| under IEEE rounding, so the columns of a row
+        // form an interval: estimate it with a float sqrt, then settle both ends with the exact double predicate.
         const int wpr = R / 32;
         const double c3 = bc[8], s3 = bc[9];
         // (obstacle, row) pairs are flattened over the whole workgroup: obstacle n owns rows [row_lo[n], row_lo[n] + cnt),
         // an exclusive scan of the counts (wave 0, shuffles) gives each pair an index, a binary search gives it back.
         for (int n = tid; n < n_obs; n += NT) {
-            const double cy = obs[n][1], r = obs[n][2];
-            const int lo = max((int)floor(cy - r - 0.5), 0), hi = min((int)ceil(cy + r - 0.5), R - 1);
+            const RasterEllipse e = raster_ellipse(obs[n][0], obs[n][1], obs[n][2], raster_geom(R));
+            oell[n][0] = e.cxp; oell[n][1] = e.cyp; oell[n][2] = e.ex; oell[n][3] = e.ey; oell[n][4] = e.rhs;
+            const int lo = max((int)floor(e.cyp - e.ey - 0.5), 0), hi = min((int)ceil(e.cyp + e.ey - 0.5), R - 1);   // rows with |i + 0.5 - cyp| <= ey
             row_lo[n] = lo;
             row_off[n + 1] = max(hi - lo + 1, 0);
         }
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
         const int n_pairs = row_off[n_obs];
         // each thread takes a contiguous run of pairs: one binary search for the first, then it walks rows / obstacles
         const int run = (n_pairs + NT - 1) / NT;
-        const float amb_eps = 1.0e-6f * (float)R;
+        const float amb_eps = 2.0e-6f * (float)R;
         int pr = tid * run;
         const int pr_end = min(pr + run, n_pairs);
         int n = 0;
@@ -503,26 +508,25 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
         for (; pr < pr_end; ++pr) {
             while (pr >= nxt) { ++n; nxt = row_off[n + 1]; }               // obstacles with an empty row range are skipped
             const int i = row_lo[n] + (pr - row_off[n]);
-            const double cx = obs[n][0], cy = obs[n][1], r = obs[n][2];
-            const double rr = r * r;
-            const double dy = ((double)i + 0.5) - cy;
-            const double dy2 = dy * dy;
-            if (dy2 > rr) continue;                                       // dx*dx + dy2 >= dy2 > rr for every column
-            // real-valued ends of the interval in column units: j + 0.5 in [cx - w, cx + w]
-            const float w = __builtin_amdgcn_sqrtf((float)(rr - dy2));     // 1-ulp hardware sqrt: an estimate is all it is
-            const float xl = (float)cx - w - 0.5f, xr = (float)cx + w - 0.5f;
+            const double cxp = oell[n][0], cyp = oell[n][1], ex = oell[n][2], ey = oell[n][3], rhs = oell[n][4];
+            const double b = (((double)i + 0.5) - cyp) * ex;
+            const double b2 = b * b;
+            if (b2 > rhs) continue;                                       // a*a + b2 >= b2 > rhs for every column
+            // real-valued ends of the interval in column units: j + 0.5 in [cxp - w, cxp + w], w = sqrt(rhs - b2) / ey
+            const float w = __builtin_amdgcn_sqrtf((float)(rhs - b2)) * __builtin_amdgcn_rcpf((float)ey);   // 1-ulp hardware sqrt / rcp: an estimate is all it is
+            const float xl = (float)cxp - w - 0.5f, xr = (float)cxp + w - 0.5f;
             int jl = (int)ceilf(xl), jh = (int)floorf(xr);
-            // The float estimate is off by < 3.6e-7 * R columns (conversion of cx, 1-ulp sqrt, two subtractions of
-            // values < R); an end within amb_eps = 1e-6 * R of an integer is settled with the exact double predicate,
-            // which is monotone in |dx|: the true end is the estimate's nearest integer or its inward neighbour.
+            // The float estimate is off by < 1e-6 * R columns (conversion of cxp, 1-ulp sqrt and reciprocal, a product, two
+            // subtractions of values < 1.01 R); an end within amb_eps = 2e-6 * R of an integer is settled with the exact double
+            // predicate, which is monotone in |dx|: the true end is the estimate's nearest integer or its inward neighbour.
             // (A wide window costs: one lane in the slow path holds up its whole wave.)
             if (fabsf(xl - rintf(xl)) < amb_eps) {
                 const int j0 = (int)rintf(xl);
-                jl = disc_pred(j0, cx, dy2, rr) ? j0 : j0 + 1;
+                jl = disc_pred(j0, cxp, ey, b2, rhs) ? j0 : j0 + 1;
             }
             if (fabsf(xr - rintf(xr)) < amb_eps) {
                 const int j0 = (int)rintf(xr);
-                jh = disc_pred(j0, cx, dy2, rr) ? j0 : j0 - 1;
+                jh = disc_pred(j0, cxp, ey, b2, rhs) ? j0 : j0 - 1;
             }
             jl = max(jl, 0); jh = min(jh, R - 1);
             if (jl > jh) continue;
@@ -619,7 +623,7 @@ template <int PHASE>
 static int launch_phase(const MapsParams& prm, hipStream_t stream) {
     const int R = prm.R, K = prm.K;
     const size_t lds = (size_t)maps_region_bytes(PHASE, R) + ((PHASE & 1) ? (size_t)K * 24 : 0) + (size_t)(K + PPN_MAX_POCKET) * 24 +
-                       maps_tab_bytes(K) + ((PHASE & 2) ? 0 : MAPS_SCRATCH);
+                       maps_tab_bytes(K) + ((PHASE & 2) ? (size_t)(K + PPN_MAX_POCKET) * 40 : MAPS_SCRATCH);
     if (hipFuncSetAttribute((const void*)edage_maps_kernel_t<PHASE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PPN_E_HIP;
     hipLaunchKernelGGL(edage_maps_kernel_t<PHASE>, dim3((unsigned)prm.n_maps), dim3(PPN_MAPS_THREADS), lds, stream, prm);
@@ -781,32 +785,30 @@ __global__ __launch_bounds__(128) void paint_markers_kernel(uint8_t* grid, int n
     if (i >= 0 && i < R && j >= 0 && j < R) grid[(size_t)m * R * R + (size_t)i * R + j] = PPN_GRID_MARK;
 }
 
-// explicit obstacle raster rule (stands in for Path.plot_obstacles, Path.py:36-49)
+// explicit obstacle raster rule (stands in for Path.plot_obstacles, Path.py:36-49; ppn_device.h raster_geom / disc_pred)
 __global__ __launch_bounds__(NT) void disc_raster_kernel(const double* obstacles, const int32_t* counts, int stride,
                                                          int n_maps, int R, uint8_t* grid) {
-    __shared__ double obs[MAX_OBS][4];
+    __shared__ double obs[MAX_OBS][5];                                       // the raster ellipse: cxp, cyp, ex, ey, (ex * ey)^2
     const int m = blockIdx.x, tid = threadIdx.x;
     const int n_obs = min(counts[m], MAX_OBS);
     for (int n = tid; n < n_obs; n += NT) {
         const double* o = obstacles + ((size_t)m * stride + n) * 3;
-        obs[n][0] = o[0]; obs[n][1] = o[1]; obs[n][2] = o[2]; obs[n][3] = o[2] * o[2];
+        const RasterEllipse e = raster_ellipse(o[0], o[1], o[2], raster_geom(R));
+        obs[n][0] = e.cxp; obs[n][1] = e.cyp; obs[n][2] = e.ex; obs[n][3] = e.ey; obs[n][4] = e.rhs;
     }
     __syncthreads();
     const int cpr = R / 16;
     uint8_t* g = grid + (size_t)m * R * R;
     for (int ch = tid; ch < R * cpr; ch += NT) {
         const int i = ch / cpr, j0 = (ch - i * cpr) * 16;
-        const double yc = (double)i + 0.5;
         uint32_t occ = 0u;
         for (int n = 0; n < n_obs; ++n) {
-            const double dy = yc - obs[n][1], rr = obs[n][3], dy2 = dy * dy;
-            if (dy2 > rr) continue;
-            const double cx = obs[n][0];
+            const double b = (((double)i + 0.5) - obs[n][1]) * obs[n][2], rhs = obs[n][4], b2 = b * b;
+            if (b2 > rhs) continue;
+            const double cxp = obs[n][0], ey = obs[n][3];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const double dx = ((double)(j0 + k) + 0.5) - cx;
-                if (dx * dx + dy2 <= rr) occ |= 1u << k;
-            }
+            for (int k = 0; k < 16; ++k)
+                if (disc_pred(j0 + k, cxp, ey, b2, rhs)) occ |= 1u << k;
         }
         uint32_t w[4];
 #pragma unroll

@@ -195,6 +195,46 @@ __device__ __forceinline__ void sincos_small(double x, double& sn, double& cs) {
     cs = q == 0 ? c : q == 1 ? -s : q == 2 ? -c : s;
 }
 
+// Geometry of the reference's obstacle raster (Path.plot_obstacles, Path.py:36-49): see oracle/edage_np.py raster_geometry for
+// the derivation.  Output pixel (i, j) shows the data point X = (j + 0.5) * ax + bx, Y = (i + 0.5) * ay + by and a circle of radius r
+// inks the ellipse with semi-axes r + sx, r + sy around its centre; carried into the pixel-centre frame that is the axis-aligned
+// ellipse of raster_ellipse().  The same double operations in the same order as the oracle (1 / ax and 1 / ay as constants).
+struct RasterGeom { double bx, by, sx, sy; };
+constexpr double PPN_RASTER_IAX = 446.4 / 444.0, PPN_RASTER_IAY = 332.64 / 330.0;
+__device__ __forceinline__ RasterGeom raster_geom(int R) {
+    const double Rd = (double)R;
+    RasterGeom g;
+    g.bx = (73.0 - 72.0) / 446.4 * Rd; g.by = (53.0 - 51.84) / 332.64 * Rd;
+    g.sx = 0.625 / 446.4 * Rd; g.sy = 0.625 / 332.64 * Rd;
+    return g;
+}
+// centre (col, row), semi-axes and (ex * ey)^2 of a circle's raster in pixel-centre coordinates
+struct RasterEllipse { double cxp, cyp, ex, ey, rhs; };
+__device__ __forceinline__ RasterEllipse raster_ellipse(double cx, double cy, double r, const RasterGeom& g) {
+    RasterEllipse e;
+    e.cxp = (cx - g.bx) * PPN_RASTER_IAX; e.cyp = (cy - g.by) * PPN_RASTER_IAY;
+    e.ex = (r + g.sx) * PPN_RASTER_IAX; e.ey = (r + g.sy) * PPN_RASTER_IAY;
+    const double q = e.ex * e.ey;
+    e.rhs = q * q;
+    return e;
+}
+// exact predicate of the raster rule for pixel column j: b2 = (((i + 0.5) - cyp) * ex)^2 of the row
+__device__ __forceinline__ bool disc_pred(int j, double cxp, double ey, double b2, double rhs) {
+    const double a = (((double)j + 0.5) - cxp) * ey;
+    return a * a + b2 <= rhs;
+}
+// How far beyond its radius r — measured from its centre in pixel-centre coordinates — the raster of ANY circle can reach inside an
+// R x R image: a pixel centre (xp, yp) in [0, R]^2 shows the data point (xp * ax + bx, yp * ay + by), at most (Dx, Dy) away from it,
+// and that point lies within r + max(sx, sy) of the circle's centre.  An upper bound (it only feeds the decision to skip a pass
+// that would be a no-op); 1.88 px at R = 256.
+__device__ __forceinline__ double raster_reach_max(int R) {
+    const RasterGeom g = raster_geom(R);
+    const double Rd = (double)R;
+    const double dx = fmax(fabs(g.bx), fabs(g.bx - Rd * (1.0 - 1.0 / PPN_RASTER_IAX)));
+    const double dy = fmax(fabs(g.by), fabs(g.by - Rd * (1.0 - 1.0 / PPN_RASTER_IAY)));
+    return sqrt(dx * dx + dy * dy) + fmax(g.sx, g.sy) + 1e-3;
+}
+
 __device__ __forceinline__ double dist2d(double ax, double ay, double bx, double by) {
     double dx = ax - bx, dy = ay - by;
     return sqrt(dx * dx + dy * dy);

@@ -29,7 +29,8 @@ class Boundary:
 
 
 def plot_obstacles(size: tuple, obstacles, resolution: tuple = (224, 224)):
-    """Obstacle raster (Path.py:36-49) by the explicit rule "pixel centre inside the disc": returns a
+    """Obstacle raster (Path.py:36-49) by the explicit rule of ppn_disc_raster — the data point a pixel centre shows in the
+    reference's cropped matplotlib figure lies inside the ellipse the stroked circle inks: returns a
     float tensor [3,R,R], 1 = free, 0 = obstacle, like the reference's ToTensor output."""
     R = int(resolution[0])
     dev = torch.device(rng.device())

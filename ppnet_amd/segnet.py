@@ -277,7 +277,7 @@ class NAT(nn.Module):
                      mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
                      drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])], norm_layer=norm_layer,
                      layer_scale=layer_scale) for i in range(self.num_levels))
-        self.out_indices = out_indices
+        self.out_indices = tuple(out_indices)
         self.compute_indices = tuple(out_indices)      # inference may narrow this to the levels the head reads
         for i in out_indices:
             self.add_module(f"norm{i}", norm_layer(self.num_features[i]))
@@ -293,12 +293,12 @@ class NAT(nn.Module):
     def forward(self, x):
         """x: the image [B,3,H,W], or (GPU inference) the u8 occupancy codes [B,H,W] it would be rendered from."""
         x = self.patch_embed.forward_codes(x) if x.dtype == torch.uint8 else self.patch_embed(x)
-        outs = []
+        outs = [None] * len(self.out_indices)          # one slot per out_index (nat.py:326-332); levels nobody reads stay None
         for idx, level in enumerate(self.levels):
             want = idx in self.compute_indices
             x, xo = level(x, getattr(self, f"norm{idx}") if want else None, inplace=True)   # x: fresh LayerNorm output
             if want:
-                outs.append(xo.permute(0, 3, 1, 2))    # [B,C,H,W] in channels_last memory format (zero-copy view)
+                outs[self.out_indices.index(idx)] = xo.permute(0, 3, 1, 2)    # [B,C,H,W] in channels_last memory format (zero-copy view)
         return outs
 
 
@@ -309,9 +309,9 @@ class DiNAT(NAT):
 class _ConvModule(nn.Sequential):
     """mmcv ConvModule(conv -> bn -> ReLU) with its parameter names `conv.*`, `bn.*` (conv has no bias under a norm)."""
 
-    def __init__(self, cin, cout, k):
+    def __init__(self, cin, cout, k, dilation=1):
         super().__init__()
-        self.add_module("conv", nn.Conv2d(cin, cout, k, 1, (k - 1) // 2, bias=False))
+        self.add_module("conv", nn.Conv2d(cin, cout, k, 1, ((k - 1) // 2) * dilation, dilation, bias=False))
         self.add_module("bn", nn.BatchNorm2d(cout))          # SyncBN reverts to BN outside distributed runs (SegNet/train.py:179-185)
         self.add_module("activate", nn.ReLU(inplace=True))
 
@@ -431,6 +431,37 @@ class UPerHead(nn.Module):
         return self.conv_seg(self.fpn_bottleneck(torch.cat(outs, dim=1)))
 
 
+class FCNHead(nn.Module):
+    """mmseg's FCNHead (SegNet/mmseg/decode_heads/fcn_head.py:11-81 over decode_head.py:54-107,224-229) — the auxiliary head of
+    the reference's NAT training configs (configs/_base_/models/nat.py:22-35, configs/nat/setr_up_nat_base.py:39-42: level 2,
+    512 -> 256 channels, one 3x3 conv-BN-ReLU, Dropout2d(0.1), 1x1 classifier, loss weight 0.4).  Checkpoint keys follow mmseg:
+    `convs.i.{conv,bn}`, `conv_cat.{conv,bn}`, `conv_seg`.  Training only: inference never evaluates it (encoder_decoder.py:63-80)."""
+
+    def __init__(self, in_channels=256, channels=256, num_classes=19, num_convs=2, kernel_size=3, concat_input=True, dilation=1,
+                 in_index=-1, dropout_ratio=0.1, align_corners=False, norm_cfg=None, loss_decode=None, **kwargs):
+        super().__init__()
+        assert num_convs >= 0 and dilation > 0
+        self.in_index, self.align_corners, self.concat_input = in_index, align_corners, concat_input
+        self.loss_weight = float((loss_decode or {}).get("loss_weight", 1.0))
+        if num_convs == 0:
+            assert in_channels == channels
+            self.convs = nn.Identity()
+        else:
+            self.convs = nn.Sequential(*[_ConvModule(in_channels if i == 0 else channels, channels, kernel_size, dilation)
+                                         for i in range(num_convs)])
+        if concat_input:
+            self.conv_cat = _ConvModule(in_channels + channels, channels, kernel_size)
+        self.conv_seg = nn.Conv2d(channels, num_classes, 1)
+        self.dropout = nn.Dropout2d(dropout_ratio) if dropout_ratio > 0 else nn.Identity()
+
+    def forward(self, inputs):
+        x = inputs[self.in_index]
+        y = self.convs(x)
+        if self.concat_input:
+            y = self.conv_cat(torch.cat([x, y], dim=1))
+        return self.conv_seg(self.dropout(y))
+
+
 NAT_BASE_UPER = dict(   # SegNet/configs/nat/upernet_nat_base.py:6-34 (the default config of SegNet/test.py:29-32)
     backbone=dict(embed_dim=128, mlp_ratio=2.0, depths=[3, 4, 18, 5], num_heads=[4, 8, 16, 32], kernel_size=7,
                   layer_scale=1e-5),
@@ -448,18 +479,62 @@ IMG_STD = (58.395, 57.12, 57.375)
 
 
 class SegNet(nn.Module):
-    """EncoderDecoder(test_cfg=mode 'whole') for inference: encode_decode -> softmax -> argmax."""
+    """EncoderDecoder(test_cfg=mode 'whole') (SegNet/mmseg/models/segmentors/encoder_decoder.py:16-265, base.py:62-112): the
+    constructor takes the reference's config sub-dicts (`from_config` the whole `model=dict(...)`), `forward` the reference
+    harness's call — `model(return_loss=False, img=[x], img_metas=[[...]]) -> list[np.ndarray int64 [H,W]]`
+    (mmseg/apis/test.py:93) — and `model(img=x, img_metas=[...], gt_semantic_seg=y)` returns the loss dict of forward_train."""
 
-    def __init__(self, backbone=None, decode_head=None):
+    def __init__(self, backbone=None, decode_head=None, auxiliary_head=None, train_cfg=None, test_cfg=None, pretrained=None):
         super().__init__()
-        self.backbone = DiNAT(**(backbone or DINAT_BASE["backbone"]))
+        bb_cfg = dict(backbone or DINAT_BASE["backbone"])
+        bb_type = bb_cfg.pop("type", "DiNAT")
+        if pretrained is not None and bb_cfg.get("pretrained") is None:
+            bb_cfg["pretrained"] = pretrained                                  # encoder_decoder.py:32-36
+        self.backbone = {"NAT": NAT, "DiNAT": DiNAT}[bb_type](**bb_cfg)
         head_cfg = dict(decode_head or DINAT_BASE["decode_head"])
         head_type = head_cfg.pop("type", "SETRUPHead")
-        self.decode_head = {"SETRUPHead": SETRUPHead, "UPerHead": UPerHead}[head_type](**head_cfg)
+        self.decode_head = {"SETRUPHead": SETRUPHead, "UPerHead": UPerHead, "FCNHead": FCNHead}[head_type](**head_cfg)
+        self.auxiliary_head = None
+        if auxiliary_head is not None:                                         # encoder_decoder.py:52-61 (a dict, or a list of them)
+            mk = lambda c: FCNHead(**{k: v for k, v in dict(c).items() if k != "type"})
+            self.auxiliary_head = nn.ModuleList(mk(c) for c in auxiliary_head) if isinstance(auxiliary_head, (list, tuple)) else mk(auxiliary_head)
         self.align_corners = self.decode_head.align_corners
-        if self.decode_head.in_index in (-1, self.backbone.num_levels - 1):
-            # SETR-UP reads only the last level: skip the per-level norm + NHWC->NCHW copies nobody consumes
-            self.backbone.compute_indices = (self.backbone.num_levels - 1,)
+        self.train_cfg, self.test_cfg = train_cfg, dict(test_cfg or {"mode": "whole"})
+        if self.test_cfg.get("mode", "whole") != "whole":
+            raise NotImplementedError("test_cfg.mode 'whole' only (every configuration under SegNet/configs)")
+        self._narrow_levels()
+
+    def _aux_heads(self):
+        a = self.auxiliary_head
+        return [] if a is None else (list(a) if isinstance(a, nn.ModuleList) else [a])
+
+    def _narrow_levels(self, inference=False):
+        """The backbone evaluates only the levels a head reads (their output norm + the NHWC -> NCHW view): SETR-UP reads the last
+        one; the auxiliary head's level joins while it can be trained (not after prepare_inference)."""
+        n = self.backbone.num_levels
+        idx = lambda i: i % n
+        ii = self.decode_head.in_index
+        need = {idx(i) for i in (ii if isinstance(ii, (tuple, list)) else (ii,))}
+        if not inference:
+            need |= {idx(h.in_index) for h in self._aux_heads()}
+        self.backbone.compute_indices = tuple(sorted(need & set(self.backbone.out_indices)))
+
+    @classmethod
+    def from_config(cls, cfg):
+        """cfg: the reference's `model = dict(type='EncoderDecoder', pretrained=..., backbone=dict(type='DiNAT', ...),
+        decode_head=dict(type='SETRUPHead', ...), auxiliary_head=..., train_cfg=..., test_cfg=dict(mode='whole'))`
+        (configs/_base_/models/dinat.py:3-46 merged with configs/dinat/dinat_base.py:5-24), or a whole config holding it under
+        'model'.  mmcv-only keys (init_cfg, norm_cfg, loss_decode, conv_cfg, act_cfg, in_patch_size, frozen_stages) are accepted
+        and ignored where this build has one fixed choice."""
+        cfg = dict(cfg.get("model", cfg))
+        typ = cfg.pop("type", "EncoderDecoder")
+        if typ != "EncoderDecoder":
+            raise NotImplementedError(f"segmentor type {typ!r}: EncoderDecoder only")
+        known = ("backbone", "decode_head", "auxiliary_head", "train_cfg", "test_cfg", "pretrained")
+        extra = set(cfg) - set(known) - {"neck", "init_cfg"}
+        if extra or cfg.get("neck") is not None:
+            raise NotImplementedError(f"unsupported model keys: {sorted(extra | ({'neck'} if cfg.get('neck') is not None else set()))}")
+        return cls(**{k: cfg[k] for k in known if k in cfg})
 
     def prepare_inference(self):
         """After the checkpoint is loaded: fold each head BatchNorm into its convolution (exact algebra in float32,
@@ -478,8 +553,12 @@ class SegNet(nn.Module):
         if not os.environ.get("PPNET_NO_FOLD"):          # A/B knob: keep the fused residual+LayerNorm form
             for level in self.backbone.levels:
                 level.fold()
+        self._narrow_levels(inference=True)              # the auxiliary head is a training-time branch
+        self.prepared = True
         self.to(memory_format=torch.channels_last)
         return self
+
+    prepared = False
 
     def encode_decode(self, img):
         out = self.decode_head(self.backbone(img))
@@ -496,10 +575,91 @@ class SegNet(nn.Module):
             img = fused.grid_to_image(img, IMG_MEAN, IMG_STD, next(self.parameters()).dtype)
         return self.forward(img).to(torch.uint8)
 
-    def forward(self, img, return_logits=False):
+    # ------------------------------------------------------------------ the reference's calling convention
+    def forward(self, img=None, img_metas=None, return_loss=True, return_logits=False, **kwargs):
+        """base.py:99-112.  Three forms:
+        * `model(return_loss=False, img=[x], img_metas=[[meta, ...]])` — what single_gpu_test / multi_gpu_test call
+          (mmseg/apis/test.py:93,196): one entry per test-time augmentation; returns list[np.ndarray int64 [H,W]], one per image.
+        * `model(img=x, img_metas=[meta, ...], gt_semantic_seg=y)` (return_loss=True) — forward_train: the dict of losses.
+        * `model(x)` with a tensor and no img_metas (this build's batched form): the argmax labels as a tensor [B,H,W]
+          (+ the logits with return_logits=True)."""
+        if isinstance(img, (list, tuple)):
+            if return_loss:
+                raise TypeError("return_loss=True takes img as a Tensor and img_metas as list[dict] (base.py:103-107)")
+            return self.forward_test(list(img), img_metas, **kwargs)
+        if img_metas is None and "gt_semantic_seg" not in kwargs:
+            logits = self.encode_decode(img)
+            pred = F.softmax(logits.float(), dim=1).argmax(dim=1)           # encoder_decoder.py:242,257
+            return (pred, logits) if return_logits else pred
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        raise TypeError("return_loss=False takes img as list[Tensor] and img_metas as list[list[dict]] (base.py:103-107)")
+
+    def forward_test(self, imgs, img_metas, rescale=True, **kwargs):
+        """base.py:64-96 + encoder_decoder.py:254-292: per augmentation softmax of the logits resized to ori_shape, flipped back
+        where the augmentation flipped, averaged over the augmentations; argmax -> one int64 array per image."""
+        for var, name in ((imgs, "imgs"), (img_metas, "img_metas")):
+            if not isinstance(var, list):
+                raise TypeError(f"{name} must be a list, but got {type(var)}")
+        if len(imgs) != len(img_metas):
+            raise ValueError(f"num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})")
+        if len(imgs) == 1:
+            return self.simple_test(imgs[0], img_metas[0], rescale)
+        assert rescale                                                       # aug_test, encoder_decoder.py:274-276
+        prob = self.inference(imgs[0], img_metas[0], rescale)
+        for x, m in zip(imgs[1:], img_metas[1:]):
+            prob = prob + self.inference(x, m, rescale)
+        return list((prob / len(imgs)).argmax(dim=1).cpu().numpy())
+
+    def simple_test(self, img, img_meta, rescale=True):
+        """encoder_decoder.py:254-265.  Unflipped whole-image inference at the input size on the GPU takes the fused tail
+        (labels_u8: up-sampling, resize, softmax and argmax in one kernel) — the same labels, as int64 arrays."""
+        meta0 = _meta(img_meta)[0] if img_meta else {}
+        size = tuple(meta0.get("ori_shape", img.shape[-2:])[:2]) if rescale else tuple(img.shape[-2:])
+        if img.is_cuda and not meta0.get("flip", False) and size == tuple(img.shape[-2:]) and not torch.is_grad_enabled():
+            return list(self.labels_u8(img).to(torch.int64).cpu().numpy())
+        return list(self.inference(img, img_meta, rescale).argmax(dim=1).cpu().numpy())
+
+    def inference(self, img, img_meta, rescale=True):
+        """encoder_decoder.py:200-252: whole_inference + softmax + un-flip.  Returns the class probabilities [B,C,H,W]."""
+        metas = _meta(img_meta) if img_meta else [{}]
+        ori = metas[0].get("ori_shape")
+        assert all(m.get("ori_shape") == ori for m in metas)
         logits = self.encode_decode(img)
-        pred = F.softmax(logits.float(), dim=1).argmax(dim=1)               # encoder_decoder.py:242,257
-        return (pred, logits) if return_logits else pred
+        if rescale and ori is not None and tuple(ori[:2]) != tuple(logits.shape[-2:]):
+            logits = F.interpolate(logits, tuple(ori[:2]), mode="bilinear", align_corners=self.align_corners)
+        out = F.softmax(logits.float(), dim=1)
+        if metas[0].get("flip", False):
+            d = metas[0].get("flip_direction", "horizontal")
+            assert d in ("horizontal", "vertical")
+            out = out.flip(dims=(3,) if d == "horizontal" else (2,))
+        return out
+
+    def forward_train(self, img, img_metas, gt_semantic_seg, **kwargs):
+        """encoder_decoder.py:122-152 with decode_head.py:209-237 (losses): {'decode.loss_ce', 'decode.acc_seg'} and, with an
+        auxiliary head, {'aux.loss_ce', 'aux.acc_seg'} (loss weights 1.0 / 0.4, ignore_index 255)."""
+        if self.prepared:
+            raise RuntimeError("SegNet.prepare_inference() folded BatchNorm / LayerScale into the weights: build a fresh SegNet to train")
+        feats = self.backbone(img)
+        gt = gt_semantic_seg.squeeze(1).long() if gt_semantic_seg.dim() == 4 else gt_semantic_seg.long()
+        losses = {}
+        heads = [("decode", self.decode_head, 1.0)] + [(f"aux_{i}" if isinstance(self.auxiliary_head, nn.ModuleList) else "aux", h, h.loss_weight)
+                                                       for i, h in enumerate(self._aux_heads())]
+        for name, head, w in heads:
+            logit = F.interpolate(head(feats).float(), gt.shape[-2:], mode="bilinear", align_corners=head.align_corners)
+            losses[f"{name}.loss_ce"] = w * F.cross_entropy(logit, gt, ignore_index=255)
+            with torch.no_grad():
+                valid = gt != 255
+                losses[f"{name}.acc_seg"] = 100.0 * ((logit.argmax(1) == gt) & valid).sum() / valid.sum().clamp(min=1)
+        return losses
+
+
+def _meta(img_meta):
+    """img_metas as the data loader hands them: list[dict], or a DataContainer-like object whose `.data[0]` is that list
+    (mmseg/apis/test.py:97)."""
+    if hasattr(img_meta, "data") and not isinstance(img_meta, (list, tuple)):
+        img_meta = img_meta.data[0]
+    return list(img_meta)
 
 
 def normalize_images(rgb_u8):

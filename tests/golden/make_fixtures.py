@@ -453,7 +453,7 @@ def fixture_plot_obstacles(PathMod):
     the real matplotlib / libjpeg / Pillow and two stand-ins for torchvision: ToTensor (u8 HWC -> f32 CHW / 255) and Resize =
     torch's bilinear interpolate without antialiasing (what torchvision 0.12 does to a tensor).  Recorded: the obstacle
     lists of 20 config-1 maps (scaled to R = 64, 224, 256) and the binarised raster (obstacle = value < 0.5), bit-packed.
-    This MEASURES the deviation of the build's explicit rule (pixel centre in the closed disc); it does not pin it: the
+    This MEASURES the deviation of the build's explicit rule (oracle/edage_np.py disc_raster); it does not pin it: the
     stand-in Resize and the JPEG decoder make the result environment-dependent by a pixel at the rims."""
     import torchvision
 

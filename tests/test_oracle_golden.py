@@ -263,12 +263,14 @@ def test_mask_path_matches_reference(golden_dir):
 
 # ------------------------------------------------------------------ G15: how far the disc rule is from the reference's raster
 def test_disc_raster_deviation_from_reference_plot_obstacles(golden_dir, capsys):
-    """A13 is replaced, not reproduced: Path.plot_obstacles (Path.py:36-49) goes matplotlib (1 pt black stroke, antialiased)
-    -> JPEG -> PIL '1' (Floyd-Steinberg dither) -> crop -> Resize, and is not integer-reproducible.  g15 holds the reference's
-    own function run in the build container (stand-ins: ToTensor, Resize = bilinear without antialiasing) on 21 config-1
-    obstacle lists; this test MEASURES the build's rule (pixel centre in the closed disc) against it — a stated deviation,
-    not a pin.  Measured: IoU 0.94-0.97, 0.6-1.2 % of all pixels differ, every differing pixel lies
-    within 2 px of a disc rim, and the reference's discs are the larger ones (the stroke adds ~0.4 px of radius)."""
+    """A13 is modelled, not reproduced bit for bit: Path.plot_obstacles (Path.py:36-49) goes matplotlib (1 pt black stroke,
+    antialiased) -> JPEG -> PIL '1' (Floyd-Steinberg dither) -> crop -> Resize, and is not integer-reproducible.  g15 holds the
+    reference's own function run in the build container (stand-ins: ToTensor, Resize = bilinear without antialiasing) on 21
+    config-1 obstacle lists; this test MEASURES the build's rule against it.  The rule models the geometry of that pipeline
+    (oracle/edage_np.py raster_geometry): the crop [53:383, 73:517] sits slightly inside matplotlib's axes box, so an output
+    pixel shows a data point displaced by up to ~1 % of R from its own centre, and the stroke inks 0.625 figure px beyond the
+    radius.  Measured: IoU 0.984-0.987 at R = 64 / 224 / 256 (0.94-0.97 for the plain "pixel centre in the disc" rule of rounds
+    1-2), 0.3 % of all pixels differ, of BOTH signs (no systematic bias left), every differing pixel within 2 px of a rim."""
     g = _load(golden_dir, "g15_plot_obstacles.npz")
     rows = []
     for c in range(int(g["ncase"][0])):
@@ -281,12 +283,26 @@ def test_disc_raster_deviation_from_reference_plot_obstacles(golden_dir, capsys)
         for cx, cy, r in obs:
             rim = np.minimum(rim, np.abs(np.sqrt((xx + 0.5 - cx) ** 2 + (yy + 0.5 - cy) ** 2) - r))
         rows.append((R, (ref & mine).sum() / (ref | mine).sum(), diff.mean(), rim.max() if len(rim) else 0.0, ref.sum() - mine.sum()))
+        # the plain rule of rounds 1-2, for the record: always the smaller discs
+        plain = np.zeros([R, R], bool)
+        for cx, cy, r in obs:
+            plain |= ((np.arange(R) + 0.5)[None, :] - cx) ** 2 + ((np.arange(R) + 0.5)[:, None] - cy) ** 2 <= r * r
+        assert (ref & mine).sum() / (ref | mine).sum() > (ref & plain).sum() / (ref | plain).sum()
     iou = np.array([r[1] for r in rows])
     with capsys.disabled():
         for R in (64, 224, 256):
             sel = [r for r in rows if r[0] == R]
             print(f"\n[A13 deviation] R={R}: IoU {min(r[1] for r in sel):.3f}-{max(r[1] for r in sel):.3f}, differing pixels "
                   f"{100 * max(r[2] for r in sel):.2f} % max, farthest from a rim {max(r[3] for r in sel):.2f} px", end="")
-    assert iou.min() > 0.93 and max(r[2] for r in rows) < 0.015
-    assert max(r[3] for r in rows) < 2.0 * max(1.0, 1.0)                      # rim-local: never a missing or extra disc
-    assert all(r[4] > 0 for r in rows)                                         # the reference's discs are the larger ones
+    assert iou.min() >= 0.98 and max(r[2] for r in rows) < 0.005
+    assert max(r[3] for r in rows) < 2.0                                       # rim-local: never a missing or extra disc
+    # no systematic bias: over the cases of each resolution the differing pixels are of both signs
+    for R in (64, 224, 256):
+        more = less = 0
+        for c in range(int(g["ncase"][0])):
+            if int(g[f"c{c}_R"][0]) != R:
+                continue
+            ref = np.unpackbits(g[f"c{c}_occ"])[:R * R].reshape(R, R).astype(bool)
+            mine = E.disc_raster(g[f"c{c}_obs"], R)
+            more += int((ref & ~mine).sum()); less += int((mine & ~ref).sum())
+        assert more > 0 and less > 0 and max(more, less) < 4 * min(more, less), (R, more, less)

@@ -3,8 +3,8 @@ import ctypes as C, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import ppnet_amd._lib as L
-tl = C.CDLL(os.path.join(ROOT, "ppnet_amd", "libppnet_hip_timing.so"))
-for n in ("ppn_edage_paths", "ppn_edage_paths_ex", "ppn_edage_maps"):
+tl = C.CDLL(os.environ.get("PPNET_TIMING_LIB") or os.path.join(ROOT, "ppnet_amd", "libppnet_hip_timing.so"))
+for n in ("ppn_edage_paths", "ppn_edage_paths_ex", "ppn_edage_paths_ex2", "ppn_edage_maps"):
     getattr(tl, n).argtypes = getattr(L.lib, n).argtypes
     getattr(tl, n).restype = C.c_int
 L.lib = tl
