@@ -17,6 +17,23 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(None)
 
 
+class WeightCache:
+    """A value derived from module parameters (a packed / folded / converted copy for a kernel), rebuilt whenever a source changes:
+    the key holds each source tensor's device, `_version` (bumped by every in-place update: optimizer.step, load_state_dict's
+    copy_) and `data_ptr` (a new storage after .to(dtype) / .to(device) or re-assignment).  An eval -> step -> eval flow therefore
+    never runs a kernel on stale weights."""
+    __slots__ = ("key", "value")
+
+    def __init__(self):
+        self.key = self.value = None
+
+    def get(self, sources, build, *extra):
+        key = tuple((t.device, t._version, t.data_ptr()) if t is not None else None for t in sources) + extra
+        if key != self.key:
+            self.value, self.key = build(), key
+        return self.value
+
+
 _PADDED = {}
 
 

@@ -143,8 +143,12 @@ class _FusedStage(nn.Module):
     def __init__(self, conv, slope):
         super().__init__()
         self.conv, self.slope = conv, slope
-        self._f32 = None                                  # (device, weight, bias) as float32 for the direct 1-channel kernel
-        self._s2 = None                                   # (device, packed weight, bias) for the MFMA stride-2 kernels
+        from .fused import WeightCache
+        self._f32 = WeightCache()                         # (weight, bias) as float32 for the direct 1-channel kernel
+        self._s2 = WeightCache()                          # (packed weight, bias) for the MFMA stride-2 kernels
+
+    def s2_pack(self):
+        return self._s2.get((self.conv.weight, self.conv.bias), lambda: pack_s2_weights(self.conv))
 
     def forward(self, x):
         c = self.conv
@@ -154,16 +158,14 @@ class _FusedStage(nn.Module):
                 and c.padding == (1, 1) and c.dilation == (1, 1)):
             # 1 -> dim at full resolution: the direct HIP kernel (ppn_conv3x3_c1_nhwc), bias + LeakyReLU inside
             from . import fused
-            if self._f32 is None or self._f32[0] != x.device:
-                self._f32 = (x.device, c.weight.detach().float().contiguous(), c.bias.detach().float().contiguous())
-            return fused.conv3x3_c1(x, self._f32[1], self._f32[2], self.slope)
+            w32, b32 = self._f32.get((c.weight, c.bias), lambda: (c.weight.detach().float().contiguous(), c.bias.detach().float().contiguous()))
+            return fused.conv3x3_c1(x, w32, b32, self.slope)
         import os
         if x.dtype == torch.bfloat16 and _is_s2_stage(c) and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0 and not os.environ.get("PPNET_LIBRARY_CONV"):
             # the 24-channel stride-2 stages: MFMA kernel with the weights in registers, bias + LeakyReLU in its epilogue
             from . import fused
-            if self._s2 is None or self._s2[0] != x.device:
-                self._s2 = (x.device,) + pack_s2_weights(c)
-            return fused.gennet_conv_s2(x, self._s2[1], self._s2[2], self.slope, isinstance(c, nn.ConvTranspose2d))
+            wp, bp = self.s2_pack()
+            return fused.gennet_conv_s2(x, wp, bp, self.slope, isinstance(c, nn.ConvTranspose2d))
         if isinstance(c, nn.ConvTranspose2d):
             y = F.conv_transpose2d(x, c.weight, None, c.stride, c.padding, c.output_padding, c.groups, c.dilation)
         else:
@@ -192,8 +194,10 @@ class AEViT(nn.Module):
         self.vit_blocks = nn.Sequential(*[_Block(dim, 3, 4, dpr[i]) for i in range(3)])
         self.dec_conv = nn.ModuleList(_stage(nn.ConvTranspose2d(dim, dim, 3, 2, 1, output_padding=1)) for _ in range(n_down))
         self.conv_final = nn.Conv2d(dim, out_channels, 3, 1, 1)
-        self._final_f32 = None                            # set by prepare_inference(): (device, float32 weight, float bias)
-        self._trunk = None                                # float32 parameter blocks of the fused ViT-trunk kernel (built on first use)
+        self._final_f32 = None                            # set by prepare_inference(): WeightCache of (float32 weight, float bias)
+        from .fused import WeightCache
+        self._trunk = WeightCache()                       # float32 parameter blocks of the fused ViT-trunk kernel
+        self._first_enc = WeightCache()                   # packed parameters of the fused first convolution + first encoder stage
 
     def prepare_inference(self):
         """After the checkpoint is loaded: fold every eval-mode BatchNorm into the (transposed) convolution in front of
@@ -211,11 +215,14 @@ class AEViT(nn.Module):
         self.conv_first = _FusedStage(self.conv_first[0], self.conv_first[2].negative_slope)
         self.enc_conv = nn.ModuleList(_FusedStage(st[0], st[2].negative_slope) for st in self.enc_conv)
         self.dec_conv = nn.ModuleList(_FusedStage(st[0], st[2].negative_slope) for st in self.dec_conv)
-        cf = self.conv_final
-        self._final_f32 = (None, cf.weight.detach().float().contiguous(), float(cf.bias.detach().float()[0]) if cf.bias is not None and cf.out_channels == 1 else 0.0)
+        from .fused import WeightCache
+        self._final_f32 = WeightCache()
         return self
 
-    _first_enc = None                                 # packed parameters of the fused first convolution + first encoder stage
+    def _final_pack(self):
+        cf = self.conv_final
+        return self._final_f32.get((cf.weight, cf.bias), lambda: (
+            cf.weight.detach().float().contiguous(), float(cf.bias.detach().float()[0]) if cf.bias is not None and cf.out_channels == 1 else 0.0))
 
     def _fused_first_stage(self, x):
         """Prepared bfloat16 inference: conv_first and enc_conv[0] as one kernel (ppn_gennet_first_enc_bf16), or None."""
@@ -230,9 +237,8 @@ class AEViT(nn.Module):
                 and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0):
             return None
         from . import fused
-        if self._first_enc is None or self._first_enc[0].device != x.device:
-            self._first_enc = pack_first_enc_weights(c1, c2)
-        return fused.gennet_first_enc(x, *self._first_enc, cf.slope, self.enc_conv[0].slope)
+        packs = self._first_enc.get((c1.weight, c1.bias, c2.weight, c2.bias), lambda: pack_first_enc_weights(c1, c2))
+        return fused.gennet_first_enc(x, *packs, cf.slope, self.enc_conv[0].slope)
 
     def forward(self, x):
         y = self._fused_first_stage(x)
@@ -250,9 +256,8 @@ class AEViT(nn.Module):
                 and self.vit_blocks[0].attn.num_heads == 3 and not os.environ.get("PPNET_LIBRARY_TRUNK")):
             # prepared bfloat16 inference: the three ViT blocks are one kernel (residual stream in registers, K / V in LDS)
             from . import fused
-            if self._trunk is None or self._trunk.device != x.device:
-                self._trunk = pack_trunk_params(self.vit_blocks).to(x.device)
-            x = fused.gennet_trunk(x.contiguous(memory_format=torch.channels_last), self._trunk, len(self.vit_blocks))
+            trunk = self._trunk.get(list(self.vit_blocks.parameters()), lambda: pack_trunk_params(self.vit_blocks).to(x.device))
+            x = fused.gennet_trunk(x.contiguous(memory_format=torch.channels_last), trunk, len(self.vit_blocks))
         else:
             t = self.vit_blocks(x.flatten(2).transpose(1, 2))                # feature2token / token2feature, base.py:43-52
             x = t.transpose(1, 2).reshape(B, C, H, W)
@@ -266,18 +271,15 @@ class AEViT(nn.Module):
             from . import fused
             for blk in self.dec_conv[:-1]:
                 x = blk(x)
-            if last._s2 is None or last._s2[0] != x.device:
-                last._s2 = (x.device,) + pack_s2_weights(last.conv)
-            if self._final_f32[0] != x.device:
-                self._final_f32 = (x.device, c.weight.detach().float().contiguous().to(x.device), self._final_f32[2])
-            return fused.gennet_dec_final(x, last._s2[1], last._s2[2], last.slope, self._final_f32[1], self._final_f32[2])
+            wp, bp = last.s2_pack()
+            wf, bf = self._final_pack()
+            return fused.gennet_dec_final(x, wp, bp, last.slope, wf, bf)
         for blk in self.dec_conv:
             x = blk(x)
         if x.is_cuda and self._final_f32 is not None and c.out_channels == 1 and c.in_channels % 8 == 0 and c.in_channels <= 32:
             from . import fused                                               # dim -> 1 at full resolution: direct HIP kernel
-            if self._final_f32[0] != x.device:
-                self._final_f32 = (x.device, c.weight.detach().float().contiguous().to(x.device), self._final_f32[2])
-            return fused.conv3x3_to1(x, self._final_f32[1], self._final_f32[2])
+            wf, bf = self._final_pack()
+            return fused.conv3x3_to1(x, wf, bf)
         return c(x)
 
 

@@ -57,7 +57,7 @@ class ConvTokenizer(nn.Module):
         x = self.proj(x.contiguous(memory_format=torch.channels_last)).permute(0, 2, 3, 1)
         return fused.layer_norm(x, self.norm) if self.norm is not None else x
 
-    _codes = None         # (lut, second convolution's bias as float32) for forward_codes, built on first use
+    _codes = None         # WeightCache of (lut, second convolution's bias as float32, packed second conv, vectors) for forward_codes
 
     def takes_codes(self, grid_u8):
         c0, c1 = self.proj[0], self.proj[1]
@@ -70,11 +70,13 @@ class ConvTokenizer(nn.Module):
         convolution is a table product on the matrix cores (ppn_tokenizer_conv1_codes_bf16), the second convolution runs
         without its bias, which the LayerNorm kernel adds in registers — the normalised image and two bias passes are
         never written."""
-        c1 = self.proj[1]
-        if self._codes is None or self._codes[0].device != grid_u8.device:
-            self._codes = (fused.tokenizer_lut(self.proj[0], IMG_MEAN, IMG_STD).to(grid_u8.device),
-                           c1.bias.detach().float().contiguous()) + fused.tokenizer_pack(c1, self.norm)
-        lut, b2, w2p, vec = self._codes
+        c0, c1 = self.proj[0], self.proj[1]
+        if self._codes is None:
+            self._codes = fused.WeightCache()
+        lut, b2, w2p, vec = self._codes.get(
+            (c0.weight, c0.bias, c1.weight, c1.bias, self.norm.weight, self.norm.bias),
+            lambda: (fused.tokenizer_lut(c0, IMG_MEAN, IMG_STD).to(grid_u8.device), c1.bias.detach().float().contiguous())
+            + fused.tokenizer_pack(c1, self.norm))
         if (c1.weight.shape == (128, 64, 3, 3) and grid_u8.shape[1] % 4 == 0 and grid_u8.shape[2] % 64 == 0
                 and not os.environ.get("PPNET_TOKENIZER_TWO_KERNELS")):
             # both convolutions and the LayerNorm in one kernel (ppn_tokenizer_codes_bf16): no library convolution, no intermediate
@@ -90,13 +92,14 @@ class ConvDownsampler(nn.Module):
         self.reduction = nn.Conv2d(dim, 2 * dim, 3, 2, 1, bias=False)
         self.norm = norm_layer(2 * dim)
 
-    _mfma = None          # (weight [2C,3,3,C] bf16, zero bias float32) for the MFMA implicit-GEMM kernel, built on first use
+    _mfma = None          # WeightCache of (weight [2C,3,3,C] bf16, zero bias float32) for the MFMA implicit-GEMM kernel
 
     def forward(self, x):                      # x [B,H,W,C] contiguous == a channels_last [B,C,H,W] view: no layout copies
         if _use_mfma_conv(x, self.reduction):
-            if self._mfma is None or self._mfma[0].device != x.device:
-                self._mfma = _mfma_weights(self.reduction)
-            y = fused.conv3x3_mfma(x.permute(0, 3, 1, 2), self._mfma[0], self._mfma[1], stride=2, relu=False)
+            if self._mfma is None:
+                self._mfma = fused.WeightCache()
+            w, b = self._mfma.get((self.reduction.weight,), lambda: _mfma_weights(self.reduction))
+            y = fused.conv3x3_mfma(x.permute(0, 3, 1, 2), w, b, stride=2, relu=False)
             return fused.layer_norm(y.permute(0, 2, 3, 1), self.norm)
         return fused.layer_norm(self.reduction(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1), self.norm)
 
@@ -385,15 +388,17 @@ class SETRUPHead(nn.Module):
         """Prepared bfloat16 inference on the hand-written MFMA kernels: every ConvModule is one implicit-GEMM launch with the
         folded-BatchNorm bias and the ReLU in its epilogue, and the last one also applies the 1x1 classifier (commuted in front
         of the last up-sampling, as in forward()) so the 512-channel activation at the highest resolution is never written."""
-        if self._mfma is None or self._mfma[0][0].device != x.device:
-            cs = self.conv_seg
-            self._mfma = [_mfma_weights(up[0].conv) for up in self.up_convs] + \
-                         [(cs.weight.detach().float().reshape(cs.out_channels, -1).contiguous(), cs.bias.detach().float().contiguous())]
+        if self._mfma is None:
+            self._mfma = fused.WeightCache()
+        cs = self.conv_seg
+        src = [t for up in self.up_convs for t in (up[0].conv.weight, up[0].conv.bias)] + [cs.weight, cs.bias]
+        packs = self._mfma.get(src, lambda: [_mfma_weights(up[0].conv) for up in self.up_convs] +
+                               [(cs.weight.detach().float().reshape(cs.out_channels, -1).contiguous(), cs.bias.detach().float().contiguous())])
         for i, up in enumerate(self.up_convs[:-1]):
-            x = up[1](fused.conv3x3_mfma(x, self._mfma[i][0], self._mfma[i][1], stride=1, relu=True))
-        w2, b2 = self._mfma[-1]
+            x = up[1](fused.conv3x3_mfma(x, packs[i][0], packs[i][1], stride=1, relu=True))
+        w2, b2 = packs[-1]
         n = len(self.up_convs) - 1
-        lo = fused.conv3x3_relu_classify2(x, self._mfma[n][0], self._mfma[n][1], w2, b2).to(x.dtype).contiguous()
+        lo = fused.conv3x3_relu_classify2(x, packs[n][0], packs[n][1], w2, b2).to(x.dtype).contiguous()
         return lo if lowres else self.up_convs[-1][1](lo)
 
 

@@ -4,8 +4,9 @@ Reference: GenNet/train.py:93-147 + GenNet/utils/train_and_eval.py:24-46 (AdamW(
 decay), MSE between the network output and mask_path, PolyLR stepped every iteration, GenNet/utils/scheduler.py:3-12);
 SegNet/mmseg/apis/train.py:67-167 + SegNet/configs/nat/setr_up_nat_base.py:46-56 (SGD lr 0.08, momentum 0.9, no weight decay,
 decode-head parameters at 10x the rate, poly schedule with power 1 and a 1500-iteration linear warm-up from ratio 1e-6,
-cross-entropy of the decode head's logits resized to the label map, mmseg/models/segmentors/encoder_decoder.py:81-93 and
-decode_heads/decode_head.py:209-237; MMDistributedDataParallel = gradient all-reduce averaged over the ranks).
+cross-entropy of the decode head's logits resized to the label map plus 0.4 x the auxiliary FCN head's on level 2,
+mmseg/models/segmentors/encoder_decoder.py:81-152, decode_heads/decode_head.py:209-237, fcn_head.py; SyncBN in the heads;
+MMDistributedDataParallel = gradient all-reduce averaged over the ranks).
 
 What is native here: the training PAIRS come straight from the generator kernels on the device (stage A/B + ppn_label_masks:
 mask_space / mask_path / the rendered map — the reference re-reads them from image files, my_dataset.py:30-76), the
@@ -82,9 +83,23 @@ def generator_pairs(paths, maps, placements, bound=None):
     return maps.grid, mask_space, mask_path
 
 
+def assert_trainable(model):
+    """The prepared inference forms (AEViT.prepare_inference: _FusedStage; SegNet.prepare_inference / NATBlock.fold: BatchNorm and
+    LayerScale folded into the weights, forward-only fused kernels) cannot be trained: say so instead of failing inside autograd
+    or dropping gradients silently.  PPNet() always prepares its networks — train fresh AEViT / SegNet modules."""
+    from .gennet import _FusedStage
+    from .segnet import NATLayer
+    m = model.module if isinstance(model, nn.parallel.DistributedDataParallel) else model
+    for sub in m.modules():
+        if isinstance(sub, _FusedStage) or (isinstance(sub, NATLayer) and sub.folded) or getattr(sub, "prepared", False):
+            raise RuntimeError(f"{type(sub).__name__} is in its prepared inference form (forward-only kernels, folded weights): "
+                               "build a fresh module (and load the checkpoint) to train")
+
+
 def gennet_train_step(model, optimizer, scheduler, mask_space, mask_path, amp_dtype=None):
     """One iteration of train_one_epoch (train_and_eval.py:24-46): input = mask_space as {0,1} floats (ToTensor * 255 of the
     palette image, my_dataset.py:8-16), target = mask_path / 255.  Returns the loss (a 0-d tensor, not synchronised)."""
+    assert_trainable(model)
     model.train()
     x = mask_space.to(torch.float32).unsqueeze(1)
     target = (mask_path.to(torch.float32) / 255.0)
@@ -100,12 +115,15 @@ def gennet_train_step(model, optimizer, scheduler, mask_space, mask_path, amp_dt
 
 
 class _SegTrain(nn.Module):
-    """forward = the training loss, so DistributedDataParallel sees one forward per step."""
+    """forward = the training loss, so DistributedDataParallel sees one forward per step: the sum of the `loss_ce` entries of
+    SegNet.forward_train (encoder_decoder.py:122-152; mmseg's _parse_losses sums every key containing 'loss', base.py:160-190) —
+    the decode head's cross-entropy plus, where the config has one (configs/nat/setr_up_nat_base.py:39-42 over
+    _base_/models/nat.py:22-35), 0.4 x the auxiliary FCN head's on level 2."""
 
     def __init__(self, segnet):
         super().__init__()
         self.net = segnet
-        # output norms of levels the head does not read are never evaluated (SegNet narrows compute_indices): freeze them, or
+        # output norms of levels no head reads are never evaluated (SegNet narrows compute_indices): freeze them, or
         # DistributedDataParallel would wait for gradients that never come
         bb = segnet.backbone
         for i in getattr(bb, "out_indices", ()):
@@ -113,13 +131,19 @@ class _SegTrain(nn.Module):
                 getattr(bb, f"norm{i}").requires_grad_(False)
 
     def forward(self, img, labels):
-        logits = self.net.decode_head(self.net.backbone(img))
-        logits = F.interpolate(logits.float(), labels.shape[-2:], mode="bilinear", align_corners=self.net.align_corners)
-        return F.cross_entropy(logits, labels.long(), ignore_index=255)
+        losses = self.net.forward_train(img, None, labels)
+        return sum(v for k, v in losses.items() if "loss" in k)
 
 
-def segnet_trainer(segnet, device=None, bucket_cap_mb=128):
-    """The module to call as loss = trainer(img, labels): SegNet wrapped for data-parallel training."""
+def segnet_trainer(segnet, device=None, bucket_cap_mb=128, sync_bn=True):
+    """The module to call as loss = trainer(img, labels): SegNet wrapped for data-parallel training.  Under an initialised
+    process group of more than one rank the heads' BatchNorm layers become SyncBatchNorm first, as the reference's norm_cfg
+    `SyncBN` does under MMDistributedDataParallel (configs/_base_/models/nat.py:2, SegNet/train.py:179-185 reverts it to BN
+    only for non-distributed runs): batch statistics are all-reduced, so every rank holds the same running statistics."""
+    import torch.distributed as dist
+    assert_trainable(segnet)
+    if sync_bn and dist.is_initialized() and dist.get_world_size() > 1 and (device is None or torch.device(device).type == "cuda"):
+        segnet = nn.SyncBatchNorm.convert_sync_batchnorm(segnet)               # (SyncBatchNorm has no CPU / gloo implementation)
     return data_parallel(_SegTrain(segnet), device, bucket_cap_mb)
 
 

@@ -110,3 +110,86 @@ def test_rccl_group_of_one_data_parallel_step():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_segnet_training_with_the_auxiliary_head():
+    """The reference's NAT training config (configs/nat/setr_up_nat_base.py:39-42 over _base_/models/nat.py:22-35) adds an FCN
+    auxiliary head on level 2 with loss weight 0.4: the step's loss is decode + 0.4 x aux, level 2's output norm stays live, the
+    auxiliary head sits in the 10x 'head' parameter group, and every parameter receives a gradient."""
+    from ppnet_amd import train
+    from ppnet_amd.segnet import SegNet
+    import torch.nn.functional as F
+    grid, space, path = _pairs(128, 2, 2, seed=7)
+    torch.manual_seed(2)
+    aux = dict(type="FCNHead", in_channels=128, in_index=2, channels=32, num_convs=1, concat_input=False, dropout_ratio=0.1,
+               num_classes=2, align_corners=False, loss_decode=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=0.4))
+    net = SegNet(**TINY_SEG, auxiliary_head=aux).cuda()
+    assert net.backbone.compute_indices == (2, 3)
+    trainer = train.segnet_trainer(net)
+    opt = train.segnet_optimizer(trainer, lr=0.02)
+    head_group = {id(p) for p in opt.param_groups[1]["params"]}
+    assert all(id(p) in head_group for p in net.auxiliary_head.parameters()) and opt.param_groups[1]["lr"] == pytest.approx(0.2)
+    l0 = float(train.segnet_train_step(trainer, opt, 0, 40, grid, space, schedule=dict(warmup_iters=0)))
+    missing = [n for n, p in net.named_parameters() if p.requires_grad and p.grad is None]
+    assert not missing, missing
+    frozen = sorted(n for n, p in net.named_parameters() if not p.requires_grad)
+    assert frozen == sorted(f"backbone.norm{i}.{w}" for i in (0, 1) for w in ("weight", "bias")), frozen
+    # the loss is the weighted sum of the two heads' cross-entropies (same dropout masks: eval mode for the check)
+    net.eval()
+    with torch.no_grad():
+        from ppnet_amd import fused
+        from ppnet_amd.segnet import IMG_MEAN, IMG_STD
+        img = fused.grid_to_image(grid, IMG_MEAN, IMG_STD, torch.float32)
+        d = net.forward_train(img, None, space)
+        feats = net.backbone(img)
+        ce = lambda head: F.cross_entropy(F.interpolate(head(feats).float(), space.shape[-2:], mode="bilinear", align_corners=False), space.long())
+        assert float(d["decode.loss_ce"]) == pytest.approx(float(ce(net.decode_head)), rel=1e-4)
+        assert float(d["aux.loss_ce"]) == pytest.approx(0.4 * float(ce(net.auxiliary_head)), rel=1e-4)
+    assert l0 > 0
+    losses = [float(train.segnet_train_step(trainer, opt, it, 40, grid, space, schedule=dict(warmup_iters=0))) for it in range(1, 10)]
+    assert losses[-1] < l0, (l0, losses)
+
+
+def test_prepared_networks_refuse_to_train_and_caches_follow_the_weights():
+    """(1) PPNet's prepared networks run forward-only kernels on folded weights: a training step on them raises a clear error.
+    (2) Packed-weight caches are keyed on the parameters' version / storage: a bf16 eval forward, an in-place weight update (what
+    optimizer.step / load_state_dict do), a second eval forward — the MFMA paths (tokenizer codes, downsampler, head) agree with
+    the library paths (PPNET_LIBRARY_CONV / PPNET_LIBRARY_TOKENIZER) on the NEW weights."""
+    from ppnet_amd import train
+    from ppnet_amd.gennet import AEViT
+    from ppnet_amd.segnet import DINAT_BASE, SegNet
+    gen = AEViT(1, 1, img_resolution=64, dim=24).cuda().eval().prepare_inference()
+    with pytest.raises(RuntimeError, match="prepared inference form"):
+        train.gennet_train_step(gen, None, None, torch.zeros(2, 64, 64, device="cuda"), torch.zeros(2, 64, 64, device="cuda"))
+    seg = SegNet(**TINY_SEG).cuda().eval().prepare_inference()
+    with pytest.raises(RuntimeError, match="prepared inference form"):
+        train.segnet_trainer(seg)
+    # caches: DiNAT-B's own widths (the MFMA kernels serve 64 -> 128 tokenizer, C % 64 downsamplers, 512-channel head) at a small size
+    torch.manual_seed(5)
+    cfg = dict(backbone=dict(DINAT_BASE["backbone"], depths=[1, 1, 1, 1], dilations=[[1], [1], [1], [1]]), decode_head=DINAT_BASE["decode_head"])
+    net = SegNet(**cfg).cuda().eval().prepare_inference().to(torch.bfloat16)
+    g = (torch.rand(2, 64, 64, device="cuda") > 0.3).to(torch.uint8) * 255
+
+    def lowres(library):
+        for k in ("PPNET_LIBRARY_CONV", "PPNET_LIBRARY_TOKENIZER"):
+            os.environ.pop(k, None)
+            if library:
+                os.environ[k] = "1"
+        try:
+            with torch.no_grad():
+                from ppnet_amd import fused
+                from ppnet_amd.segnet import IMG_MEAN, IMG_STD
+                x = fused.grid_to_image(g, IMG_MEAN, IMG_STD, torch.bfloat16) if library else g
+                return net.decode_head(net.backbone(x), lowres=True).float()
+        finally:
+            for k in ("PPNET_LIBRARY_CONV", "PPNET_LIBRARY_TOKENIZER"):
+                os.environ.pop(k, None)
+    a0, b0 = lowres(False), lowres(True)
+    scale = b0.abs().mean().item()
+    assert (a0 - b0).abs().mean().item() < 0.05 * scale
+    with torch.no_grad():                                                      # an optimizer step's worth of in-place change
+        for p in net.parameters():
+            p.mul_(1.0 + 0.25 * torch.randn_like(p.float()).to(p.dtype))
+    a1, b1 = lowres(False), lowres(True)
+    assert (b1 - b0).abs().mean().item() > 0.2 * scale                         # the weights did change the output
+    assert (a1 - b1).abs().mean().item() < 0.05 * b1.abs().mean().item()       # and the MFMA paths followed them

@@ -341,3 +341,136 @@ def test_nat_upernet_vs_fp64_composition():
     assert want.shape == (2, 2, 128, 128) and float(want.std()) > 1e-3
     assert float((got - want).abs().max()) < 2e-3 * scale
     assert float((got_f - want).abs().max()) < 2e-3 * scale
+
+
+# ------------------------------------------------------------------ the reference's calling convention (mmseg)
+def _reference_dinat_base_cfg():
+    """configs/_base_/models/dinat.py:2-46 merged with configs/dinat/dinat_base.py:5-24 the way mmcv merges `_base_` files
+    (dict values update key by key), as plain data."""
+    norm_cfg = dict(type='SyncBN', requires_grad=True)
+    return dict(
+        type='EncoderDecoder', pretrained=None,
+        backbone=dict(type='DiNAT', embed_dim=128, mlp_ratio=2.0, depths=[3, 4, 18, 5], num_heads=[4, 8, 16, 32], drop_path_rate=0.5,
+                      kernel_size=7, layer_scale=1e-5,
+                      dilations=[[1, 16, 1], [1, 4, 1, 8], [1, 2, 1, 3, 1, 4, 1, 2, 1, 3, 1, 4, 1, 2, 1, 3, 1, 4], [1, 2, 1, 2, 1]],
+                      out_indices=(0, 1, 2, 3), qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., in_patch_size=4,
+                      frozen_stages=-1),
+        decode_head=dict(type='SETRUPHead', norm_layer=dict(type='LN', eps=1e-6, requires_grad=True), num_convs=4, up_scale=2,
+                         kernel_size=3,
+                         init_cfg=[dict(type='Constant', val=1.0, bias=0, layer='LayerNorm'),
+                                   dict(type='Normal', std=0.01, override=dict(name='conv_seg'))],
+                         in_channels=1024, channels=512, in_index=-1, num_classes=2, norm_cfg=norm_cfg, align_corners=False,
+                         loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)),
+        train_cfg=dict(), test_cfg=dict(mode='whole'))
+
+
+def test_from_config_builds_the_reference_models():
+    from ppnet_amd.segnet import FCNHead, SegNet
+    m = SegNet.from_config(_reference_dinat_base_cfg())
+    assert sorted(m.state_dict()) == sorted(SegNet().state_dict())                # same modules as the built-in DINAT_BASE
+    assert m.backbone.compute_indices == (3,) and m.auxiliary_head is None and m.test_cfg == {"mode": "whole"}
+    assert [b.drop_path_rate for b in m.backbone.levels[0].blocks][0] == 0.0 and m.backbone.levels[3].blocks[-1].drop_path_rate == 0.5
+    # configs/nat/setr_up_nat_base.py:6-42 over _base_/models/nat.py:3-38: NAT backbone, five SETR-UP stages, FCN auxiliary head
+    norm_cfg = dict(type='SyncBN', requires_grad=True)
+    cfg = dict(model=dict(
+        type='EncoderDecoder', pretrained=None,
+        backbone=dict(type='NAT', embed_dim=128, mlp_ratio=2.0, depths=[3, 4, 18, 5], num_heads=[4, 8, 16, 32], drop_path_rate=0.5,
+                      kernel_size=7, layer_scale=1e-5, out_indices=(0, 1, 2, 3), qkv_bias=True, qk_scale=None, drop_rate=0.,
+                      attn_drop_rate=0., in_patch_size=4, frozen_stages=-1),
+        decode_head=dict(type='SETRUPHead', norm_layer=dict(type='LN', eps=1e-6, requires_grad=True), num_convs=5, up_scale=2,
+                         kernel_size=3, in_channels=1024, channels=512, in_index=-1, num_classes=2, norm_cfg=norm_cfg,
+                         align_corners=False, loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)),
+        auxiliary_head=dict(type='FCNHead', in_channels=512, in_index=2, channels=256, num_convs=1, concat_input=False,
+                            dropout_ratio=0.1, num_classes=2, norm_cfg=norm_cfg, align_corners=False,
+                            loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=0.4)),
+        train_cfg=dict(), test_cfg=dict(mode='whole')))
+    m = SegNet.from_config(cfg)
+    assert isinstance(m.auxiliary_head, FCNHead) and m.auxiliary_head.loss_weight == 0.4
+    assert m.backbone.compute_indices == (2, 3)                                    # the auxiliary head reads level 2 while it trains
+    sd = m.state_dict()
+    assert sd["auxiliary_head.convs.0.conv.weight"].shape == (256, 512, 3, 3) and "auxiliary_head.convs.0.bn.running_mean" in sd
+    assert sd["auxiliary_head.conv_seg.weight"].shape == (2, 256, 1, 1) and "auxiliary_head.conv_cat.conv.weight" not in sd
+    assert len(m.decode_head.up_convs) == 5 and all(b.attn.dilation == 1 for lvl in m.backbone.levels for b in lvl.blocks)
+    m.prepare_inference()
+    assert m.backbone.compute_indices == (3,)                                      # a training-time branch: not evaluated at inference
+    with pytest.raises(NotImplementedError):
+        SegNet.from_config(dict(type='CascadeEncoderDecoder', backbone={}, decode_head={}))
+    with pytest.raises(NotImplementedError):
+        SegNet.from_config(dict(_reference_dinat_base_cfg(), test_cfg=dict(mode='slide', crop_size=(64, 64), stride=(32, 32))))
+
+
+class _Meta:
+    """Stand-in for mmcv's DataContainer around img_metas (mmseg/apis/test.py:97: `data['img_metas'][0].data[0]`)."""
+
+    def __init__(self, metas):
+        self.data = [metas]
+
+
+def test_forward_is_the_mmseg_harness_call_on_cpu():
+    """`result = model(return_loss=False, **data)` with data = {'img': [x], 'img_metas': [[meta, ...]]} exactly as
+    single_gpu_test calls it (mmseg/apis/test.py:89-95), on the CPU: the network itself is GPU-only, so encode_decode is replaced
+    by a fixed logit function of the image and the harness logic — nesting, rescale to ori_shape, flip, softmax / argmax, the
+    list of int64 arrays, the type errors of base.py:76-84 — is what is checked."""
+    import torch.nn.functional as F
+    from ppnet_amd.segnet import SegNet
+    m = SegNet(backbone=dict(embed_dim=16, mlp_ratio=2.0, depths=[1, 1, 1, 1], num_heads=[1, 1, 2, 4], kernel_size=7),
+               decode_head=dict(in_channels=128, channels=16, num_convs=2, up_scale=2, num_classes=2)).eval()
+
+    def fake_logits(img):
+        s = F.avg_pool2d(img.float().mean(1, keepdim=True), 3, 1, 1)
+        return torch.cat([s, -s], dim=1)
+    m.encode_decode = fake_logits
+    torch.manual_seed(0)
+    x = torch.randn(3, 3, 32, 32)
+    meta = dict(ori_shape=(32, 32, 3), img_shape=(32, 32, 3), pad_shape=(32, 32, 3), scale_factor=1.0, flip=False)
+    data = dict(img=[x], img_metas=[[meta] * 3])
+    result = m(return_loss=False, **data)
+    assert isinstance(result, list) and len(result) == 3
+    want = fake_logits(x).softmax(1).argmax(1).numpy()
+    for r, w in zip(result, want):
+        assert isinstance(r, np.ndarray) and r.dtype == np.int64 and r.shape == (32, 32) and np.array_equal(r, w)
+    assert np.array_equal(np.stack(m(return_loss=False, img=[x], img_metas=[_Meta([meta] * 3)])), want)     # DataContainer form
+    # rescale to ori_shape (whole_inference, encoder_decoder.py:200-217)
+    meta48 = dict(meta, ori_shape=(48, 40, 3))
+    r48 = m(return_loss=False, img=[x], img_metas=[[meta48] * 3])
+    assert r48[0].shape == (48, 40)
+    w48 = F.interpolate(fake_logits(x), (48, 40), mode="bilinear", align_corners=False).softmax(1).argmax(1).numpy()
+    assert np.array_equal(np.stack(r48), w48)
+    # flip augmentation: probabilities flipped back and averaged with the plain pass (aug_test, encoder_decoder.py:267-285)
+    metaf = dict(meta, flip=True, flip_direction="horizontal")
+    ra = m(return_loss=False, img=[x, x.flip(3)], img_metas=[[meta] * 3, [metaf] * 3])
+    p = (fake_logits(x).softmax(1) + fake_logits(x.flip(3)).softmax(1).flip(3)) / 2
+    assert np.array_equal(np.stack(ra), p.argmax(1).numpy())
+    # the batched tensor form of this build is unchanged
+    assert torch.equal(m(x), torch.from_numpy(want))
+    with pytest.raises(TypeError):
+        m(return_loss=False, img=x, img_metas=[[meta] * 3])
+    with pytest.raises(TypeError):
+        m.forward_test(x, [[meta]])
+    with pytest.raises(ValueError):
+        m(return_loss=False, img=[x, x], img_metas=[[meta] * 3])
+
+
+@pytest.mark.gpu
+def test_mmseg_call_equals_labels_u8_on_gpu():
+    """DiNAT + SETR-UP on the GPU under the harness call: the list of int64 label maps equals labels_u8 (the fused tail), and the
+    generic path (logits -> softmax -> argmax) agrees with it wherever the two classes are not tied to the last bf16 bit."""
+    from ppnet_amd.segnet import SegNet
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    m = SegNet(backbone=dict(embed_dim=32, mlp_ratio=2.0, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], kernel_size=7,
+                             dilations=[[1, 2], [1, 2], [1, 2], [1, 1]], layer_scale=1e-5),
+               decode_head=dict(in_channels=256, channels=32, num_convs=4, up_scale=2, num_classes=2)).to(dev).eval()
+    x = torch.randn(4, 3, 64, 64, device=dev)
+    meta = dict(ori_shape=(64, 64, 3), img_shape=(64, 64, 3), pad_shape=(64, 64, 3), scale_factor=1.0, flip=False)
+    res = m(return_loss=False, img=[x], img_metas=[[meta] * 4])
+    assert isinstance(res, list) and len(res) == 4 and all(r.dtype == np.int64 and r.shape == (64, 64) for r in res)
+    assert np.array_equal(np.stack(res), m.labels_u8(x).cpu().numpy().astype(np.int64))
+    prob = m.inference(x, [meta] * 4, True)
+    assert (torch.from_numpy(np.stack(res)).to(dev) == prob.argmax(1)).float().mean().item() > 0.995
+    # forward_train: the loss dict of encoder_decoder.py:122-152
+    with torch.enable_grad():
+        m.train()
+        losses = m(img=x, img_metas=[meta] * 4, gt_semantic_seg=torch.randint(0, 2, (4, 1, 64, 64), device=dev))
+        assert set(losses) == {"decode.loss_ce", "decode.acc_seg"} and losses["decode.loss_ce"].requires_grad
+        losses["decode.loss_ce"].backward()

@@ -114,3 +114,18 @@ def test_two_ranks_gloo_step_equals_averaged_gradients(tmp_path):
     assert float(r0["loss"]) == pytest.approx(float(losses[0]), rel=1e-6) and float(r1["loss"]) == pytest.approx(float(losses[1]), rel=1e-6)
     for p, q in zip(net.parameters(), r0["params"]):
         assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), float((p - q).abs().max())
+
+
+def test_assert_trainable_names_prepared_modules():
+    """train.assert_trainable: fresh modules pass, prepared / folded ones raise (they run forward-only kernels on folded weights)."""
+    from ppnet_amd import train
+    from ppnet_amd.gennet import AEViT
+    from ppnet_amd.segnet import SegNet
+    tiny = dict(backbone=dict(embed_dim=16, mlp_ratio=2.0, depths=[1, 1, 1, 1], num_heads=[1, 1, 2, 4], kernel_size=7, layer_scale=1e-5),
+                decode_head=dict(in_channels=128, channels=16, num_convs=2, up_scale=2, num_classes=2))
+    train.assert_trainable(AEViT(1, 1, img_resolution=64, dim=24))
+    train.assert_trainable(SegNet(**tiny))
+    with pytest.raises(RuntimeError):
+        train.assert_trainable(AEViT(1, 1, img_resolution=64, dim=24).eval().prepare_inference())
+    with pytest.raises(RuntimeError):
+        train.assert_trainable(SegNet(**tiny).eval().prepare_inference())

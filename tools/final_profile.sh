@@ -3,11 +3,15 @@
 # maps kernel, PPNet per-kernel breakdown, matrix-pipe counters of the MFMA kernels, NA kernel counters.
 # Outputs land in gpurun_out/final/; copy the summaries to profiles/ (tools/final_profile.sh TAG names them).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$PWD; OUT=$ROOT/gpurun_out/final; mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+# the driver's exact round-end command, for a like-for-like comparison with BENCH_rNN.json — plain and under the kernel tracer
+python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err
 cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ksd -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ppnet > $OUT/ksd.log 2>&1
+cp $(find /tmp/ksd -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_driver_cmd.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 $ROOT/bench.py --no-cpu-baseline --no-ppnet > $OUT/ks.log 2>&1
 cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ppnet > $OUT/pf.log 2>&1
