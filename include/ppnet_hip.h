@@ -421,6 +421,25 @@ int ppn_nat128_ln_mlp_add_bf16(void* s, const float* offset, const void* ln_w, c
 int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int32_t N, int32_t K, int32_t epilogue,
                   int32_t persistent_blocks, void* stream);
 
+/* The dense half of a NAT layer at C = 256 / 512 / 1024 with everything between two projections in the GEMMs' epilogues
+ * (SegNet/nat.py:62-85 `Mlp.forward`, :140-153 `NATLayer.forward`; csrc/nat_gemm.hip).  a [M][K], w [N][K] (torch Linear
+ * layout), c [M][N], all bfloat16; M, N % 256 == 0, K % 64 == 0.
+ *   mode 0: c = LN(a) w0^T + b0 computed from the RAW rows of a: the caller passes w = w0 diag(gamma), bias = b0 + w0 beta,
+ *           colsum[n] = sum_k w[n][k] (of the bfloat16 values), and stats_in [partials_in][M][2] = partial (sum, sum of squares) of
+ *           every row of a (1 <= partials_in <= 4, summed in order; the LayerNorm is over the K features, eps as given):
+ *           c = rstd (a w^T - mean colsum) + bias.  K >= 192.
+ *   mode 1: c = gelu(mode 0) (erf form; evaluated through a logistic fit of erf, |error| < 3e-5).
+ *   mode 2: c += a w^T + bias IN PLACE, and stats_out [N / 256][M][2] receives, per 256-column tile, (sum, sum of squares) of every
+ *           row of the NEW c over the tile's columns — of the bfloat16 values stored: what mode 0 / 1 of the next projection
+ *           reads as stats_in with partials_in = N / 256.  colsum / stats_in unused.
+ * Persistent: one workgroup per CU; bit-reproducible (no atomics). */
+int ppn_nat_gemm_bf16(const void* a, const void* w, const float* bias, const float* colsum, const float* stats_in, int32_t partials_in,
+                      float* stats_out, void* c, int64_t M, int32_t N, int32_t K, int32_t mode, float eps, void* stream);
+
+/* stats[rows][2] = (sum, sum of squares) of every row of the bfloat16 tensor x [rows][C], C % 8 == 0 in [64, 1024]: the
+ * stats_in (partials_in = 1) of a level's first projection, whose input no mode-2 GEMM produced. */
+int ppn_row_stats_bf16(const void* x, int64_t rows, int32_t C, float* stats, void* stream);
+
 /* PIL.Image.resize(size, BILINEAR) for 8-bit single-channel images, bit-exact: Pillow's ImagingResample
  * (support = max(scale,1), 22-bit fixed-point coefficients, horizontal pass then vertical pass, each rounded
  * to 8 bits).  Used by extract_path's down-sampling (process_map.py:301).  in [n][H][W], tmp [n][H][outW],

@@ -573,6 +573,28 @@ int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int6
     return PPN_OK;
 }
 
+int ppn_nat_gemm_bf16(const void* a, const void* w, const float* bias, const float* colsum, const float* stats_in, int32_t partials_in,
+                      float* stats_out, void* c, int64_t M, int32_t N, int32_t K, int32_t mode, float eps, void* stream) {
+    if (!a || !w || !c || !bias || M <= 0 || M >= (1LL << 31) || (M % 256) != 0 || N <= 0 || (N % 256) != 0 || K < 64 || (K % 64) != 0 ||
+        mode < 0 || mode > 2)
+        return PPN_E_INVALID;
+    if (mode != 2 && (!colsum || !stats_in || partials_in < 1 || partials_in > 4 || K / 64 < 3)) return PPN_E_INVALID;
+    if (mode == 2 && !stats_out) return PPN_E_INVALID;
+    if ((long long)N * 2 * 8 >= (1LL << 31) || (long long)K * 2 * 8 >= (1LL << 31)) return PPN_E_UNSUPPORTED;     // per-lane 32-bit offsets
+    const int e = ppn::nat_gemm_launch(a, w, bias, colsum, stats_in, partials_in, stats_out, c, M, N, K, mode, eps, (hipStream_t)stream);
+    if (e == -2) return hip_fail(hipErrorInvalidDevice);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
+int ppn_row_stats_bf16(const void* x, int64_t rows, int32_t C, float* stats, void* stream) {
+    if (!x || !stats || rows < 0 || C < 64 || C > 1024 || (C % 8) != 0) return PPN_E_INVALID;
+    if (rows == 0) return PPN_OK;
+    const int e = ppn::row_stats_launch(x, rows, C, stats, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_resize_bilinear_u8(const uint8_t* in, int32_t n, int32_t H, int32_t W, int32_t outH, int32_t outW, uint8_t* tmp,
                            uint8_t* out, void* stream) {
     if (!in || n < 0 || H <= 0 || W <= 0 || outH <= 0 || outW <= 0 || !tmp || !out) return PPN_E_INVALID;

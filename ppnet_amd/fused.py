@@ -366,6 +366,46 @@ def gemm_bf16(a, w, bias32, epilogue="bias", out=None, persistent_blocks=0):
     return out
 
 
+def nat_gemm(a, w, bias32, mode, out, colsum=None, stats_in=None, stats_out=None, eps=1e-5):
+    """The NAT projections with the LayerNorm / residual / statistics in the epilogue (ppn_nat_gemm_bf16, csrc/nat_gemm.hip).
+    mode "ln": out = LN(a) W0^T + b0 from the raw rows of a (w = W0 diag(gamma), bias32 = b0 + W0 beta, colsum, stats_in
+    [P, M, 2]); "ln_gelu": gelu of that; "acc": out += a w^T + bias32 in place, row partials of the new out -> stats_out
+    [N / 256, M, 2]."""
+    md = {"ln": 0, "ln_gelu": 1, "acc": 2}[mode]
+    M, K = a.shape
+    N = w.shape[0]
+    assert a.is_cuda and a.dtype == w.dtype == out.dtype == torch.bfloat16 and a.is_contiguous() and w.is_contiguous() and out.is_contiguous()
+    assert w.shape == (N, K) and out.shape == (M, N) and bias32.dtype == torch.float32 and bias32.numel() == N and bias32.is_contiguous()
+    P = 0
+    if md != 2:
+        assert colsum.dtype == torch.float32 and colsum.numel() == N and colsum.is_contiguous()
+        assert stats_in.dtype == torch.float32 and stats_in.is_contiguous() and stats_in.dim() == 3 and stats_in.shape[1:] == (M, 2)
+        P = stats_in.shape[0]
+    else:
+        assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.shape == (N // 256, M, 2)
+    with torch.cuda.device(a.device):
+        rc = L.lib.ppn_nat_gemm_bf16(_p(a), _p(w), _p(bias32), _p(colsum), _p(stats_in), P, _p(stats_out), _p(out), M, N, K, md, float(eps),
+                                     ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream))
+    L.check(rc, "ppn_nat_gemm_bf16")
+    return out
+
+
+def nat_gemm_ok(M, N, K, acc):
+    """Shapes ppn_nat_gemm_bf16 serves: whole 256 x 256 tiles, at least three k-tiles in a tile (the accumulating mode adds four)."""
+    return M > 0 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and (K // 64 + (4 if acc else 0)) >= 3
+
+
+def row_stats(x2d):
+    """[1, rows, 2] float32 = (sum, sum of squares) of every row of a bfloat16 [rows, C] tensor (ppn_row_stats_bf16)."""
+    rows, Cc = x2d.shape
+    assert x2d.is_cuda and x2d.dtype == torch.bfloat16 and x2d.is_contiguous()
+    st = torch.empty(1, rows, 2, dtype=torch.float32, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        rc = L.lib.ppn_row_stats_bf16(_p(x2d), rows, Cc, _p(st), ctypes.c_void_p(torch.cuda.current_stream(x2d.device).cuda_stream))
+    L.check(rc, "ppn_row_stats_bf16")
+    return st
+
+
 def gennet_conv_s2(x_nchw_cl, w_packed, bias32, negative_slope, transposed):
     """GenNet's 24-channel stride-2 conv (transposed=False) / transposed conv (True) + bias + LeakyReLU on MFMA
     (ppn_gennet_conv_s2_bf16).  x: channels_last bfloat16 [B,24,H,W]; w_packed / bias32 from gennet.pack_s2_weights."""
