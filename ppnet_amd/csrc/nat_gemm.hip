@@ -56,7 +56,8 @@ constexpr int VEC_BYTES_LN = 2048 + MAX_P * 2048;                    // bias' f3
 constexpr int VEC_BYTES_ACC = 1024;                                  // bias f32[256]
 constexpr int RED_BYTES = 4 * 256 * 8;                               // ACC: float2 red[4 wave columns][256 rows]
 constexpr int ID_KTILES = BN / BK;                                   // ACC: the identity segment's k-tiles
-__host__ __device__ constexpr int lds_bytes(bool acc) { return VEC_OFF + (acc ? VEC_BYTES_ACC + RED_BYTES : VEC_BYTES_LN); }   // 156 672 / 157 696 of 163 840
+constexpr int ROWS_BYTES = 256 * 8;                                  // LN: float2 (rstd, -rstd * mean) of the tile's rows
+__host__ __device__ constexpr int lds_bytes(bool acc) { return VEC_OFF + (acc ? VEC_BYTES_ACC + RED_BYTES : VEC_BYTES_LN + ROWS_BYTES); }   // 156 672 / 159 744 of 163 840
 
 struct Params {
     const __bf16* A;        // [M][K] activations (LN modes: the raw residual stream)
@@ -78,15 +79,136 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_uniform
                                      (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
 }
 
-// s_waitcnt vmcnt(n'), n' = n rounded down to a multiple of 2 (conservative) and capped at 62; n is wave-uniform.
+// s_waitcnt vmcnt(n'), n' = n rounded down to a multiple of 2 (conservative) and capped at 62; n is wave-uniform.  The steady state
+// of the k-loop (four quarter-tiles in flight: 8) is tested first; everything else goes down a five-level tree of scalar branches.
 __device__ __forceinline__ void wait_vm(int n) {
-#define PPN_W(k) case k: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * k) : "memory"); break;
-    switch (n >= 62 ? 31 : (n < 0 ? 0 : n >> 1)) {
-        PPN_W(0) PPN_W(1) PPN_W(2) PPN_W(3) PPN_W(4) PPN_W(5) PPN_W(6) PPN_W(7) PPN_W(8) PPN_W(9) PPN_W(10) PPN_W(11) PPN_W(12) PPN_W(13)
-        PPN_W(14) PPN_W(15) PPN_W(16) PPN_W(17) PPN_W(18) PPN_W(19) PPN_W(20) PPN_W(21) PPN_W(22) PPN_W(23) PPN_W(24) PPN_W(25) PPN_W(26)
-        PPN_W(27) PPN_W(28) PPN_W(29) PPN_W(30) PPN_W(31)
+    if (n == 8) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); return; }
+    const int h = n >= 62 ? 31 : (n < 0 ? 0 : n >> 1);
+    if (h < 16) {
+        if (h < 8) {
+            if (h < 4) {
+                if (h < 2) {
+                    if (h < 1) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    }
+                } else {
+                    if (h < 3) {
+                        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    }
+                }
+            } else {
+                if (h < 6) {
+                    if (h < 5) {
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                    }
+                } else {
+                    if (h < 7) {
+                        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                    }
+                }
+            }
+        } else {
+            if (h < 12) {
+                if (h < 10) {
+                    if (h < 9) {
+                        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                    }
+                } else {
+                    if (h < 11) {
+                        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+                    }
+                }
+            } else {
+                if (h < 14) {
+                    if (h < 13) {
+                        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+                    }
+                } else {
+                    if (h < 15) {
+                        asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+                    }
+                }
+            }
+        }
+    } else {
+        if (h < 24) {
+            if (h < 20) {
+                if (h < 18) {
+                    if (h < 17) {
+                        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+                    }
+                } else {
+                    if (h < 19) {
+                        asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+                    }
+                }
+            } else {
+                if (h < 22) {
+                    if (h < 21) {
+                        asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
+                    }
+                } else {
+                    if (h < 23) {
+                        asm volatile("s_waitcnt vmcnt(44)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(46)" ::: "memory");
+                    }
+                }
+            }
+        } else {
+            if (h < 28) {
+                if (h < 26) {
+                    if (h < 25) {
+                        asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(50)" ::: "memory");
+                    }
+                } else {
+                    if (h < 27) {
+                        asm volatile("s_waitcnt vmcnt(52)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(54)" ::: "memory");
+                    }
+                }
+            } else {
+                if (h < 30) {
+                    if (h < 29) {
+                        asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(58)" ::: "memory");
+                    }
+                } else {
+                    if (h < 31) {
+                        asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(62)" ::: "memory");
+                    }
+                }
+            }
+        }
     }
-#undef PPN_W
 }
 
 // erf-GELU through a logistic fit of erf: gelu(x) = x / (1 + exp(-x (p0 + p1 x^2 + p2 x^4))), x^2 clamped to 64 (beyond |x| = 8
@@ -95,6 +217,17 @@ __device__ __forceinline__ float gelu_logistic(float x) {
     const float x2 = fminf(x * x, 64.0f);
     const float t = x * (2.3009787f + x2 * (0.10690469f - 1.0350827e-3f * x2));
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-t));
+}
+// two at a time: the multiplies / adds as packed float32 instructions (v_pk_mul_f32, v_pk_fma_f32, v_pk_add_f32 process a register
+// pair per issue slot; the epilogue is VALU-issue bound)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_logistic2(f32x2 x) {
+    f32x2 x2 = x * x;
+    x2 = f32x2{fminf(x2.x, 64.0f), fminf(x2.y, 64.0f)};
+    const f32x2 k0 = {2.3009787f, 2.3009787f}, k1 = {0.10690469f, 0.10690469f}, k2 = {-1.0350827e-3f, -1.0350827e-3f}, one = {1.0f, 1.0f};
+    const f32x2 t = x * __builtin_elementwise_fma(x2, __builtin_elementwise_fma(x2, k2, k1), k0);
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(-t.x), __builtin_amdgcn_exp2f(-t.y)} + one;
+    return x * f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
 }
 
 // A 16-byte LDS read as four floats, through the same vector type as the MFMA fragments.  (hipcc's waitcnt pass puts
@@ -116,6 +249,11 @@ struct TileSrc { int m0, n0; };      // a tile's origin (wave-uniform: lives in 
 
 template <bool LN, bool GELU, bool ACC>
 __global__ __launch_bounds__(NTHREADS, 1) void nat_gemm_kernel(const Params p) {
+#ifdef PPN_NG_NARROW
+    constexpr bool WIDE = false;
+#else
+    constexpr bool WIDE = true;                                      // 16-byte stores (a lane-row exchange of the packed results) or 2 x 8-byte
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -225,81 +363,113 @@ __global__ __launch_bounds__(NTHREADS, 1) void nat_gemm_kernel(const Params p) {
         }
     };
 
-    // ---- epilogue pieces.  After swap_rows a lane holds 8 consecutive n of ONE row: tile fq & 1, columns 8 (fq >> 1) of it.
-    const int qcol = (fq & 1) * 16 + (fq >> 1) * 8;
-    const uint32_t lst = ((uint32_t)frow * (uint32_t)ldc + (uint32_t)qcol) * 2u;                   // this lane's store offset inside a quadrant's rows
-    auto swap_rows = [&](f32x4& x, f32x4& y) PPN_INL {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[r]), __float_as_uint(y[r]), false, false);
-            x[r] = __uint_as_float(t[0]); y[r] = __uint_as_float(t[1]);
+    // ---- epilogue pieces
+    const uint32_t lst = ((uint32_t)frow * (uint32_t)ldc + (uint32_t)fq * 4u) * 2u;                // this lane's store offset inside a quadrant's rows
+    const uint32_t lst16 = ((uint32_t)frow * (uint32_t)ldc + (uint32_t)((fq & 1) * 16 + (fq >> 1) * 8)) * 2u;   // the same after the lane-row exchange
+    // LN: (rstd, -rstd * mean) of the tile's 256 rows from the (sum, sum of squares) partials, once per tile: thread 2 r computes row
+    // r — rows [0, 128) by waves 0-3, the wave group that reads them, [128, 256) by waves 4-7 — one phase before the first finish
+    float2* vec_rows = reinterpret_cast<float2*>(lds + VEC_OFF + VEC_BYTES_LN);
+    auto row_prepass = [&]() PPN_INL {
+        const int row = tid >> 1;
+        const float4 q0 = lds_f4(vec_stat + (row & ~1));
+        float sx = (row & 1) ? q0.z : q0.x, sy = (row & 1) ? q0.w : q0.y;
+        for (int pp = 1; pp < p.P_in; ++pp) {
+            const float4 q = lds_f4(vec_stat + pp * 256 + (row & ~1));
+            sx += (row & 1) ? q.z : q.x; sy += (row & 1) ? q.w : q.y;
         }
+        const float mean = sx * p.inv_k;
+        const float rstd = __builtin_amdgcn_rsqf(fmaxf(sy * p.inv_k - mean * mean, 0.f) + p.eps);
+        if ((tid & 1) == 0) lds_st_f2(vec_rows + row, make_float2(rstd, -rstd * mean));
+    };
+    // sum over the four lanes that share a row (lanes l, l ^ 16, l ^ 32, l ^ 48) on the VALU: v_permlane16/32_swap of a value with
+    // itself leaves (even rows, odd rows) / (lower half, upper half) copies whose sum is the xor-16 / xor-32 partner sum
+    auto quad_sum = [&](float v) PPN_INL {
+        auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+        t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(t[0]) + __uint_as_float(t[1]);
     };
     // finish quadrant (ap, bp) of the tile at (m0, n0): 4 x 16-byte stores per lane.  first_of_part: the first quadrant of its A
-    // part to finish ((0,0) and (1,1)); the second one closes the part's row sums (ACC).
+    // part to finish ((0,0) and (1,1)); the second one closes the part's row sums (ACC).  Every LDS read of the quadrant is issued
+    // up front (one latency, not one per row: the epilogue sits on its wave group's critical path).
     auto finish = [&](int ap, int bp, int m0, int n0, bool first_of_part) PPN_INL {
-        const int nl = wc * 64 + bp * 32 + qcol;
+#ifdef PPN_NG_NOFINISH
+        {   // diagnostic build: keep the accumulators alive, do nothing else
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) { asm volatile("" :: "v"(acc[ap][mt][bp][0]), "v"(acc[ap][mt][bp][1])); }
+            return;
+        }
+#endif
+        const int nl = wc * 64 + bp * 32 + fq * 4;                    // this lane's columns: nl .. nl + 3 and nl + 16 .. nl + 19
+        const int row0 = wr * 128 + ap * 64 + frow;
+        const float4 b0 = lds_f4(vec_bias + nl), b1 = lds_f4(vec_bias + nl + 16);
+        float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+        float2 rn[4], prev[4];
+        if (LN) {
+            c0 = lds_f4(vec_csum + nl); c1 = lds_f4(vec_csum + nl + 16);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) rn[mt] = lds_f2(vec_rows + row0 + mt * 16);
+        }
+        if (ACC && !first_of_part) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) prev[mt] = lds_f2(red + wc * 256 + row0 + mt * 16);
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            float s1 = 0.f, s2 = 0.f;                                 // ACC: this lane's 8 columns of the row
-            f32x4 x = acc[ap][mt][bp][0], y = acc[ap][mt][bp][1];
-            swap_rows(x, y);
-            float rstd = 1.f, nrm = 0.f;
-            if (LN) {
-                // the row's statistics ((sum, sum of squares) partials -> rstd, -rstd * mean) and the columns' constants are read from
-                // LDS per row: they are cheap there and 24 registers dear here
-                // (16-byte reads: the statistics of rows row & ~1 and row | 1)
-                const int row = wr * 128 + ap * 64 + mt * 16 + frow;
-                const float4 q0 = lds_f4(vec_stat + (row & ~1));
-                float2 st = (row & 1) ? make_float2(q0.z, q0.w) : make_float2(q0.x, q0.y);
-                for (int pp = 1; pp < p.P_in; ++pp) {
-                    const float4 q = lds_f4(vec_stat + pp * 256 + (row & ~1));
-                    st.x += (row & 1) ? q.z : q.x; st.y += (row & 1) ? q.w : q.y;
-                }
-                const float mean = st.x * p.inv_k;
-                rstd = __builtin_amdgcn_rsqf(fmaxf(st.y * p.inv_k - mean * mean, 0.f) + p.eps);
-                nrm = -rstd * mean;
-            }
+            // the lane's accumulators: 4 consecutive n of row frow in each of the quadrant's two 16-column tiles -> two 8-byte stores
+            // (an exchange between lane rows would make one 16-byte store of them: 8 more VALU instructions per row, and the epilogue
+            // is VALU-issue bound, not store-issue bound, once its stores trickle out beside the next tile's MFMAs)
             uint32_t w[4];
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f32x4 v = h == 0 ? x : y;
-                const float4 b4 = lds_f4(vec_bias + nl + 4 * h);
-                float o0, o1, o2, o3;
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x4 v = acc[ap][mt][bp][nt];
+                const float4 b4 = nt == 0 ? b0 : b1;
+                f32x2 o01 = {v[0], v[1]}, o23 = {v[2], v[3]};
                 if (LN) {
-                    const float4 c4 = lds_f4(vec_csum + nl + 4 * h);
-                    o0 = rstd * v[0] + (nrm * c4.x + b4.x); o1 = rstd * v[1] + (nrm * c4.y + b4.y);
-                    o2 = rstd * v[2] + (nrm * c4.z + b4.z); o3 = rstd * v[3] + (nrm * c4.w + b4.w);
+                    const float4 c4 = nt == 0 ? c0 : c1;
+                    const f32x2 r2 = {rn[mt].x, rn[mt].x}, n2 = {rn[mt].y, rn[mt].y};
+                    o01 = __builtin_elementwise_fma(r2, o01, __builtin_elementwise_fma(n2, f32x2{c4.x, c4.y}, f32x2{b4.x, b4.y}));
+                    o23 = __builtin_elementwise_fma(r2, o23, __builtin_elementwise_fma(n2, f32x2{c4.z, c4.w}, f32x2{b4.z, b4.w}));
                 } else {
-                    o0 = v[0] + b4.x; o1 = v[1] + b4.y; o2 = v[2] + b4.z; o3 = v[3] + b4.w;
+                    o01 += f32x2{b4.x, b4.y}; o23 += f32x2{b4.z, b4.w};
                 }
-                if (GELU) { o0 = gelu_logistic(o0); o1 = gelu_logistic(o1); o2 = gelu_logistic(o2); o3 = gelu_logistic(o3); }
+                if (GELU) { o01 = gelu_logistic2(o01); o23 = gelu_logistic2(o23); }
                 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-                const bf16x2 p0 = {(__bf16)o0, (__bf16)o1}, p1 = {(__bf16)o2, (__bf16)o3};
-                w[2 * h] = __builtin_bit_cast(uint32_t, p0); w[2 * h + 1] = __builtin_bit_cast(uint32_t, p1);
+                const bf16x2 p0 = {(__bf16)o01.x, (__bf16)o01.y}, p1 = {(__bf16)o23.x, (__bf16)o23.y};
+                w[2 * nt] = __builtin_bit_cast(uint32_t, p0); w[2 * nt + 1] = __builtin_bit_cast(uint32_t, p1);
                 if (ACC) {                                            // sums of the ROUNDED values: what the next GEMM will read
-                    const float f0 = __uint_as_float(w[2 * h] << 16), f1 = __uint_as_float(w[2 * h] & 0xffff0000u);
-                    const float f2 = __uint_as_float(w[2 * h + 1] << 16), f3 = __uint_as_float(w[2 * h + 1] & 0xffff0000u);
-                    s1 += (f0 + f1) + (f2 + f3);
-                    s2 += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+                    const float f0 = __uint_as_float(w[2 * nt] << 16), f1 = __uint_as_float(w[2 * nt] & 0xffff0000u);
+                    const float f2 = __uint_as_float(w[2 * nt + 1] << 16), f3 = __uint_as_float(w[2 * nt + 1] & 0xffff0000u);
+                    s1 += (f0 + f1) + (f2 + f3); s2 += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
                 }
             }
-            if (LN) asm volatile("" ::: "memory");                   // keep the next row's LDS reads in the next row
             char* ub = reinterpret_cast<char*>(p.C) + ((size_t)(m0 + wr * 128 + ap * 64 + mt * 16) * ldc + n0 + wc * 64 + bp * 32) * 2;
-            *reinterpret_cast<uint4*>(ub + lst) = make_uint4(w[0], w[1], w[2], w[3]);
+#ifndef PPN_NG_NOSTORE
+            if (WIDE) {
+                // v_permlane16_swap exchanges the PACKED pairs between neighbouring lane rows (2 instructions per row, on bf16 pairs —
+                // not 8 on floats): lane row g ends with tile g & 1, columns 8 (g >> 1) .. + 7 of it -> one 16-byte store
+                auto t0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
+                auto t1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
+                *reinterpret_cast<uint4*>(ub + lst16) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+            } else {
+                *reinterpret_cast<uint2*>(ub + lst) = make_uint2(w[0], w[1]);
+                *reinterpret_cast<uint2*>(ub + lst + 32) = make_uint2(w[2], w[3]);
+            }
+#else
+            asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(ub + lst));
+#endif
             if (ACC) {
-                // the quadrant's 32 columns of the row -> red[wc][row]: the part's first quadrant writes, its second one adds (the
-                // same lane of the same wave a phase later: LDS operations of a wave are in order, the sum order is fixed)
-                s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-                if (fq == 0) {
-                    float2* r = red + (wc * 256 + wr * 128 + ap * 64 + mt * 16 + frow);
-                    if (first_of_part) lds_st_f2(r, make_float2(s1, s2));
-                    else { const float2 o = lds_f2(r); lds_st_f2(r, make_float2(o.x + s1, o.y + s2)); }
-                }
+                // over the quadrant's 32 columns of the row -> red[wc][row]: the part's first quadrant writes, its second one adds (the
+                // same lane of the same wave a phase later: the LDS operations of a wave are in order and the sum order is fixed)
+                s1 = quad_sum(s1); s2 = quad_sum(s2);
+                if (!first_of_part) { s1 += prev[mt].x; s2 += prev[mt].y; }
+                if (fq == 0) lds_st_f2(red + wc * 256 + row0 + mt * 16, make_float2(s1, s2));
             }
         }
-        issued += 4;
+#if !defined(PPN_NG_NOSTORE) && !defined(PPN_NG_NOFINISH)
+        issued += WIDE ? 4 : 8;
+#endif
     };
     // ACC: the row partials of the finished tile -> stats_out[tile column][row] (one float per thread, fixed summation order)
     auto store_stats = [&](int m0, int n0) PPN_INL {
@@ -328,6 +498,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void nat_gemm_kernel(const Params p) {
         if (k < nk) stage(op, u, cur, k, slot); else stage(op, u, nxt, k - nk, slot);
     };
 
+#ifdef PPN_NG_SKEW
+    for (int i = 0; i < (int)((blockIdx.x >> 3) & 7); ++i) __builtin_amdgcn_s_sleep(PPN_NG_SKEW);   // diagnostic: desynchronise the CUs' tile boundaries
+#endif
     // prologue: the first tile's vectors; then k-tile 0 whole and k-tile 1's first halves
     stage_vec(cur);
     mark_vec = issued;
@@ -350,8 +523,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void nat_gemm_kernel(const Params p) {
         __builtin_amdgcn_s_setprio(0);                         \
         __builtin_amdgcn_s_barrier();                          \
     } while (0)
-    // the wait of phase ph (0-based): everything up to the DMA issued four phases ago has landed
-#define PPN_NG_WAIT(ph) do { const int old_mark = mark_p[ph]; mark_p[ph] = issued; wait_vm(issued - old_mark); } while (0)
 
     // One k-tile = 4 phases, each {fragment reads + one quarter-tile of LDS-DMA + counted wait | barrier | 16 MFMA | barrier}; the
     // quadrants (A part, B part) in MFMA order: (0,0) (0,1) (1,1) (1,0).
@@ -370,34 +541,41 @@ __global__ __launch_bounds__(NTHREADS, 1) void nat_gemm_kernel(const Params p) {
         const int par = g & 1;
         const unsigned char* b0 = lds + B0_OFF + s3 * BH_BYTES;
         const int s3n = s3 == 0 ? 2 : s3 - 1;                        // (g + 2) % 3
+        // In every phase the DMA is issued (and its mark taken) BEFORE the epilogue's stores: the counter is in order, so a wait for
+        // the DMA of four phases ago also waits for every store issued before that DMA, and stores drain slowly (a tile's 128 KB per
+        // CU, every CU at once) — this way a store has five phases to complete before a wait reaches back to it, not four.
         // ---- phase 1
         load_b(b0);
         __builtin_amdgcn_sched_barrier(0);
         load_a(par, 0);
-        if (MODE == 3) finish(1, 0, pm0, pn0, false);
         stage_ahead(1, 1, kt, 1, par ^ 1);
-        if (MODE == 2) wait_vm(issued - mark_vec);                  // the tile's vectors: read from the next phase on
-        PPN_NG_WAIT(0);
+        const int om0 = mark_p[0]; mark_p[0] = issued;
+        if (MODE == 2 && LN) row_prepass();                         // the vectors are visible (waited for a phase ago); its output is read next phase
+        if (MODE == 3) finish(1, 0, pm0, pn0, false);
+        wait_vm(issued - om0);
         PPN_NG_MMA(0, 0, ZERO);
         // ---- phase 2
         load_b(lds + B1_OFF + par * BH_BYTES);
+        stage_ahead(0, 1, kt, 1, par ^ 1);
+        const int om1 = mark_p[1]; mark_p[1] = issued;
         if (MODE == 2) finish(0, 0, pm0, pn0, true);
         if (MODE == 3 && ACC) store_stats(pm0, pn0);
-        stage_ahead(0, 1, kt, 1, par ^ 1);
-        PPN_NG_WAIT(1);
+        wait_vm(issued - om1);
         PPN_NG_MMA(0, 1, ZERO);
         // ---- phase 3
         load_a(par, 1);
-        if (MODE == 2) finish(0, 1, pm0, pn0, false);
-        if (MODE == 3) { stage_vec(cur); mark_vec = issued; }
         stage_ahead(0, 0, kt, 2, par);
         mark_p[2] = issued;
+        if (MODE == 2) finish(0, 1, pm0, pn0, false);
+        if (MODE == 3) { stage_vec(cur); mark_vec = issued; }       // every wave has finished with the previous tile's vectors
         PPN_NG_MMA(1, 1, ZERO);
         // ---- phase 4
         load_b(b0);
-        if (MODE == 2) finish(1, 1, pm0, pn0, true);
         stage_ahead(2, 0, kt, 2, s3n);
-        PPN_NG_WAIT(3);
+        const int om3 = mark_p[3]; mark_p[3] = issued;
+        if (MODE == 2) finish(1, 1, pm0, pn0, true);
+        if (MODE != 2 && kt == nk - 2) wait_vm(issued - mark_vec);  // the tile's vectors: read from the next phase (its last k-tile's first) on
+        wait_vm(issued - om3);
         PPN_NG_MMA(1, 0, ZERO);
         ++g;
         s3 = s3 == 2 ? 0 : s3 + 1;
@@ -422,7 +600,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void nat_gemm_kernel(const Params p) {
             }
         }
     }
-#undef PPN_NG_WAIT
 #undef PPN_NG_MMA
     if (wr == 0) __builtin_amdgcn_s_barrier();                       // rebalance the barrier count of the two groups
 }
