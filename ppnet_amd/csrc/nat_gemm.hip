@@ -78,6 +78,12 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_uniform
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
 }
+// the same with the non-temporal policy (aux = 2): for bytes this launch reads once (MI355X_MICROARCH.md, nt-weights row: issue ->
+// landed ~18 % sooner for a once-read stream)
+__device__ __forceinline__ void glds16_nt(const void* g, unsigned char* lds_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 2);
+}
 
 // s_waitcnt vmcnt(n'), n' = n rounded down to a multiple of 2 (conservative) and capped at 62; n is wave-uniform.  The steady state
 // of the k-loop (four quarter-tiles in flight: 8) is tested first; everything else goes down a five-level tree of scalar branches.
@@ -300,6 +306,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void nat_gemm_kernel(const Params p) {
                 const int blk = j * 16 + u * 8 + wave;
                 const char* ub = !idseg ? baseA + ((size_t)(t.m0 + blk * 8) * p.K + kt * BK) * 2
                                         : reinterpret_cast<const char*>(p.C) + ((size_t)(t.m0 + blk * 8) * ldc + t.n0 + (kt - nkw) * BK) * 2;
+#ifdef PPN_NG_NT_A
+                if (ACC) glds16_nt(ub + (!idseg ? lofs : lofs_c), lds + A_OFF + slot * A_BYTES + blk * 1024);
+                else
+#endif
                 glds16(ub + (!idseg ? lofs : lofs_c), lds + A_OFF + slot * A_BYTES + blk * 1024);
             } else {
                 const int c = j * 8 + wave, unit = op == 1 ? 1 : 0;

@@ -39,6 +39,39 @@ def _use_mfma_conv(x, conv):
             and conv.weight.dtype == torch.bfloat16 and not os.environ.get("PPNET_LIBRARY_CONV"))
 
 
+def _own_gemm_ok(x2, lin):
+    """The build's own MFMA GEMM (ppn_gemm_bf16) serves bfloat16 inference with K % 64 == 0, K >= 128, N % 8 == 0."""
+    K, N = lin.in_features, lin.out_features
+    return (x2.is_cuda and x2.dtype == torch.bfloat16 and lin.weight.dtype == torch.bfloat16 and K % 64 == 0 and K >= 128 and N % 8 == 0
+            and x2.is_contiguous() and not fused.recording(x2, lin.weight) and not os.environ.get("PPNET_LIBRARY_GEMM"))
+
+
+def _bias32(lin):
+    """A Linear's bias as float32 (zeros if none), cached on the module against its parameter's version."""
+    c = lin.__dict__.get("_ppn_b32")
+    if c is None:
+        c = lin.__dict__["_ppn_b32"] = fused.WeightCache()
+    return c.get((lin.bias, lin.weight), lambda: (lin.bias.detach().float().contiguous() if lin.bias is not None
+                                                  else torch.zeros(lin.out_features, dtype=torch.float32, device=lin.weight.device)))
+
+
+def _linear(x2, lin, gelu=False):
+    """lin(x2) (+ erf GELU) for 2-D x2 on the build's own GEMM where it applies; the framework's call otherwise (float32, odd sizes)."""
+    if _own_gemm_ok(x2, lin):
+        return fused.gemm_bf16(x2, lin.weight.detach(), _bias32(lin), "bias_gelu" if gelu else "bias")
+    if gelu and x2.is_cuda and x2.dtype == torch.bfloat16:
+        return torch._addmm_activation(lin.bias, x2, lin.weight.t(), use_gelu=True)
+    y = F.linear(x2, lin.weight, lin.bias)
+    return F.gelu(y) if gelu else y
+
+
+def _accumulate(s2, x2, lin):
+    """s2 += x2 @ lin.weight^T in place (no bias: the folded layer carries it outside), own GEMM where it applies."""
+    if _own_gemm_ok(x2, lin) and s2.is_contiguous():
+        return fused.gemm_bf16(x2, lin.weight.detach(), None, "accum", out=s2)
+    return s2.addmm_(x2, lin.weight.t())
+
+
 def _mfma_weights(conv):
     """(weight as [Cout,3,3,Cin] bfloat16 — the k order of the implicit GEMM — and the bias as float32, zeros if none)."""
     w = conv.weight.detach().permute(0, 2, 3, 1).contiguous()
@@ -111,20 +144,20 @@ class Mlp(nn.Module):
         self.act = act_layer()
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
 
+    def _erf_gelu(self):
+        return isinstance(self.act, nn.GELU) and self.act.approximate == "none"
+
     def hidden(self, x):
-        """act(fc1(x)) as a 2-D [tokens, hidden] tensor."""
+        """act(fc1(x)) as a 2-D [tokens, hidden] tensor: bias + GELU in the projection's epilogue (one pass over the hidden
+        activations less; in bf16 at least as close to float32 erf-GELU as the two-kernel form, tools/gelu_epilogue_check.py)."""
         x2 = x.reshape(-1, x.shape[-1])
-        if x.is_cuda and x.dtype == torch.bfloat16 and isinstance(self.act, nn.GELU) and self.act.approximate == "none":
-            return torch._addmm_activation(self.fc1.bias, x2, self.fc1.weight.t(), use_gelu=True)
+        if x.is_cuda and x.dtype == torch.bfloat16 and self._erf_gelu() and not fused.recording(x, self.fc1.weight):
+            return _linear(x2.contiguous(), self.fc1, gelu=True)
         return self.act(self.fc1(x2))
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.bfloat16 and isinstance(self.act, nn.GELU) and self.act.approximate == "none":
-            # bias + GELU in the projection's epilogue (hipBLASLt): one pass over the hidden activations less.  In bf16 its
-            # result is at least as close to float32 erf-GELU as the two-kernel form (mean |err| 0.9e-3 vs 1.25e-3 on
-            # O(1) values, tools/gelu_epilogue_check.py) — the intermediate is not rounded to bf16 before the GELU.
-            h = torch._addmm_activation(self.fc1.bias, x.reshape(-1, x.shape[-1]), self.fc1.weight.t(), use_gelu=True)
-            return self.fc2(h).view(*x.shape[:-1], -1)
+        if x.is_cuda and x.dtype == torch.bfloat16 and self._erf_gelu() and not fused.recording(x, self.fc1.weight):
+            return _linear(self.hidden(x), self.fc2).view(*x.shape[:-1], -1)
         return self.fc2(self.act(self.fc1(x)))
 
 
@@ -155,17 +188,42 @@ class NATLayer(nn.Module):
         if self._streams_c128(s):
             # 128-channel level: LN -> qkv and LN -> MLP -> residual are one token-streaming kernel each (weights in LDS)
             qkv = fused.nat128_ln_qkv(s, c_in, self.norm1, self.attn.qkv)
-            s.view(-1, C).addmm_(self.attn.attend(s, qkv=qkv).view(-1, C), self.attn.proj.weight.t())
+            _accumulate(s.view(-1, C), self.attn.attend(s, qkv=qkv).view(-1, C), self.attn.proj)
             fused.nat128_ln_mlp_(s, c_mid, self.norm2, self.mlp.fc1, self.mlp.fc2, final_add=c_out if restore else None)
             off = None if restore else c_out
             return s, (fused.layer_norm(s, next_norm, offset=off) if next_norm is not None else None), restore
         if y is None:
             y = fused.layer_norm(s, self.norm1, offset=c_in)
         s2 = s.view(-1, C)
-        s2.addmm_(self.attn.attend(y).view(-1, C), self.attn.proj.weight.t())          # s += o W'^T  (bias in c_mid)
+        _accumulate(s2, self.attn.attend(y).view(-1, C), self.attn.proj)                # s += o W'^T  (bias in c_mid)
         y2 = fused.layer_norm(s, self.norm2, offset=c_mid)
-        s2.addmm_(self.mlp.hidden(y2), self.mlp.fc2.weight.t())                        # s += h W2'^T (bias in c_out)
+        _accumulate(s2, self.mlp.hidden(y2), self.mlp.fc2)                              # s += h W2'^T (bias in c_out)
         return s, (fused.layer_norm(s, next_norm, offset=c_out) if next_norm is not None else None), False
+
+    _ln_packs = None
+
+    def ln_packs(self):
+        """What ppn_nat_gemm_bf16 reads for this (folded) layer, rebuilt when a parameter changes: the LayerNorms folded into the
+        projections behind them — W' = W diag(gamma) (bfloat16), b' = b + W beta, colsum(W') of the bfloat16 values, float32 —
+        for qkv and fc1, and proj / fc2 (LayerScale already folded by NATBlock.fold) with float32 biases:
+        (wq, bq, csq, w1, b1, cs1, wp, bp, w2, b2)."""
+        if self._ln_packs is None:
+            self._ln_packs = fused.WeightCache()
+        q, f1, pj, f2, n1, n2 = self.attn.qkv, self.mlp.fc1, self.attn.proj, self.mlp.fc2, self.norm1, self.norm2
+
+        def build():
+            out = []
+            for lin, ln in ((q, n1), (f1, n2)):
+                w32 = lin.weight.detach().float()
+                wf = (w32 * ln.weight.detach().float()[None, :]).to(torch.bfloat16).contiguous()
+                b = (lin.bias.detach().float() if lin.bias is not None else 0.0) + w32 @ ln.bias.detach().float()
+                out += [wf, b.contiguous(), wf.float().sum(1).contiguous()]
+            for lin in (pj, f2):
+                out += [lin.weight.detach().contiguous(), lin.bias.detach().float().contiguous() if lin.bias is not None
+                        else torch.zeros(lin.out_features, dtype=torch.float32, device=lin.weight.device)]
+            return tuple(out)
+        return self._ln_packs.get((q.weight, q.bias, f1.weight, f1.bias, pj.weight, pj.bias, f2.weight, f2.bias, n1.weight, n1.bias,
+                                   n2.weight, n2.bias), build)
 
     def _streams_c128(self, s):
         return (s.shape[-1] == 128 and s.is_cuda and s.dtype == torch.bfloat16 and (s.numel() // 128) % 16 == 0
@@ -222,6 +280,8 @@ class NATBlock(nn.Module):
         over the tokenizer's / downsampler's fresh output), otherwise it is copied first."""
         if not inplace:
             x = x.clone()
+        if self._ln_folded_ok(x):
+            return self._forward_ln_folded(x, out_norm)
         y = None
         n = len(self.blocks)
         hw = (x.shape[1], x.shape[2])
@@ -238,6 +298,46 @@ class NATBlock(nn.Module):
             else:
                 x, y = blk(x, y, out_norm, None)
         xo = y if out_norm is not None else x
+        return (x, xo) if self.downsample is None else (self.downsample(x), xo)
+
+    def _ln_folded_ok(self, x):
+        """The level runs on ppn_nat_gemm_bf16 (csrc/nat_gemm.hip): folded bfloat16 inference, C and the MLP width multiples of
+        256, whole 256-token tiles."""
+        b0 = self.blocks[0]
+        C = x.shape[-1]
+        return (b0.folded and x.is_cuda and x.dtype == torch.bfloat16 and b0.attn.qkv.weight.dtype == torch.bfloat16 and C % 256 == 0
+                and (x.numel() // C) % 256 == 0 and b0.mlp.fc1.out_features % 256 == 0 and b0.mlp._erf_gelu() and x.is_contiguous()
+                and not torch.is_grad_enabled() and not os.environ.get("PPNET_LIBRARY_GEMM") and not os.environ.get("PPNET_NO_LN_FOLD"))
+
+    def _forward_ln_folded(self, x, out_norm):
+        """The level with the dense half of every layer on the build's own persistent GEMMs (reference SegNet/nat.py:140-153): per
+        layer four launches and the attention —
+            qkv = GEMM_ln(s)            LayerNorm folded into the projection: the GEMM reads the raw residual stream and the row
+                                        sums the previous accumulating GEMM left behind
+            a   = NA(qkv)
+            s  += a Wp'^T + bp'         in place, residual add in the matrix pipe, row sums of the new s out
+            h   = GEMM_ln_gelu(s)       LayerNorm folded in, erf-GELU in the epilogue
+            s  += h W2'^T + b2'
+        — no LayerNorm kernel, no separate residual / bias / activation pass, no vendor GEMM.  s is the TRUE residual stream (the
+        biases are added in the epilogues), so the downsampler and the output norm read it as it is."""
+        B, H, W, C = x.shape
+        M = B * H * W
+        s2 = x.view(M, C)
+        st = fused.row_stats(s2)                                            # the level's first stream came from a LayerNorm kernel
+        P = C // 256
+        st_mid = torch.empty(P, M, 2, dtype=torch.float32, device=x.device)
+        st_out = torch.empty(P, M, 2, dtype=torch.float32, device=x.device)
+        for blk in self.blocks:
+            wq, bq, csq, w1, b1, cs1, wp, bp, w2, b2 = blk.ln_packs()
+            qkv = torch.empty(B, H, W, 3 * C, dtype=x.dtype, device=x.device)
+            fused.nat_gemm(s2, wq, bq, "ln", qkv.view(M, 3 * C), colsum=csq, stats_in=st, eps=blk.norm1.eps)
+            a = blk.attn.attend(x, qkv=qkv)
+            fused.nat_gemm(a.view(M, C), wp, bp, "acc", s2, stats_out=st_mid)
+            h = torch.empty(M, w1.shape[0], dtype=x.dtype, device=x.device)
+            fused.nat_gemm(s2, w1, b1, "ln_gelu", h, colsum=cs1, stats_in=st_mid, eps=blk.norm2.eps)
+            fused.nat_gemm(h, w2, b2, "acc", s2, stats_out=st_out)
+            st = st_out
+        xo = fused.layer_norm(x, out_norm) if out_norm is not None else x
         return (x, xo) if self.downsample is None else (self.downsample(x), xo)
 
     def fold(self):
