@@ -198,6 +198,63 @@ def ppnet_cpu_baseline(torch, grids_u8, heat_ridge, init, end, obs, n_obs, R_):
             "host_cores": os.cpu_count()}
 
 
+MFMA_PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: float32-input MFMA = the float32 vector rate
+
+
+def ppnet_fp32_leg(torch, dev, grids_u8, batch, steps=3):
+    """The same two networks at the REFERENCE's precision (GenNet/predict.py:46-52,88 and SegNet/test.py:181-191 run float32):
+    PPNet(weights_dtype=None) on the same batch — a reported leg, not a tuning target.  It makes the bfloat16 figure a stated
+    speed-up over a same-precision run.  On this path the convolutions and projections are ROCm library calls (MIOpen,
+    hipBLASLt / rocBLAS through PyTorch) in float32; the neighbourhood attention (ppn_na2d_fwd, float32 form), the fused residual /
+    LayerNorm / up-sampling / label kernels are the build's own.  The kernel names of one batch are listed from the profiler."""
+    from ppnet_amd.ppnet import PPNet
+    torch.manual_seed(0)
+    model = PPNet(resolution=R, weights_dtype=None).to(dev).eval()
+    # PPNet(weights_dtype=None) asks MIOpen for its exhaustive algorithm search (140 s on a fresh box for a 6 % faster batch:
+    # 147 -> ~138 ms): a reported leg of a bench that has to finish in minutes takes the heuristic pick
+    torch.backends.cudnn.benchmark = bool(os.environ.get("BENCH_FP32_MIOPEN_SEARCH"))
+    g = grids_u8[:batch]
+
+    def one():
+        return model.heatmap(model.segment_u8(g))
+    t0 = time.perf_counter()
+    one(); torch.cuda.synchronize()
+    first_s = time.perf_counter() - t0                                  # includes the libraries' one-off algorithm search
+    one(); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t1) / steps * 1e3
+    seg_fl, gen_fl = ppnet_flops_per_plan(R)
+    tflops = (seg_fl + gen_fl) * batch / (ms * 1e-3) / 1e12
+    lib_kernels, own_kernels = None, None
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            one(); torch.cuda.synchronize()
+        agg = {}
+        for ev in prof.key_averages():
+            if getattr(ev, "device_time_total", 0) or getattr(ev, "cuda_time_total", 0):
+                agg[ev.key] = agg.get(ev.key, 0.0) + float(getattr(ev, "device_time_total", 0) or getattr(ev, "cuda_time_total", 0))
+        own = {k: v for k, v in agg.items() if "ppn::" in k}
+        lib = {k: v for k, v in agg.items() if "ppn::" not in k and "Memcpy" not in k and "Memset" not in k}
+        top = lambda d: [f"{k[:70]} ({v / 1e3:.2f} ms)" for k, v in sorted(d.items(), key=lambda kv: -kv[1])[:12]]
+        lib_kernels, own_kernels = top(lib), top(own)
+        lib_ms, own_ms = sum(lib.values()) / 1e3, sum(own.values()) / 1e3
+    except Exception as e:                                               # the list is an extra: never fail the bench line over it
+        lib_kernels, lib_ms, own_ms = [f"profiler unavailable: {e!r}"[:160]], None, None
+    del model
+    torch.cuda.empty_cache()
+    return {"metric": "ppnet_plans_per_sec_fp32", "value": round(batch / (ms * 1e-3), 1), "unit": "plans/s", "ms_per_batch": round(ms, 2),
+            "steps": steps, "dtype": "f32", "first_batch_s": round(first_s, 1),
+            "what": "SegNet + GenNet forward only (the planner tail is identical to the bf16 leg's), PPNet(weights_dtype=None)",
+            "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tflops / MFMA_PEAK_FP32_TFLOPS, 4)},
+            "library_kernels_ms": round(lib_ms, 2) if lib_ms is not None else None, "own_kernels_ms": round(own_ms, 2) if own_ms is not None else None,
+            "library_kernels": lib_kernels, "own_kernels": own_kernels}
+
+
 def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg):
     """BASELINE config 3: PPNet inference (SegNet DiNAT-B + SETR-UP -> GenNet AE-ViT -> waypoint extraction ->
     collision check), batch of 256 problems over the 256x256 maps stage B just produced, per GPU.  Weights are
@@ -331,6 +388,7 @@ def main():
     ap.add_argument("--no-ppnet", action="store_true", help="skip the PPNet plans/s leg (BASELINE config 3)")
     ap.add_argument("--ppnet-batch", type=int, default=256)
     ap.add_argument("--ppnet-steps", type=int, default=10)
+    ap.add_argument("--no-ppnet-fp32", action="store_true", help="skip the float32 (reference-precision) PPNet leg")
     args = ap.parse_args()
 
     import torch
@@ -540,6 +598,13 @@ def main():
         }
         if ppnet is not None:
             out["ppnet"] = ppnet
+            if world == 1 and not args.no_ppnet_fp32:
+                try:
+                    f32 = ppnet_fp32_leg(torch, dev, mb.grid, args.ppnet_batch)
+                    f32["bf16_speedup"] = round(ppnet["ms_segnet"] + ppnet["ms_gennet"] and f32["ms_per_batch"] / (ppnet["ms_segnet"] + ppnet["ms_gennet"]), 2)
+                    out["ppnet_fp32"] = f32
+                except Exception as e:
+                    out["ppnet_fp32"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
