@@ -414,6 +414,10 @@ int ppn_nat128_ln_mlp_bf16(void* s, const float* offset, const void* ln_w, const
                            int64_t tokens, float eps, void* stream);
 int ppn_nat128_ln_mlp_add_bf16(void* s, const float* offset, const void* ln_w, const void* ln_b, const void* w1, const void* b1, const void* w2,
                                const float* final_add, int64_t tokens, float eps, void* stream);
+/* s[tokens][128] += a[tokens][128] . w[128][128]^T in place, bfloat16 (the output projection + residual of a 128-channel NAT layer,
+ * SegNet/nat.py:144-146, LayerScale folded into w by the caller, no bias): one streaming kernel, w resident in LDS.  tokens % 16 == 0. */
+int ppn_nat128_proj_add_bf16(void* s, const void* a, const void* w, int64_t tokens, void* stream);
+
 /* Dense projection c[M][N] = epilogue(a[M][K] . w[N][K]^T) on bfloat16 (torch.nn.Linear layout; SegNet/nat.py:62-85,111-120).
  * epilogue: 0 = + bias[n]; 1 = gelu(+ bias[n]) (erf form); 2 = c += (the residual stream accumulates, bias unused).
  * K % 64 == 0, K >= 128, N % 8 == 0.  persistent_blocks: 0 = one tile per workgroup; else the number of workgroups (a multiple

@@ -562,6 +562,13 @@ int ppn_nat128_ln_mlp_bf16(void* s, const float* offset, const void* ln_w, const
     return ppn_nat128_ln_mlp_add_bf16(s, offset, ln_w, ln_b, w1, b1, w2, nullptr, tokens, eps, stream);
 }
 
+int ppn_nat128_proj_add_bf16(void* s, const void* a, const void* w, int64_t tokens, void* stream) {
+    if (!s || !a || !w || tokens <= 0 || (tokens % 16) != 0) return PPN_E_INVALID;
+    const int e = ppn::nat128_proj_add_launch(s, a, w, tokens, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int32_t N, int32_t K, int32_t epilogue,
                   int32_t persistent_blocks, void* stream) {
     if (!a || !w || !c || M <= 0 || M >= (1LL << 31) || N <= 0 || (N % 8) != 0 || K < 128 || (K % 64) != 0 || epilogue < 0 || epilogue > 2 ||

@@ -236,6 +236,50 @@ __global__ __launch_bounds__(NAT128_THREADS, 1) void nat128_ln_mlp_kernel(__hip_
     }
 }
 
+// ---- output projection + residual: s += a Wp^T ---------------------------------------------------------------------------
+// (reference SegNet/nat.py:144-146: x = shortcut + drop_path(gamma1 * attn(...)); LayerScale folded into Wp by the host, the bias
+// carried in the level's offset.)  HBM-bound: reads a and s, writes s — one wave per 16 tokens, Wp (32 KB) resident in LDS, the
+// attention output's rows ARE the B operand (64 contiguous bytes per lane), the result is added to s in the store.  A GEMM
+// library (or the 256 x 256-tile GEMM: N = 128 fills half a tile) needs 0.15 - 0.25 ms for the 1 M tokens of a batch; this is
+// the three tensor passes.
+constexpr int PROJ_LDS = C128 * 256;
+
+__global__ __launch_bounds__(NAT128_THREADS, 1) void nat128_proj_add_kernel(__hip_bfloat16* __restrict__ s, const __hip_bfloat16* __restrict__ a,
+                                                                            const __hip_bfloat16* __restrict__ w, long long groups) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    stage_k128(lds, w, C128, [](int r) { return out_channel(r >> 4, r & 15); });
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    for (long long grp = (long long)blockIdx.x * NAT128_WAVES + wave; grp < groups; grp += (long long)gridDim.x * NAT128_WAVES) {
+        const long long tok0 = grp * 16;
+        const uint4* src = reinterpret_cast<const uint4*>(a + (tok0 + n) * C128 + 32 * g);
+        __hip_bfloat16* row = s + (tok0 + n) * C128 + 16 * g;
+        uint4 u[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = src[k];
+#pragma unroll
+        for (int qd = 0; qd < 2; ++qd) { r[2 * qd] = reinterpret_cast<const uint4*>(row + qd * 64)[0]; r[2 * qd + 1] = reinterpret_cast<const uint4*>(row + qd * 64)[1]; }
+        f32x4 acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(lds, t * 16 + n, 4 * g + ks, 16), __builtin_bit_cast(bf16x8, u[ks]), acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int qd = 0; qd < 2; ++qd) {
+            uint4* p = reinterpret_cast<uint4*>(row + qd * 64);
+            const uint4 r0 = r[2 * qd], r1 = r[2 * qd + 1];
+            const f32x4 a0 = acc[qd * 4 + 0], a1 = acc[qd * 4 + 1], a2 = acc[qd * 4 + 2], a3 = acc[qd * 4 + 3];
+            p[0] = make_uint4(pack_bf16x2(bf_lo(r0.x) + a0[0], bf_hi(r0.x) + a0[1]), pack_bf16x2(bf_lo(r0.y) + a0[2], bf_hi(r0.y) + a0[3]),
+                              pack_bf16x2(bf_lo(r0.z) + a1[0], bf_hi(r0.z) + a1[1]), pack_bf16x2(bf_lo(r0.w) + a1[2], bf_hi(r0.w) + a1[3]));
+            p[1] = make_uint4(pack_bf16x2(bf_lo(r1.x) + a2[0], bf_hi(r1.x) + a2[1]), pack_bf16x2(bf_lo(r1.y) + a2[2], bf_hi(r1.y) + a2[3]),
+                              pack_bf16x2(bf_lo(r1.z) + a3[0], bf_hi(r1.z) + a3[1]), pack_bf16x2(bf_lo(r1.w) + a3[2], bf_hi(r1.w) + a3[3]));
+        }
+    }
+}
+
 static int blocks_for(long long groups) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -257,6 +301,22 @@ int nat128_ln_qkv_launch(const void* s, const float* off, const void* lnw, const
     hipLaunchKernelGGL(nat128_ln_qkv_kernel, dim3(blocks_for(groups)), dim3(NAT128_THREADS), QKV_LDS, stream, (const __hip_bfloat16*)s, off,
                        (const __hip_bfloat16*)lnw, (const __hip_bfloat16*)lnb, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, (__hip_bfloat16*)qkv,
                        groups, eps);
+    return (int)hipGetLastError();
+}
+
+int nat128_proj_add_launch(void* s, const void* a, const void* w, long long tokens, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)nat128_proj_add_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PROJ_LDS) != hipSuccess) return (int)hipGetLastError();
+        attr = true;
+    }
+    const long long groups = tokens / 16;
+    // the kernel is HBM-bound and small (32 KB of LDS): several workgroups per CU keep enough loads in flight
+    int blocks = blocks_for(groups);
+    const long long need = (groups + NAT128_WAVES - 1) / NAT128_WAVES;
+    if (need > blocks) blocks = (int)(need < 2LL * blocks ? need : 2LL * blocks);
+    hipLaunchKernelGGL(nat128_proj_add_kernel, dim3(blocks), dim3(NAT128_THREADS), PROJ_LDS, stream, (__hip_bfloat16*)s, (const __hip_bfloat16*)a,
+                       (const __hip_bfloat16*)w, groups);
     return (int)hipGetLastError();
 }
 

@@ -105,6 +105,7 @@ int nat128_ln_qkv_launch(const void* s, const float* off, const void* lnw, const
                          float eps, hipStream_t stream);
 int nat128_ln_mlp_launch(void* s, const float* off, const void* lnw, const void* lnb, const void* w1, const void* b1, const void* w2, const float* add,
                          long long tokens, float eps, hipStream_t stream);
+int nat128_proj_add_launch(void* s, const void* a, const void* w, long long tokens, hipStream_t stream);
 int gennet_trunk_launch(const void* x, void* y, const float* params, int B, int N, int n_blocks, hipStream_t stream);
 int nat_gemm_launch(const void* a, const void* w, const float* bias, const float* colsum, const float* stats_in, int p_in,
                     float* stats_out, void* c, long long M, int N, int K, int mode, float eps, hipStream_t stream);

@@ -466,6 +466,18 @@ def nat128_ln_mlp_(s, offset, ln, fc1, fc2, final_add=None):
     return s
 
 
+def nat128_proj_add_(s, a, proj):
+    """s += a @ proj.weight^T in place for 128-channel token rows (ppn_nat128_proj_add_bf16; no bias: the folded layer carries it in
+    the next offset)."""
+    w = proj.weight.detach()
+    assert s.is_cuda and s.dtype == a.dtype == w.dtype == torch.bfloat16 and s.is_contiguous() and a.is_contiguous() and w.is_contiguous()
+    assert s.shape[-1] == 128 and a.shape == s.shape and w.shape == (128, 128)
+    with torch.cuda.device(s.device):
+        rc = L.lib.ppn_nat128_proj_add_bf16(_p(s), _p(a), _p(w), s.numel() // 128, ctypes.c_void_p(torch.cuda.current_stream(s.device).cuda_stream))
+    L.check(rc, "ppn_nat128_proj_add_bf16")
+    return s
+
+
 def gennet_dec_final(x_nchw_cl, w_packed, bias32, negative_slope, w_final32, bias_final):
     """GenNet's last decoder stage + final convolution as one kernel (ppn_gennet_dec_final_bf16): x channels_last bfloat16
     [B,24,H,W] -> [B,1,2H,2W]; w_packed / bias32 from gennet.pack_s2_weights (transposed), w_final32 the final convolution's

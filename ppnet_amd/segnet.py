@@ -188,7 +188,7 @@ class NATLayer(nn.Module):
         if self._streams_c128(s):
             # 128-channel level: LN -> qkv and LN -> MLP -> residual are one token-streaming kernel each (weights in LDS)
             qkv = fused.nat128_ln_qkv(s, c_in, self.norm1, self.attn.qkv)
-            _accumulate(s.view(-1, C), self.attn.attend(s, qkv=qkv).view(-1, C), self.attn.proj)
+            fused.nat128_proj_add_(s, self.attn.attend(s, qkv=qkv), self.attn.proj)      # s += o W'^T (bias in c_mid)
             fused.nat128_ln_mlp_(s, c_mid, self.norm2, self.mlp.fc1, self.mlp.fc2, final_add=c_out if restore else None)
             off = None if restore else c_out
             return s, (fused.layer_norm(s, next_norm, offset=off) if next_norm is not None else None), restore

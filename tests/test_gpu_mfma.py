@@ -387,3 +387,23 @@ def test_gennet_fused_decoder_tail_is_bit_identical_to_the_two_kernels(B, H, W):
     with torch.no_grad():
         want = fin(F.leaky_relu(dec(x.float()), 0.01).to(BF).float())
     _close(one, want)
+
+
+def test_nat128_proj_add_vs_float64():
+    """ppn_nat128_proj_add_bf16: s += a Wp^T for 128-channel tokens (SegNet/nat.py:144-146 with LayerScale folded), against the
+    float64 product of the same bfloat16 operands: one bfloat16 rounding of the sum (2^-8 relative) + float32 accumulation."""
+    import torch
+    from ppnet_amd import fused
+    torch.manual_seed(11)
+    tokens = 16 * 1000 + 48
+    s0 = (torch.randn(tokens, 128, device="cuda") * 1.5).to(torch.bfloat16)
+    a = torch.randn(tokens, 128, device="cuda").to(torch.bfloat16)
+    proj = torch.nn.Linear(128, 128).cuda().to(torch.bfloat16)
+    s = s0.clone()
+    fused.nat128_proj_add_(s, a, proj)
+    ref = s0.double() + a.double() @ proj.weight.double().t()
+    err = (s.double() - ref).abs()
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-3).all()), float(err.max())
+    s2 = s0.clone()
+    fused.nat128_proj_add_(s2, a, proj)
+    assert torch.equal(s, s2)
