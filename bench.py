@@ -255,6 +255,54 @@ def ppnet_fp32_leg(torch, dev, grids_u8, batch, steps=3):
             "library_kernels": lib_kernels, "own_kernels": own_kernels}
 
 
+def _kernel_split(torch, fn, top=14):
+    """(own kernels, other kernels) of one call of fn as ["name (ms)", ...] lists + their totals in ms, from the profiler."""
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        fn(); torch.cuda.synchronize()
+    agg = {}
+    for ev in prof.key_averages():
+        t = float(getattr(ev, "device_time_total", 0) or getattr(ev, "cuda_time_total", 0))
+        if t:
+            agg[ev.key] = agg.get(ev.key, 0.0) + t
+    own = {k: v for k, v in agg.items() if "ppn::" in k}
+    lib = {k: v for k, v in agg.items() if "ppn::" not in k and "Memcpy" not in k and "Memset" not in k}
+    fmt = lambda d: [f"{k[:70]} ({v / 1e3:.2f} ms)" for k, v in sorted(d.items(), key=lambda kv: -kv[1])[:top]]
+    return fmt(own), fmt(lib), sum(own.values()) / 1e3, sum(lib.values()) / 1e3
+
+
+def segnet_nat_uper_leg(torch, dev, grids_u8, batch, steps=5):
+    """The reference's DEFAULT SegNet configuration (SegNet/test.py:29-32 -> configs/nat/upernet_nat_base.py:6-34): NAT-Base (dilation
+    1 everywhere) + UPerHead(channels 64), prepared bfloat16 inference on the build's own kernels (UPerHead._forward_mfma), batch of
+    256 maps at 256 x 256: segmentations per second and the per-kernel split of one batch."""
+    from ppnet_amd import fused
+    from ppnet_amd.segnet import IMG_MEAN, IMG_STD, NAT_BASE_UPER, SegNet
+    torch.manual_seed(0)
+    net = SegNet(**NAT_BASE_UPER).to(dev).eval().prepare_inference().to(torch.bfloat16)
+    g = grids_u8[:batch]
+
+    def one():
+        with torch.no_grad():
+            return net.labels_u8(g)                                            # u8 occupancy codes -> palette tokenizer -> ... -> u8 labels
+    one(); one(); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t1) / steps * 1e3
+    out = {"metric": "segnet_nat_upernet_maps_per_sec", "value": round(batch / (ms * 1e-3), 1), "unit": "maps/s", "ms_per_batch": round(ms, 2),
+           "batch": batch, "steps": steps, "dtype": "bf16 (fp32 accumulate)",
+           "config": "NAT-Base (depths 3/4/18/5, kernel 7, dilation 1) + UPerHead(channels 64, pool scales 1/2/3/6), 2 classes"}
+    try:
+        own, lib, own_ms, lib_ms = _kernel_split(torch, one)
+        out.update(own_kernels=own, own_kernels_ms=round(own_ms, 2), other_kernels=lib, other_kernels_ms=round(lib_ms, 2))
+    except Exception as e:
+        out["kernel_split_error"] = repr(e)[:200]
+    del net
+    torch.cuda.empty_cache()
+    return out
+
+
 def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg):
     """BASELINE config 3: PPNet inference (SegNet DiNAT-B + SETR-UP -> GenNet AE-ViT -> waypoint extraction ->
     collision check), batch of 256 problems over the 256x256 maps stage B just produced, per GPU.  Weights are
@@ -389,6 +437,9 @@ def main():
     ap.add_argument("--ppnet-batch", type=int, default=256)
     ap.add_argument("--ppnet-steps", type=int, default=10)
     ap.add_argument("--no-ppnet-fp32", action="store_true", help="skip the float32 (reference-precision) PPNet leg")
+    ap.add_argument("--segnet", choices=["dinat_setr", "nat_uper", "both"], default="both",
+                    help="SegNet legs: dinat_setr = BASELINE config 3 (DiNAT-B + SETR-UP, inside the ppnet object); nat_uper = the reference's "
+                         "default config (NAT-Base + UPerHead) as a leg of its own; both (default)")
     args = ap.parse_args()
 
     import torch
@@ -598,6 +649,11 @@ def main():
         }
         if ppnet is not None:
             out["ppnet"] = ppnet
+            if world == 1 and args.segnet in ("nat_uper", "both"):
+                try:
+                    out["segnet_nat_uper"] = segnet_nat_uper_leg(torch, dev, mb.grid, args.ppnet_batch)
+                except Exception as e:
+                    out["segnet_nat_uper"] = {"error": repr(e)[:300]}
             if world == 1 and not args.no_ppnet_fp32:
                 try:
                     f32 = ppnet_fp32_leg(torch, dev, mb.grid, args.ppnet_batch)

@@ -419,7 +419,8 @@ int ppn_nat128_ln_mlp_add_bf16(void* s, const float* offset, const void* ln_w, c
 int ppn_nat128_proj_add_bf16(void* s, const void* a, const void* w, int64_t tokens, void* stream);
 
 /* Dense projection c[M][N] = epilogue(a[M][K] . w[N][K]^T) on bfloat16 (torch.nn.Linear layout; SegNet/nat.py:62-85,111-120).
- * epilogue: 0 = + bias[n]; 1 = gelu(+ bias[n]) (erf form); 2 = c += (the residual stream accumulates, bias unused).
+ * epilogue: 0 = + bias[n]; 1 = gelu(+ bias[n]) (erf form); 2 = c += (the residual stream accumulates, bias unused);
+ * 3 = max(+ bias[n], 0) (a 1x1 ConvModule: convolution + folded BatchNorm + ReLU, mmseg/models/decode_heads/uper_head.py:40-63).
  * K % 64 == 0, K >= 128, N % 8 == 0.  persistent_blocks: 0 = one tile per workgroup; else the number of workgroups (a multiple
  * of 8, normally the CU count) that walk the tiles with the LDS-DMA stream running across tile boundaries (M, N % 256 == 0). */
 int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int32_t N, int32_t K, int32_t epilogue,

@@ -571,7 +571,7 @@ int ppn_nat128_proj_add_bf16(void* s, const void* a, const void* w, int64_t toke
 
 int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int32_t N, int32_t K, int32_t epilogue,
                   int32_t persistent_blocks, void* stream) {
-    if (!a || !w || !c || M <= 0 || M >= (1LL << 31) || N <= 0 || (N % 8) != 0 || K < 128 || (K % 64) != 0 || epilogue < 0 || epilogue > 2 ||
+    if (!a || !w || !c || M <= 0 || M >= (1LL << 31) || N <= 0 || (N % 8) != 0 || K < 128 || (K % 64) != 0 || epilogue < 0 || epilogue > 3 ||
         (epilogue != 2 && !bias) || persistent_blocks < 0 || (persistent_blocks % 8) != 0)
         return PPN_E_INVALID;
     if (M * K * 2 >= (1LL << 32) || (long long)N * K * 2 >= (1LL << 32)) return PPN_E_UNSUPPORTED;

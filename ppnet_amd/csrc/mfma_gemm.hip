@@ -67,6 +67,7 @@ int gemm_mfma_launch(const void* a, const void* w, const float* bias, void* c, l
         case 0: return launch<gemm::DENSE, gemm::EPI_BIAS>(p, persistent, stream);
         case 1: return launch<gemm::DENSE, gemm::EPI_BIAS_GELU>(p, persistent, stream);
         case 2: return launch<gemm::DENSE, gemm::EPI_ACCUM>(p, persistent, stream);
+        case 3: return launch<gemm::DENSE, gemm::EPI_BIAS_RELU>(p, persistent, stream);
         default: return -1;
     }
 }

@@ -351,7 +351,7 @@ def conv3x3_relu_classify2(x_nchw_cl, w_k, bias32, w2_32, b2_32):
 def gemm_bf16(a, w, bias32, epilogue="bias", out=None, persistent_blocks=0):
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T) on the MFMA kernel (ppn_gemm_bf16).  epilogue: "bias", "bias_gelu", or "accum"
     (out += a @ w^T, bias unused)."""
-    epi = {"bias": 0, "bias_gelu": 1, "accum": 2}[epilogue]
+    epi = {"bias": 0, "bias_gelu": 1, "accum": 2, "bias_relu": 3}[epilogue]
     M, K = a.shape
     N = w.shape[0]
     assert a.is_cuda and a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.is_contiguous() and w.is_contiguous()

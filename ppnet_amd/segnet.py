@@ -28,14 +28,17 @@ def drop_path(x, rate, training):
     return x * (mask / keep)
 
 
-def _use_mfma_conv(x, conv):
+def _use_mfma_conv(x, conv, narrow=False):
     """The hand-written MFMA implicit-GEMM convolution (ppn_conv3x3_mfma_bf16) serves bfloat16 inference on the GPU for 3x3,
-    padding 1, Cin % 64 == 0, Cout % 256 == 0 (whole 256-wide output tiles); everything else stays on the library."""
+    padding 1, Cin % 64 == 0, Cout % 256 == 0 (whole 256-wide output tiles); everything else stays on the library.
+    narrow=True also takes Cout % 8 == 0 (UPerNet's 64-channel convolutions: a quarter of the 256-wide tile computes — they are
+    3 % of the backbone's arithmetic, and a library call per convolution costs more than the idle columns)."""
     import os
     if fused.recording(x, conv.weight):
         return False                                   # training: the library convolution (differentiable)
     return (x.is_cuda and x.dtype == torch.bfloat16 and not conv.training and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
-            and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 256 == 0
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0
+            and conv.out_channels % (8 if narrow else 256) == 0
             and conv.weight.dtype == torch.bfloat16 and not os.environ.get("PPNET_LIBRARY_CONV"))
 
 
@@ -522,9 +525,79 @@ class UPerHead(nn.Module):
         self.conv_seg = nn.Conv2d(channels, num_classes, 1)                  # Dropout2d is the identity at inference
 
     def _resize(self, x, size):
+        if (x.is_cuda and not self.align_corners and tuple(size) == (2 * x.shape[2], 2 * x.shape[3]) and x.shape[1] % 8 == 0
+                and x.dtype in (torch.float32, torch.bfloat16) and not fused.recording(x)):
+            return fused.upsample2x_nhwc(x)                                  # the FPN's x2 steps: the build's NHWC kernel
         return F.interpolate(x, size=size, mode="bilinear", align_corners=self.align_corners)
 
+    _packs = None
+
+    def _prepared_mfma(self, x):
+        """Prepared bfloat16 inference on the build's own kernels: BatchNorm folded into every ConvModule (a bias on its conv)."""
+        cms = [m for m in self.modules() if isinstance(m, _ConvModule)]
+        return (x.is_cuda and x.dtype == torch.bfloat16 and not self.training and all(isinstance(c.bn, nn.Identity) and c.conv.bias is not None for c in cms)
+                and self.conv_seg.out_channels == 2 and not fused.recording(x, self.conv_seg.weight) and not os.environ.get("PPNET_LIBRARY_CONV"))
+
+    def _forward_mfma(self, inputs):
+        """uper_head.py:76-127 with every convolution on the hand-written kernels: 1x1 ConvModules (laterals, pyramid pooling) are
+        ppn_gemm_bf16 over the NHWC tokens with bias + ReLU in the epilogue, 3x3 ConvModules the implicit-GEMM kernel
+        (ppn_conv3x3_mfma_bf16), the last one fused with the 1x1 classifier (ppn_conv3x3_relu_classify2_bf16: the 64-channel
+        activation at the highest resolution is never written); x2 resizes on the NHWC up-sampling kernel.  What stays on the
+        framework: the adaptive average pools of the pyramid (4 tiny reductions of the 8 x 8 level), the x4 / x8 resizes of the
+        coarse FPN outputs and the channel concatenations."""
+        if self._packs is None:
+            self._packs = fused.WeightCache()
+        cms = [m[1] for m in self.psp_modules] + [self.bottleneck] + list(self.lateral_convs) + list(self.fpn_convs) + [self.fpn_bottleneck]
+        src = [t for c in cms for t in (c.conv.weight, c.conv.bias)] + [self.conv_seg.weight, self.conv_seg.bias]
+
+        def build():
+            pk = {}
+            for c in cms:
+                cv = c.conv
+                if cv.kernel_size == (1, 1):
+                    pk[c] = (cv.weight.detach().reshape(cv.out_channels, cv.in_channels).contiguous(), cv.bias.detach().float().contiguous())
+                else:
+                    pk[c] = _mfma_weights(cv)
+            cs = self.conv_seg
+            pk["seg"] = (cs.weight.detach().float().reshape(cs.out_channels, -1).contiguous(), cs.bias.detach().float().contiguous())
+            return pk
+        pk = self._packs.get(src, build)
+
+        def conv1(cm, t):                                                    # 1x1 ConvModule on a channels_last [B,C,H,W] tensor
+            Bn, Cc, Hh, Ww = t.shape
+            tok = t.permute(0, 2, 3, 1).reshape(-1, Cc)
+            w, b = pk[cm]
+            if tok.shape[0] >= 256 and Cc % 64 == 0 and Cc >= 128 and tok.is_contiguous():
+                y = fused.gemm_bf16(tok, w, b, "bias_relu")
+            else:                                                            # the pyramid's 1 .. 36 pooled positions per image: too few rows for a tile
+                y = F.relu(F.linear(tok, w, b.to(tok.dtype)))
+            return y.view(Bn, Hh, Ww, -1).permute(0, 3, 1, 2)
+
+        def conv3(cm, t, relu=True):
+            w, b = pk[cm]
+            if _use_mfma_conv(t, cm.conv, narrow=True):
+                return fused.conv3x3_mfma(t, w, b, stride=1, relu=relu)
+            y = F.conv2d(t, cm.conv.weight, cm.conv.bias, 1, 1)
+            return F.relu(y) if relu else y
+        inputs = [inputs[i] for i in self.in_index]
+        x = inputs[-1]
+        psp = torch.cat([x] + [self._resize(conv1(m[1], m[0](x)), x.shape[2:]) for m in self.psp_modules], dim=1)
+        laterals = [conv1(cm, inputs[i]) for i, cm in enumerate(self.lateral_convs)] + [conv3(self.bottleneck, psp.contiguous(memory_format=torch.channels_last))]
+        for i in range(len(laterals) - 1, 0, -1):
+            laterals[i - 1] = laterals[i - 1] + self._resize(laterals[i], laterals[i - 1].shape[2:])
+        outs = [conv3(self.fpn_convs[i], laterals[i].contiguous(memory_format=torch.channels_last)) for i in range(len(laterals) - 1)] + [laterals[-1]]
+        outs = [outs[0]] + [self._resize(o, outs[0].shape[2:]) for o in outs[1:]]
+        cat = torch.cat(outs, dim=1).contiguous(memory_format=torch.channels_last)
+        fb = self.fpn_bottleneck
+        if _use_mfma_conv(cat, fb.conv, narrow=True):
+            w, b = pk[fb]
+            w2, b2 = pk["seg"]
+            return fused.conv3x3_relu_classify2(cat, w, b, w2, b2).to(cat.dtype)
+        return self.conv_seg(conv3(fb, cat))
+
     def forward(self, inputs):
+        if self._prepared_mfma(inputs[self.in_index[-1]]):
+            return self._forward_mfma(inputs)
         inputs = [inputs[i] for i in self.in_index]
         x = inputs[-1]
         psp = torch.cat([x] + [self._resize(m(x), x.shape[2:]) for m in self.psp_modules], dim=1)
@@ -667,7 +740,7 @@ class SegNet(nn.Module):
 
     def encode_decode(self, img):
         out = self.decode_head(self.backbone(img))
-        return F.interpolate(out, img.shape[2:], mode="bilinear", align_corners=self.align_corners)
+        return F.interpolate(out, img.shape[-2:], mode="bilinear", align_corners=self.align_corners)   # (img may be u8 codes [B,R,R])
 
     def labels_u8(self, img):
         """argmax labels as u8 [B,R,R].  SETR-UP head with two classes on the GPU: the x2 up-sampling of the logits, the
@@ -676,9 +749,9 @@ class SegNet(nn.Module):
         if (img.is_cuda and isinstance(head, SETRUPHead) and head.conv_seg.out_channels == 2 and not self.align_corners
                 and not head.align_corners and head.up_convs[-1][1].scale_factor == 2.0):
             return fused.seg_labels_2class(head(self.backbone(img), lowres=True), img.shape[-2:])
-        if img.dtype == torch.uint8:                   # occupancy codes: render the image for the generic path
-            img = fused.grid_to_image(img, IMG_MEAN, IMG_STD, next(self.parameters()).dtype)
-        return self.forward(img).to(torch.uint8)
+        if img.dtype == torch.uint8 and not self.backbone.patch_embed.takes_codes(img):
+            img = fused.grid_to_image(img, IMG_MEAN, IMG_STD, next(self.parameters()).dtype)   # occupancy codes the tokenizer kernel cannot take: render
+        return self.forward(img).to(torch.uint8)                  # (codes go straight to the palette tokenizer: NAT.forward)
 
     # ------------------------------------------------------------------ the reference's calling convention
     def forward(self, img=None, img_metas=None, return_loss=True, return_logits=False, **kwargs):

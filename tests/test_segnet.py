@@ -474,3 +474,52 @@ def test_mmseg_call_equals_labels_u8_on_gpu():
         losses = m(img=x, img_metas=[meta] * 4, gt_semantic_seg=torch.randint(0, 2, (4, 1, 64, 64), device=dev))
         assert set(losses) == {"decode.loss_ce", "decode.acc_seg"} and losses["decode.loss_ce"].requires_grad
         losses["decode.loss_ce"].backward()
+
+
+@pytest.mark.gpu
+def test_nat_upernet_prepared_bf16_on_own_kernels_vs_fp64_composition():
+    """The reference's default SegNet config (NAT-Base + UPerHead, SegNet/test.py:29-32) as bench.py --segnet nat_uper runs it:
+    prepared (BatchNorm and LayerScale folded), bfloat16, every convolution / projection on the build's own kernels
+    (UPerHead._forward_mfma, the LN-folded persistent GEMMs, the MFMA attention) — against the float64 op-by-op composition of
+    uper_head.py:76-127 + psp_head.py:48-60 + nat.py.  Tolerance as for the SETR-UP configuration (tests/test_ppnet_config3.py): rms
+    logit error below 1 % of the logit rms, labels equal wherever the float64 margin exceeds 6 x the rms error."""
+    import copy
+    from oracle import segnet_ref as SR
+    from ppnet_amd.segnet import NAT_BASE_UPER, SegNet, UPerHead, normalize_images
+    torch.manual_seed(2)
+    m = SR.randomize(SegNet(**NAT_BASE_UPER).eval(), seed=3).cuda()
+    img = normalize_images(torch.randint(0, 256, (4, 256, 256, 3), dtype=torch.uint8, device="cuda"))
+    want = SR.segnet_logits_fp64(m, NAT_BASE_UPER, img, head="uper")
+    f = copy.deepcopy(m).prepare_inference().to(torch.bfloat16)
+    calls = []
+    orig = UPerHead._forward_mfma
+    UPerHead._forward_mfma = lambda self, inputs: (calls.append(1), orig(self, inputs))[1]
+    try:
+        got = f.encode_decode(img.to(torch.bfloat16)).double()
+    finally:
+        UPerHead._forward_mfma = orig
+    assert calls, "the prepared bf16 head did not take the own-kernel path"
+    err = got - want
+    rms = float(err.pow(2).mean().sqrt())
+    assert rms < 0.01 * float(want.pow(2).mean().sqrt()), (rms, float(want.pow(2).mean().sqrt()))
+    margin = (want[:, 0] - want[:, 1]).abs()
+    sure = margin > 6 * rms
+    assert float(sure.float().mean()) > 0.5
+    assert bool((got.argmax(1) == want.argmax(1))[sure].all())
+
+
+@pytest.mark.gpu
+def test_nat_upernet_labels_from_occupancy_codes():
+    """labels_u8 on the u8 occupancy codes (palette tokenizer, no rendered image) equals labels_u8 on the rendered, normalised image
+    for the NAT + UPerNet configuration (the generic tail: resize -> softmax -> argmax), up to bf16 ties."""
+    from ppnet_amd import fused
+    from ppnet_amd.segnet import IMG_MEAN, IMG_STD, NAT_BASE_UPER, SegNet
+    torch.manual_seed(4)
+    net = SegNet(**NAT_BASE_UPER).cuda().eval().prepare_inference().to(torch.bfloat16)
+    g = torch.full((2, 128, 128), 255, dtype=torch.uint8, device="cuda")
+    g[:, 30:60, 40:90] = 0
+    g[:, 100:107, 10:17] = 128
+    a = net.labels_u8(g)
+    b = net.labels_u8(fused.grid_to_image(g, IMG_MEAN, IMG_STD, torch.bfloat16))
+    assert a.shape == (2, 128, 128) and a.dtype == torch.uint8
+    assert float((a == b).float().mean()) > 0.98
