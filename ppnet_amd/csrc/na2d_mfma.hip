@@ -289,6 +289,12 @@ int na2d_mfma_launch(const void* qkv, const void* pad_kv, const float* rpb, void
     if (const char* f = getenv("PPNET_NA_RT")) { const int v = atoi(f); if (v == 4 || v == 8 || v == 16) best = v; }   // A/B: force the region size
     if (best == 4) return launch_rt<4>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, zero, stream);
     if (best == 8) return launch_rt<8>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, zero, stream);
+    // 16 x 16 regions: the persistent LDS-DMA kernel (na2d_halo16.hip); this file's kernel where that one declines (or PPNET_NA_HALO16=0: A/B)
+    const char* ab = getenv("PPNET_NA_HALO16");
+    if (!(ab && ab[0] == '0')) {
+        const int r = na2d_halo16_launch(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, zero, stream);
+        if (r != -1) return r;
+    }
     return launch_rt<16>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, zero, stream);
 }
 

@@ -69,6 +69,8 @@ int na2d_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out
 const void* zero_line();
 int na2d_mfma_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
                      float scale, hipStream_t stream);
+int na2d_halo16_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
+                       float scale, const void* zero, hipStream_t stream);
 int na2d_bwd_launch(const void* qkv, const float* rpb, const void* dout, void* dqkv, float* drpb, float* attn_p, float* attn_ds, int B, int H, int W,
                     int heads, int dil, float scale, int dtype, hipStream_t stream);
 
