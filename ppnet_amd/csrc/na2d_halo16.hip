@@ -10,11 +10,12 @@
 //   compute(i)     wave w = block (w / 4, w % 4) of the tile: 10 + 15 MFMAs, the softmax of 16 queries (na2d_mfma.hip's block)
 // with ONE barrier per tile (after it every wave has finished tile i - 1, so its buffer may be overwritten; the stage of tile i was
 // issued a whole tile earlier).  The per-lane part of a piece's address (halo row t, column sc, chunk) does not depend on the tile;
-// what does comes from a 64-byte descriptor per tile that a preparation kernel writes once per launch (with the bias tables), so a
-// tile costs the scalar unit one load instead of nine integer divisions.
+// what does comes from a 64-byte descriptor per tile that a preparation kernel writes once per launch (with the bias tables): byte
+// offsets of its halo, query and output origins and its geometry — a tile costs one scalar load instead of nine integer divisions,
+// and a piece of the halo two compares (its class: stored token / padded token / zeros) before a DMA from a uniform base.
 //
-// LDS (141,312 B): 2 x { K image 22 x 24 slots x 64 B | V image (32-byte halves swapped on every other group of 4 slots, as
-// na2d_mfma.hip) | 4 zero slots | BT, BTM 2 x 16 x 22 f32 }.  The column pitch is 24 slots for 22 loaded: a block reads 16 slots from
+// LDS (141,824 B): 2 x { K image 22 x 24 slots x 64 B | V image (both with the 32-byte halves of a row swapped on every other
+// group of 4 slots: conflict-free fragment reads) | 4 zero slots | BT, BTM 2 x 16 x 24 f32 }.  The column pitch is 24 slots for 22 loaded: a block reads 16 slots from
 // column co <= 12, so its last 4 run into the next halo row (the V image / the zero slots behind the last row) — finite values
 // whose logits carry the window mask, i.e. probability exactly 0.
 #include <hip/hip_runtime.h>
@@ -34,49 +35,56 @@ constexpr int MK = 7, MN = 3, MHD = 32;
 constexpr int TQ = 4;                  // 4 x 4 queries per MFMA block
 constexpr int HR = 10;                 // key tiles (halo rows) per block
 constexpr int KB = 64;                 // bytes per staged key row (32 bf16)
-constexpr int BT_ROWS = 16, BT_COLS = 22;
+constexpr int BT_ROWS = 16, BT_PITCH = 24;   // bias tables: 22 columns used; at a pitch of 24 floats the 4 query rows of a block read disjoint banks
 constexpr int RT = 16, HROWS = RT + 6, PC = 24;
 constexpr int SLOTS = HROWS * PC;      // 528 = 33 x 16
 constexpr int IMG = SLOTS * KB;
 constexpr int TAIL = 4 * KB;
-constexpr int TBL = 2 * BT_ROWS * BT_COLS * 4;
+constexpr int TBL = 2 * BT_ROWS * BT_PITCH * 4;
 constexpr int BUF = 2 * IMG + TAIL + TBL;
 constexpr int NPAIR = SLOTS / 16;      // wave instructions per image
 constexpr int NW = 16, NTHR = NW * 64;
 constexpr int PPW = (NPAIR + NW - 1) / NW;
 constexpr int DESC = 16;               // ints per tile descriptor
-static_assert(SLOTS % 16 == 0 && TBL % 16 == 0 && (PC & 3) == 0 && ((PC >> 2) & 1) == 0, "staging layout");
+static_assert(SLOTS % 16 == 0 && TBL % 16 == 0 && (PC & 7) == 0, "staging layout");
+static_assert(PPW * 10 <= 32 && HROWS + 2 <= 32 && PC <= 32, "packed staging coordinates");
 
-enum { D_B, D_GI, D_GJ, D_TY0, D_TX0, D_HS, D_WS, D_HQ, D_WQ, D_R0, D_C0, D_NR, D_NC, D_VALID };
+// descriptor of a tile (what of it does not depend on the head): byte offsets of the halo origin's k row (head 0), of the tile
+// origin's q row and of its output row; the halo extent and its real part (virtual padding), packed; the tile's geometry
+enum { D_KV = 0, D_Q = 2, D_O = 4, D_EXT = 6, D_TY0, D_TX0, D_HS, D_WS, D_HQ, D_WQ, D_R0, D_C0, D_VALID };
 
 __device__ __forceinline__ int clampm(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// LDS-DMA of 16 bytes per lane to lds_uniform + 16 * lane.  Written as assembly on purpose: the compiler orders LDS reads it cannot
-// tell apart from a __builtin_amdgcn_global_load_lds in flight behind that copy (s_waitcnt vmcnt(0) — before the transposed V reads
-// here), which would make every tile wait for the NEXT tile's staging; what it does not see it does not wait for, and its own
+// LDS-DMA of 16 bytes per lane, base + off -> lds_uniform + 16 * lane.  Written as assembly on purpose: the compiler orders LDS reads
+// it cannot tell apart from a __builtin_amdgcn_global_load_lds in flight behind that copy (s_waitcnt vmcnt(0) — before the transposed
+// V reads here), which would make every tile wait for the NEXT tile's staging; what it does not see it does not wait for, and its own
 // counted waits only become stricter by operations it does not know of (vmcnt retires in order).  M0 is otherwise unused here.
-__device__ __forceinline__ void dma16(const void* g, unsigned lds_uniform) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_uniform) : "memory");
+__device__ __forceinline__ void dma16(const void* base_uniform, unsigned off, unsigned lds_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base_uniform), "s"(lds_uniform) : "memory");
 }
-__device__ __forceinline__ float lds_f(const float* p) { return *p; }
+__device__ __forceinline__ float max3(float a, float b, float c) {        // (fmaxf would canonicalise every MFMA result first)
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 }  // namespace
 
-// Once per launch: blocks [0, heads) write the two bias tables of a head in the units of the raw product ([heads][2][16][22] f32:
+// Once per launch: blocks [0, heads) write the two bias tables of a head in the units of the raw product ([heads][2][16][24] f32:
 // rpb[h] / scale zero-padded; the same inside the centred 7 x 7 window and -1e30 elsewhere = bias AND window mask of a query whose
 // window the border does not clamp); the blocks behind them write one descriptor per tile.
-__global__ __launch_bounds__(352) void na2d_halo16_prep_kernel(const float* __restrict__ rpb, float* __restrict__ table, int* __restrict__ desc, int heads,
-                                                               float scale, int H, int W, int Hr, int Wr, int dil, int tiles_y, int tiles_x,
-                                                               int total_tiles) {
+__global__ __launch_bounds__(BT_ROWS * BT_PITCH) void na2d_halo16_prep_kernel(const float* __restrict__ rpb, float* __restrict__ table, int* __restrict__ desc,
+                                                                              int heads, float scale, int H, int W, int Hr, int Wr, int dil, int tiles_y,
+                                                                              int tiles_x, int total_tiles, int padded) {
     const int t = threadIdx.x;
     if ((int)blockIdx.x < heads) {
         const int h = blockIdx.x;
-        const int a = t / BT_COLS, b = t - a * BT_COLS;
+        const int a = t / BT_PITCH, b = t - a * BT_PITCH;
         const float v = (a < 13 && b < 13) ? rpb[(size_t)h * 169 + a * 13 + b] / scale : 0.f;
-        table[((size_t)h * 2) * BT_ROWS * BT_COLS + t] = v;
-        table[((size_t)h * 2 + 1) * BT_ROWS * BT_COLS + t] = (a >= MN && a <= 3 * MN && b >= MN && b <= 3 * MN) ? v : -1.0e30f;
+        table[((size_t)h * 2) * BT_ROWS * BT_PITCH + t] = v;
+        table[((size_t)h * 2 + 1) * BT_ROWS * BT_PITCH + t] = (a >= MN && a <= 3 * MN && b >= MN && b <= 3 * MN) ? v : -1.0e30f;
         return;
     }
-    const int gtile = ((int)blockIdx.x - heads) * 352 + t;
+    const int gtile = ((int)blockIdx.x - heads) * (BT_ROWS * BT_PITCH) + t;
     if (gtile >= total_tiles) return;
     const int ntiles = tiles_y * tiles_x;
     const int bz = gtile / ntiles, tile_id = gtile - bz * ntiles;
@@ -85,102 +93,139 @@ __global__ __launch_bounds__(352) void na2d_halo16_prep_kernel(const float* __re
     const int hs = (H - gi + dil - 1) / dil, ws = (W - gj + dil - 1) / dil;                     // key sub-image of this dilation group
     const int hq = gi < Hr ? (Hr - gi + dil - 1) / dil : 0, wq = gj < Wr ? (Wr - gj + dil - 1) / dil : 0;   // its real part: the queries
     const int ty0 = (tile_id / tiles_x) * RT, tx0 = (tile_id % tiles_x) * RT;
+    const int valid = (ty0 < hq && tx0 < wq) ? 1 : 0;                                           // groups differ by one row / column
+    int* d = desc + (size_t)gtile * DESC;
+    if (!valid) {
+        for (int i = 0; i < DESC; ++i) d[i] = 0;
+        return;
+    }
+    const int Hs = padded ? Hr : H, Ws = padded ? Wr : W;                                       // stored token grid
     const int R0 = clampm(ty0 - MN, 0, hs - MK), C0 = clampm(tx0 - MN, 0, ws - MK);            // halo origin
     const int ymax = min(ty0 + RT - 1, hq - 1), xmax = min(tx0 + RT - 1, wq - 1);
-    int* d = desc + (size_t)gtile * DESC;
-    d[D_B] = b; d[D_GI] = gi; d[D_GJ] = gj; d[D_TY0] = ty0; d[D_TX0] = tx0; d[D_HS] = hs; d[D_WS] = ws; d[D_HQ] = hq; d[D_WQ] = wq;
-    d[D_R0] = R0; d[D_C0] = C0;
-    d[D_NR] = clampm(ymax - MN, 0, hs - MK) + MK - R0;                                          // halo extent
-    d[D_NC] = clampm(xmax - MN, 0, ws - MK) + MK - C0;
-    d[D_VALID] = (ty0 < hq && tx0 < wq) ? 1 : 0;                                                // groups differ by one row / column
-    d[14] = 0; d[15] = 0;
+    const int NR = clampm(ymax - MN, 0, hs - MK) + MK - R0, NC = clampm(xmax - MN, 0, ws - MK) + MK - C0;   // halo extent
+    const int NRr = padded ? min(NR, hq - R0) : NR, NCr = padded ? min(NC, wq - C0) : NC;       // ... that holds stored tokens
+    const unsigned long long tokb = (unsigned long long)3 * heads * MHD * 2;
+    const unsigned long long kv = ((unsigned long long)(b * Hs + gi + R0 * dil) * Ws + gj + C0 * dil) * tokb + (unsigned long long)heads * MHD * 2;
+    const unsigned long long qo = ((unsigned long long)(b * Hs + gi + ty0 * dil) * Ws + gj + tx0 * dil) * tokb;
+    const unsigned long long oo = ((unsigned long long)(b * Hr + gi + ty0 * dil) * Wr + gj + tx0 * dil) * ((unsigned long long)heads * MHD * 2);
+    d[D_KV] = (int)(unsigned)kv; d[D_KV + 1] = (int)(unsigned)(kv >> 32);
+    d[D_Q] = (int)(unsigned)qo; d[D_Q + 1] = (int)(unsigned)(qo >> 32);
+    d[D_O] = (int)(unsigned)oo; d[D_O + 1] = (int)(unsigned)(oo >> 32);
+    d[D_EXT] = NR | (NC << 8) | (NRr << 16) | (NCr << 24);
+    d[D_TY0] = ty0; d[D_TX0] = tx0; d[D_HS] = hs; d[D_WS] = ws; d[D_HQ] = hq; d[D_WQ] = wq; d[D_R0] = R0; d[D_C0] = C0; d[D_VALID] = 1;
 }
 
-struct Tile { int b, gi, gj, ty0, tx0, hs, ws, hq, wq, R0, C0, NR, NC, valid, h; };
+struct Tile {
+    unsigned long long kv, q, o;
+    int ext, ty0, tx0, hs, ws, hq, wq, R0, C0, valid, h;
+};
 
-__device__ __forceinline__ Tile load_tile(const int* __restrict__ desc, int item, int heads) {
-    const int gtile = item / heads;
+__device__ __forceinline__ Tile load_tile(const int* __restrict__ desc, int gtile, int h) {
     const int* d = desc + (size_t)gtile * DESC;
     Tile t;
-    t.h = item - gtile * heads;
-    t.b = d[D_B]; t.gi = d[D_GI]; t.gj = d[D_GJ]; t.ty0 = d[D_TY0]; t.tx0 = d[D_TX0]; t.hs = d[D_HS]; t.ws = d[D_WS]; t.hq = d[D_HQ]; t.wq = d[D_WQ];
-    t.R0 = d[D_R0]; t.C0 = d[D_C0]; t.NR = d[D_NR]; t.NC = d[D_NC]; t.valid = d[D_VALID];
+    t.h = h;
+    t.kv = (unsigned long long)(unsigned)d[D_KV] | ((unsigned long long)(unsigned)d[D_KV + 1] << 32);
+    t.q = (unsigned long long)(unsigned)d[D_Q] | ((unsigned long long)(unsigned)d[D_Q + 1] << 32);
+    t.o = (unsigned long long)(unsigned)d[D_O] | ((unsigned long long)(unsigned)d[D_O + 1] << 32);
+    t.ext = d[D_EXT]; t.ty0 = d[D_TY0]; t.tx0 = d[D_TX0]; t.hs = d[D_HS]; t.ws = d[D_WS]; t.hq = d[D_HQ]; t.wq = d[D_WQ];
+    t.R0 = d[D_R0]; t.C0 = d[D_C0]; t.valid = d[D_VALID];
     return t;
 }
 
 __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pad_kv, __bf16* __restrict__ out,
-                                                           const float* __restrict__ bt_table, const int* __restrict__ desc, int Hr, int Wr, int Hs,
-                                                           int Ws, int heads, int dil, float scale, int n_items, const __bf16* __restrict__ zero) {
+                                                           const float* __restrict__ bt_table, const int* __restrict__ desc, int Wr, int Ws, int heads,
+                                                           int dil, float scale, int n_items, const __bf16* __restrict__ zero) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nl[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;                                // MFMA column (query) and lane quarter
-    const size_t tok = (size_t)3 * heads * MHD;
+    const unsigned tokb = 3u * heads * MHD * 2;                            // bytes of a token's qkv row
 
-    // this workgroup's items: XCD x (workgroups x, x + 8, ...) owns a contiguous run with the head fastest — the heads of a token
-    // share its 128-byte lines, neighbouring tiles share halos — and its workgroups take consecutive items of it at the same time
+    // this workgroup's items (item = tile * heads + head): XCD x (workgroups x, x + 8, ...) owns a contiguous run with the head
+    // fastest — the heads of a token share its 128-byte lines, neighbouring tiles share halos — and its workgroups take consecutive
+    // items of it at the same time
     const int nx = gridDim.x >> 3, xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
     const int per = (n_items + 7) >> 3;
     const int end = min((xcd + 1) * per, n_items);
     int item = xcd * per + kx;
     if (item >= end) return;                                               // workgroup-uniform
+    int gtile = item / heads, h = item - gtile * heads;
+    const int step_t = nx / heads, step_h = nx - step_t * heads;           // item + nx without a division per tile
 
     // the 4 zero slots behind each V image
     if (threadIdx.x < 2 * TAIL / 4) reinterpret_cast<uint32_t*>(nl + (threadIdx.x >= TAIL / 4 ? BUF : 0) + 2 * IMG)[threadIdx.x & (TAIL / 4 - 1)] = 0u;
 
-    // ---- the tile-independent part of this lane's staging pieces: pair k = wave + 16 i covers slots 16 k .. 16 k + 15 of both images
-    // (halo row t, column sc: 5 bits each, PPW pairs in one register — kept packed, and opaque, so that the loop carries one register
-    // for them instead of six)
-    unsigned st_pack = 0;
-    const int chunk = lane & 3;
+    // ---- the tile-independent part of this lane's staging pieces.  Pair k = wave + 16 i covers slots 16 k .. 16 k + 15 of both
+    // images, this lane the 16 bytes at position lane % 4 of slot 16 k + lane / 4 = halo row t, column sc.  Both images are stored with
+    // the 32-byte halves of a row swapped on every other group of 4 slots (the K fragment reads take 16 bytes per lane and the
+    // transposed V reads 8 from 16 slots at a 64-byte pitch: slots s and s + 4 would meet in the same banks); the DMA lands
+    // lane-linear, so the lane FETCHES the other chunk.  16 | slots per pair and 8 | PC: the group parity is the lane's own.
+    const unsigned c16 = (unsigned)((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 16;
+    unsigned st_pack = 0, st_off[PPW];
+    {
+        const unsigned rowstep = (unsigned)(Ws * dil) * tokb, colstep = (unsigned)dil * tokb;
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int slot = (wave + NW * i) * 16 + (lane >> 2);
-        const int t = slot / PC;
-        st_pack |= ((unsigned)t | ((unsigned)(slot - t * PC) << 5)) << (10 * i);
+        for (int i = 0; i < PPW; ++i) {
+            const int slot = (wave + NW * i) * 16 + (lane >> 2);
+            const int t = slot / PC, sc = slot - t * PC;
+            st_pack |= ((unsigned)t | ((unsigned)sc << 5)) << (10 * i);
+            st_off[i] = (unsigned)t * rowstep + (unsigned)sc * colstep + c16;      // from the halo origin's k row, bytes
+        }
     }
-    static_assert(PPW * 10 <= 32 && HROWS + 2 <= 32 && PC <= 32, "packed staging coordinates");
-    // V is stored with its 32-byte halves swapped on every other group of 4 slots (the transposed reads take 8 bytes per lane from
-    // 16 slots at a 64-byte pitch; slots s and s + 4 would meet in the same banks): the DMA lands lane-linear, so the lane FETCHES
-    // the other chunk.  16 | slots per pair, so the group parity is the lane's own
-    const int vchunk = chunk ^ (((lane >> 4) & 1) << 1);
-    const size_t vofs = (size_t)heads * MHD;
-
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)nl;
+    const char* qkvb = reinterpret_cast<const char*>(qkv);
+    const unsigned vofs = (unsigned)heads * MHD * 2;
+
+    // Every slot has a source — its token's row, the padded token (virtual padding: k / v = the qkv bias) or a line of zeros (beyond
+    // the halo extent; V must stay finite and K a number) — so each of the three classes is one DMA under its lanes' mask from a
+    // uniform base with a 32-bit lane offset: two compares per pair are all the vector work the staging of a tile costs
     auto stage = [&](const Tile& T, unsigned buf) __attribute__((always_inline)) {
         if (!T.valid) return;
-        const __bf16* base = qkv + ((size_t)(T.b * Hs + T.gi + T.R0 * dil) * Ws + T.gj + T.C0 * dil) * tok + ((size_t)heads + T.h) * MHD;
-        const __bf16* pk = pad_kv ? pad_kv + ((size_t)heads + T.h) * MHD : zero;   // a padded token's k row (its v row: + heads * 32)
-        const int ylim = pad_kv ? Hr : 0x7fffffff, xlim = pad_kv ? Wr : 0x7fffffff;
-        const unsigned rowstep = (unsigned)(Ws * dil) * (unsigned)tok, colstep = (unsigned)dil * (unsigned)tok;
+        const char* kbase = qkvb + T.kv + (unsigned)T.h * (MHD * 2);
+        const char* vbase = kbase + vofs;
+        const int NR = T.ext & 255, NC = (T.ext >> 8) & 255, NRr = (T.ext >> 16) & 255, NCr = (T.ext >> 24) & 255;
         unsigned pk2 = st_pack;
-        asm volatile("" : "+v"(pk2));
+        asm volatile("" : "+v"(pk2));                                      // (unpacked per tile: one register across the loop, not six)
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int k = wave + NW * i;
             if (k < NPAIR) {                                               // wave-uniform
                 const int t = (pk2 >> (10 * i)) & 31, sc = (pk2 >> (10 * i + 5)) & 31;
-                const bool inside = t < T.NR && sc < T.NC;
-                const bool real = inside && T.gi + (T.R0 + t) * dil < ylim && T.gj + (T.C0 + sc) * dil < xlim;
-                const unsigned off = (unsigned)t * rowstep + (unsigned)sc * colstep;
-                const __bf16* row = real ? base + off : (inside ? pk : zero);
-                const bool z = !real && !(inside && pad_kv);
-                dma16(row + 8 * chunk, buf + k * 1024);
-                dma16(row + (z ? (size_t)0 : vofs) + 8 * vchunk, buf + IMG + k * 1024);
+                const bool real = t < NRr && sc < NCr, inside = t < NR && sc < NC;
+                const unsigned kl = buf + k * 1024, vl = buf + IMG + k * 1024;
+                if (real) {
+                    dma16(kbase, st_off[i], kl);
+                    dma16(vbase, st_off[i], vl);
+                } else if (inside) {                                       // only with pad_kv
+                    const char* pk = reinterpret_cast<const char*>(pad_kv) + (size_t)(heads + T.h) * (MHD * 2);
+                    dma16(pk, c16, kl);
+                    dma16(pk + vofs, c16, vl);
+                } else {
+                    dma16(zero, c16, kl);
+                    dma16(zero, c16, vl);
+                }
             }
         }
         if (wave < 3 && wave * 64 + lane < TBL / 16)                       // this head's two tables
-            dma16(bt_table + (size_t)T.h * (TBL / 4) + (wave * 64 + lane) * 4, buf + 2 * IMG + TAIL + wave * 1024);
-    };
-    // the q fragment of this wave's block (B operand: channels 8g .. 8g+7 of query j; dead queries shadow a live one, never stored)
-    const int by = wave >> 2, bx = wave & 3;
-    auto q_request = [&](const Tile& T) __attribute__((always_inline)) -> bf16x8 {
-        const int ti0 = T.ty0 + by * TQ, tj0 = T.tx0 + bx * TQ;
-        const int uq = clampm(ti0 + (j >> 2), 0, max(T.hq - 1, 0)), vq = clampm(tj0 + (j & 3), 0, max(T.wq - 1, 0));
-        const int qy = T.gi + uq * dil, qx = T.gj + vq * dil;
-        return *reinterpret_cast<const bf16x8*>(qkv + ((size_t)(T.b * Hs + min(qy, Hs - 1)) * Ws + min(qx, Ws - 1)) * tok + (size_t)T.h * MHD + 8 * g);
+            dma16(bt_table + (size_t)T.h * (TBL / 4), (unsigned)(wave * 64 + lane) * 16, buf + 2 * IMG + TAIL + wave * 1024);
     };
 
-    Tile cur = load_tile(desc, item, heads);
+    // ---- this wave's block of the tile: rows 4 by .., columns 4 bx ..; lane (j, g): query (jy, jx) of it, quarter g
+    const int by = wave >> 2, bx = wave & 3;
+    const int jy = j >> 2, jx = j & 3;
+    const int ry = by * TQ + jy, rx = bx * TQ + jx;                        // the query's place in the tile
+    const unsigned qoff_full = (unsigned)(ry * Ws + rx) * (unsigned)dil * tokb + 16u * g;             // B operand: channels 8g .. 8g+7 of query j
+    const unsigned ooff_full = (unsigned)(ry * Wr + rx) * (unsigned)dil * (unsigned)(heads * MHD * 2) + 8u * g;
+    const int btl_full = (-jy * BT_PITCH - jx + 4 * g) * 4;
+    // dead queries (a tile the image cuts) shadow a live one and are never stored
+    auto q_request = [&](const Tile& T) __attribute__((always_inline)) -> bf16x8 {
+        const int rmax = T.hq - 1 - T.ty0, cmax = T.wq - 1 - T.tx0;
+        unsigned qoff = qoff_full;
+        if (rmax < RT - 1 || cmax < RT - 1)                                // wave-uniform
+            qoff = (unsigned)(clampm(ry, 0, max(rmax, 0)) * Ws + clampm(rx, 0, max(cmax, 0))) * (unsigned)dil * tokb + 16u * g;
+        return *reinterpret_cast<const bf16x8*>(qkvb + T.q + (unsigned)T.h * (MHD * 2) + qoff);
+    };
+
+    Tile cur = load_tile(desc, gtile, h);
     stage(cur, lds0);
     bf16x8 q_next = q_request(cur);
     int bsel = 0;
@@ -195,12 +240,15 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
         bf16x8 qf = q_next;
         asm volatile("" : "+v"(qf));
         __syncthreads();
-        unsigned char* buf = nl + bsel * BUF;
+        const unsigned char* buf = nl + bsel * BUF;
         const int nitem = item + nx;
         const bool more = nitem < end;                                     // workgroup-uniform
         Tile nxt = cur;
         if (more) {
-            nxt = load_tile(desc, nitem, heads);
+            gtile += step_t;
+            h += step_h;
+            if (h >= heads) { h -= heads; ++gtile; }
+            nxt = load_tile(desc, gtile, h);
             stage(nxt, lds0 + (bsel ^ 1) * BUF);
             q_next = q_request(nxt);
         }
@@ -210,13 +258,11 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
         if (T.valid && ti0 < T.hq && tj0 < T.wq) {                         // wave-uniform
             const unsigned char* Kimg = buf;
             const unsigned char* Vimg = buf + IMG;
-            const float* BT = reinterpret_cast<const float*>(buf + 2 * IMG + TAIL);
-            const float* BTM = BT + BT_ROWS * BT_COLS;
+            const unsigned char* BT = buf + 2 * IMG + TAIL;
             const int hs = T.hs, ws = T.ws, hq = T.hq, wq = T.wq;
-            const int u = ti0 + (j >> 2), v = tj0 + (j & 3);
-            const bool qvalid = u < hq && v < wq;
-            const int uc = u < hq ? u : hq - 1, vc = v < wq ? v : wq - 1;  // dead queries shadow a live one (never stored)
-            const int wi = clampm(uc - MN, 0, hs - MK), wj = clampm(vc - MN, 0, ws - MK);
+            const bool cut = ti0 + TQ > hq || tj0 + TQ > wq;               // wave-uniform: the image ends inside this block
+            const int jyc = cut ? min(jy, hq - 1 - ti0) : jy, jxc = cut ? min(jx, wq - 1 - tj0) : jx;
+            const bool qvalid = jyc == jy && jxc == jx;
             const int r0 = clampm(ti0 - MN, 0, hs - MK), c0 = clampm(tj0 - MN, 0, ws - MK);    // this block's window origin
             const int ro = r0 - T.R0, co = c0 - T.C0;                      // ... inside the staged halo: ro + 9 < HROWS, co <= 12
 
@@ -224,23 +270,26 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
             // 8g .. 8g+7; the 40 bias values of this lane), then S^T: key tile t = halo row ro + t, slots co .. co + 15
             f32x4 sacc[HR];
             bf16x8 kf[HR];
-            const unsigned char* kb = Kimg + ((ro * PC) + co + j) * KB + g * 16;
+            const int ks0 = ro * PC + co + j;
+            const unsigned char* kb = Kimg + ks0 * KB + ((g ^ (((ks0 >> 2) & 1) << 1)) * 16);
             // The relative position bias enters as the MFMA's INITIAL ACCUMULATOR, in the units of the raw product (rpb / scale; the
             // logit is (q.k + b) * scale * log2 e).  A block none of whose 16 queries has its window clamped by the border
             // (wave-uniform) takes the table whose entries outside the centred 7 x 7 window are -1e30: bias and window mask are then
             // one function of the key's offset from the query (na2d_mfma.hip)
-            const bool interior = ti0 >= MN && ti0 + TQ - 1 + MN <= hs - 1 && tj0 >= MN && tj0 + TQ - 1 + MN <= ws - 1 && ti0 + TQ <= hq && tj0 + TQ <= wq;
-            const float* bt = (interior ? BTM : BT) + (r0 - uc + MK - 1) * BT_COLS + (c0 + 4 * g - vc + MK - 1);
+            const bool interior = ti0 >= MN && ti0 + TQ - 1 + MN <= hs - 1 && tj0 >= MN && tj0 + TQ - 1 + MN <= ws - 1 && !cut;
+            const int bts = ((interior ? BT_ROWS * BT_PITCH : 0) + (r0 - ti0 + MK - 1) * BT_PITCH + (c0 - tj0 + MK - 1)) * 4;   // uniform
+            const int btl = cut ? (-jyc * BT_PITCH - jxc + 4 * g) * 4 : btl_full;
+            const float* bt = reinterpret_cast<const float*>(BT + bts + btl);
 #pragma unroll
             for (int t = 0; t < HR; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(kb + t * PC * KB);
 #pragma unroll
-            for (int t = 0; t < HR; ++t)
-                sacc[t] = f32x4{lds_f(bt + t * BT_COLS), lds_f(bt + t * BT_COLS + 1), lds_f(bt + t * BT_COLS + 2), lds_f(bt + t * BT_COLS + 3)};
+            for (int t = 0; t < HR; ++t) sacc[t] = f32x4{bt[t * BT_PITCH], bt[t * BT_PITCH + 1], bt[t * BT_PITCH + 2], bt[t * BT_PITCH + 3]};
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < HR; ++t) sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, sacc[t], 0, 0, 0);
             if (!interior) {
                 // window mask.  Lane (j, g) holds, per tile t, keys (row r0 + t, column c0 + 4g + r), r = 0 .. 3, of query j
+                const int wi = clampm(ti0 + jyc - MN, 0, hs - MK), wj = clampm(tj0 + jxc - MN, 0, ws - MK);
                 uint32_t rowmask = 0;
 #pragma unroll
                 for (int t = 0; t < HR; ++t) rowmask |= (uint32_t)((r0 + t >= wi) && (r0 + t <= wi + MK - 1)) << t;
@@ -257,9 +306,16 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
                     }
                 }
             }
-            float mx = NEG;
+            float red[14];                                                 // 40 -> 14 -> 5 -> 2 -> 1: 20 instructions, 4 deep
 #pragma unroll
-            for (int t = 0; t < HR; ++t) mx = fmaxf(mx, fmaxf(fmaxf(sacc[t][0], sacc[t][1]), fmaxf(sacc[t][2], sacc[t][3])));
+            for (int i = 0; i < 13; ++i) {
+                const int a0 = 3 * i, a1 = 3 * i + 1, a2 = 3 * i + 2;
+                red[i] = max3(sacc[a0 >> 2][a0 & 3], sacc[a1 >> 2][a1 & 3], sacc[a2 >> 2][a2 & 3]);
+            }
+            red[13] = sacc[HR - 1][3];
+            const float m0 = max3(red[0], red[1], red[2]), m1 = max3(red[3], red[4], red[5]), m2 = max3(red[6], red[7], red[8]);
+            const float m3 = max3(red[9], red[10], red[11]), m4 = fmaxf(red[12], red[13]);
+            float mx = fmaxf(max3(m0, m1, m2), fmaxf(m3, m4));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float nm = -mx * sl2;                                    // p = 2^((S' - max) * scale * log2 e): one multiply-add per logit
@@ -273,7 +329,7 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
             f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, lacc = {0.f, 0.f, 0.f, 0.f};
             const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
             const int vslot = (ro * PC) + co + 4 * g + q4;
-            const int vsw = (vslot >> 2) & 1;                              // this lane's slots are stored half-swapped (every row: PC / 4 even)
+            const int vsw = (vslot >> 2) & 1;                              // this lane's slots are stored half-swapped (every row: 8 | PC)
             const unsigned char* vb = Vimg + vslot * KB + 8 * p4;
             const unsigned char* vbc[2] = {vb + vsw * 32, vb + (vsw ^ 1) * 32};
             bf16x4 vlo[HR / 2][2], vhi[HR / 2][2];
@@ -281,7 +337,6 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
             for (int ks = 0; ks < HR / 2; ++ks)
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
-                    // (bfloat16-typed, as lds_f)
                     vlo[ks][cb] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vbc[cb] + (2 * ks) * PC * KB));
                     vhi[ks][cb] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vbc[cb] + (2 * ks + 1) * PC * KB));
                 }
@@ -300,12 +355,11 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
             }
             if (qvalid) {
                 const float inv = 1.0f / lacc[0];
-                const int y = T.gi + u * dil, x = T.gj + v * dil;
-                __bf16* dst = out + ((size_t)(T.b * Hr + y) * Wr + x) * ((size_t)heads * MHD) + (size_t)T.h * MHD;
+                char* dst = reinterpret_cast<char*>(out) + T.o + (unsigned)T.h * (MHD * 2) + ooff_full;
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
                     const uint2 w = make_uint2(pack_bf16x2(oacc[cb][0] * inv, oacc[cb][1] * inv), pack_bf16x2(oacc[cb][2] * inv, oacc[cb][3] * inv));
-                    *reinterpret_cast<uint2*>(dst + cb * 16 + 4 * g) = w;   // channels cb*16 + 4g .. +3 of query j
+                    *reinterpret_cast<uint2*>(dst + cb * 32) = w;           // channels cb*16 + 4g .. +3 of query j
                 }
             }
         }
@@ -323,9 +377,9 @@ int na2d_halo16_launch(const void* qkv, const void* pad_kv, const float* rpb, vo
     const int tiles_y = (hq + RT - 1) / RT, tiles_x = (wq + RT - 1) / RT;
     const long long total = (long long)tiles_y * tiles_x * B * dil * dil;
     const long long items = total * heads;
-    const int Hs = pad_kv ? Hr : H, Ws = pad_kv ? Wr : W;                    // stored token grid
-    // a piece's offset from its tile's halo origin is 32-bit (elements)
-    if (items >= (1LL << 30) || (long long)(HROWS + 1) * dil * Ws * 3 * heads * MHD >= (1LL << 31)) return -1;
+    const int Ws = pad_kv ? Wr : W;                                          // stored token grid
+    // a piece's offset from its tile's halo origin, and a query's from its tile's, are 32-bit (bytes)
+    if (items >= (1LL << 30) || heads > 255 || (long long)(HROWS + 2) * dil * Ws * 3 * heads * MHD * 2 >= (1LL << 31)) return -1;
     static std::atomic<int> state{0};                                        // 0 unknown, 1 ready, -1 unavailable
     static int n_cu = 0;
     if (!state.load()) {
@@ -343,14 +397,15 @@ int na2d_halo16_launch(const void* qkv, const void* pad_kv, const float* rpb, vo
     if (e != hipSuccess) return (int)e;
     float* table = reinterpret_cast<float*>(ws);
     int* desc = reinterpret_cast<int*>(ws + tbl_bytes);
-    hipLaunchKernelGGL(na2d_halo16_prep_kernel, dim3(heads + (unsigned)((total + 351) / 352)), dim3(352), 0, stream, rpb, table, desc, heads, scale, H, W,
-                       Hr, Wr, dil, tiles_y, tiles_x, (int)total);
-    // whole XCD rows of workgroups, no more than the items of the shortest XCD run
+    constexpr int PT = BT_ROWS * BT_PITCH;
+    hipLaunchKernelGGL(na2d_halo16_prep_kernel, dim3(heads + (unsigned)((total + PT - 1) / PT)), dim3(PT), 0, stream, rpb, table, desc, heads, scale, H, W,
+                       Hr, Wr, dil, tiles_y, tiles_x, (int)total, pad_kv ? 1 : 0);
+    // whole XCD rows of workgroups, no more than the items of an XCD's run
     const long long per = (items + 7) / 8;
     int grid = n_cu;
     if (per * 8 < grid) grid = (int)per * 8;
     hipLaunchKernelGGL(na2d_halo16_kernel, dim3(grid), dim3(NTHR), 2 * BUF, stream, (const __bf16*)qkv, (const __bf16*)pad_kv, (__bf16*)out,
-                       (const float*)table, (const int*)desc, Hr, Wr, Hs, Ws, heads, dil, scale, (int)items, (const __bf16*)zero);
+                       (const float*)table, (const int*)desc, Wr, Ws, heads, dil, scale, (int)items, (const __bf16*)zero);
     e = hipGetLastError();
     const hipError_t f = hipFreeAsync(ws, stream);
     return (int)(e != hipSuccess ? e : f);
