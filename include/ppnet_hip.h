@@ -264,11 +264,15 @@ int ppn_na2d_fwd_vpad(const void* qkv, const void* pad_kv, const float* rpb, voi
 
 /* Backward of ppn_na2d_fwd (the gradient NATTEN's natten2dqkrpb / natten2dav backward kernels compute; first brick of the
  * training step, GenNet/train.py:93-147, SegNet/mmseg/apis/train.py:67-167).  qkv [B][H][W][3][heads][32] and rpb as in the
- * forward, dout [B][H][W][heads*32]; outputs dqkv (same layout as qkv), drpb [heads][13][13] float32 ACCUMULATED into (zero it
- * first).  workspace: 2 * B * heads * H * W * 49 floats (the attention probabilities and their gradient).  H, W >= 7 * dilation
- * (the training module pads the tokens itself, as NATTEN's does).  dtype 0 = float32, 1 = bfloat16 (float32 arithmetic). */
-int ppn_na2d_bwd(const void* qkv, const float* rpb, const void* dout, void* dqkv, float* drpb, float* workspace, int32_t B, int32_t H,
-                 int32_t W, int32_t heads, int32_t dilation, float scale, int32_t dtype, void* stream);
+ * forward, dout [B][H][W][heads*32]; outputs dqkv (same layout as qkv) and drpb [heads][13][13] float32, both fully WRITTEN (the
+ * rpb gradient is summed in a fixed order: bit-reproducible).  Two passes over 8 x 8 regions staged through LDS, the
+ * probabilities recomputed in the second; workspace: ppn_na2d_bwd_workspace(...) floats, 16-byte aligned (softmax statistics of
+ * every query, 4 floats, + 169 partial sums of drpb per region and head) — workspace_floats is what the caller allocated and is
+ * checked.  H, W >= 7 * dilation (the training module pads the tokens itself, as NATTEN's does).  dtype 0 = float32,
+ * 1 = bfloat16 (float32 arithmetic). */
+int64_t ppn_na2d_bwd_workspace(int32_t B, int32_t H, int32_t W, int32_t heads, int32_t dilation);   /* floats; < 0: invalid shape */
+int ppn_na2d_bwd(const void* qkv, const float* rpb, const void* dout, void* dqkv, float* drpb, float* workspace, int64_t workspace_floats,
+                 int32_t B, int32_t H, int32_t W, int32_t heads, int32_t dilation, float scale, int32_t dtype, void* stream);
 
 /* Fused residual + LayerScale + LayerNorm around the NAT layer's dense ops (SegNet/nat.py:140-153):
  *   a == NULL : y_out = LayerNorm(x)                                   (x_out ignored)

@@ -318,14 +318,19 @@ int ppn_na2d_fwd(const void* qkv, const float* rpb, void* out, int32_t B, int32_
     return ppn_na2d_fwd_padded(qkv, rpb, out, B, H, W, H, W, heads, dilation, scale, dtype, stream);
 }
 
-int ppn_na2d_bwd(const void* qkv, const float* rpb, const void* dout, void* dqkv, float* drpb, float* workspace, int32_t B, int32_t H,
-                 int32_t W, int32_t heads, int32_t dilation, float scale, int32_t dtype, void* stream) {
-    if (!qkv || !rpb || !dout || !dqkv || !drpb || !workspace || B <= 0 || heads <= 0 || dilation < 1 || H < 7 * dilation || W < 7 * dilation ||
-        (dtype != 0 && dtype != 1))
-        return PPN_E_INVALID;
-    const long long n = (long long)B * heads * H * W * 49;
-    const int e = ppn::na2d_bwd_launch(qkv, rpb, dout, dqkv, drpb, workspace, workspace + n, B, H, W, heads, dilation, scale, dtype,
-                                       (hipStream_t)stream);
+int64_t ppn_na2d_bwd_workspace(int32_t B, int32_t H, int32_t W, int32_t heads, int32_t dilation) {
+    if (B <= 0 || heads <= 0 || heads > 65535 || dilation < 1 || H < 7 * dilation || W < 7 * dilation) return -1;
+    if ((long long)B * heads * H * W >= (1LL << 40)) return -1;
+    return ppn::na2d_bwd_workspace_floats(B, H, W, heads, dilation);
+}
+
+int ppn_na2d_bwd(const void* qkv, const float* rpb, const void* dout, void* dqkv, float* drpb, float* workspace, int64_t workspace_floats,
+                 int32_t B, int32_t H, int32_t W, int32_t heads, int32_t dilation, float scale, int32_t dtype, void* stream) {
+    if (!qkv || !rpb || !dout || !dqkv || !drpb || !workspace || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
+    const int64_t need = ppn_na2d_bwd_workspace(B, H, W, heads, dilation);
+    if (need < 0 || workspace_floats < need || (reinterpret_cast<uintptr_t>(workspace) & 15)) return PPN_E_INVALID;
+    const int e = ppn::na2d_bwd_launch(qkv, rpb, dout, dqkv, drpb, workspace, B, H, W, heads, dilation, scale, dtype, (hipStream_t)stream);
+    if (e == -1) return PPN_E_INVALID;
     if (e != 0) return hip_fail((hipError_t)e);
     return PPN_OK;
 }

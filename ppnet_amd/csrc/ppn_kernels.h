@@ -71,8 +71,9 @@ int na2d_mfma_launch(const void* qkv, const void* pad_kv, const float* rpb, void
                      float scale, hipStream_t stream);
 int na2d_halo16_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
                        float scale, const void* zero, hipStream_t stream);
-int na2d_bwd_launch(const void* qkv, const float* rpb, const void* dout, void* dqkv, float* drpb, float* attn_p, float* attn_ds, int B, int H, int W,
-                    int heads, int dil, float scale, int dtype, hipStream_t stream);
+long long na2d_bwd_workspace_floats(int B, int H, int W, int heads, int dil);
+int na2d_bwd_launch(const void* qkv, const float* rpb, const void* dout, void* dqkv, float* drpb, float* workspace, int B, int H, int W, int heads,
+                    int dil, float scale, int dtype, hipStream_t stream);
 
 int norm_launch(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,
                 long long rows, int C, float eps, int dtype, int Hr, int Wr, int Hp, int Wp, const void* xoff, hipStream_t stream);

@@ -86,12 +86,15 @@ class _NA2DFunction(torch.autograd.Function):
         B, H, W, C3 = qkv.shape
         dout = dout.to(qkv.dtype).contiguous()
         dqkv = torch.empty_like(qkv)
-        drpb = torch.zeros_like(rpb32)
-        ws = torch.empty(2 * B * heads * H * W * 49, dtype=torch.float32, device=qkv.device)
+        drpb = torch.empty_like(rpb32)
+        need = L.lib.ppn_na2d_bwd_workspace(B, H, W, heads, dilation)     # softmax statistics + drpb partial sums; P is recomputed
+        if need < 0:
+            raise ValueError(f"ppn_na2d_bwd: shape {(B, H, W, heads, dilation)} is outside the kernel")
+        ws = torch.empty(need, dtype=torch.float32, device=qkv.device)
         dtype = {torch.float32: 0, torch.bfloat16: 1}[qkv.dtype]
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         with torch.cuda.device(qkv.device):
-            rc = L.lib.ppn_na2d_bwd(p(qkv), p(rpb32), p(dout), p(dqkv), p(drpb), p(ws), B, H, W, heads, dilation, float(scale), dtype,
+            rc = L.lib.ppn_na2d_bwd(p(qkv), p(rpb32), p(dout), p(dqkv), p(drpb), p(ws), need, B, H, W, heads, dilation, float(scale), dtype,
                                     ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream))
         L.check(rc, "ppn_na2d_bwd")
         return dqkv, drpb.to(rpb_dtype), None, None, None

@@ -119,10 +119,12 @@ def test_virtual_padding_equals_materialised_padding(dev, H, W, Hr, Wr, d, heads
         assert np.abs(got.float().cpu().numpy() - ref).max() < 3e-2
 
 
-@pytest.mark.parametrize("B,H,W,heads,d", [(2, 9, 11, 2, 1), (1, 16, 14, 2, 2), (2, 7, 7, 1, 1), (1, 21, 24, 1, 3)])
+@pytest.mark.parametrize("B,H,W,heads,d", [(2, 9, 11, 2, 1), (1, 16, 14, 2, 2), (2, 7, 7, 1, 1), (1, 21, 24, 1, 3), (1, 20, 27, 2, 1),
+                                           (1, 37, 40, 1, 2), (1, 33, 17, 1, 1)])
 def test_na2d_backward_vs_fp64_autograd(dev, B, H, W, heads, d):
     """ppn_na2d_bwd (dQ, dK, dV, dRPB) against autograd through the float64 gather definition of the op (oracle/segnet_ref.py
-    na_fp64, itself checked against the brute-force oracle) — borders, dilation groups of unequal size, several heads."""
+    na_fp64, itself checked against the brute-force oracle) — borders, dilation groups of unequal size, several heads, maps of
+    several 8 x 8 regions per axis (a border key is seen by up to 10 queries per axis; 20 rows: a region whose query halo is 15)."""
     import torch
     from oracle import segnet_ref as SR
     from ppnet_amd.na import na2d_autograd
@@ -155,6 +157,37 @@ def test_na2d_backward_vs_fp64_autograd(dev, B, H, W, heads, d):
     want.backward(gout.double())
     assert (qkv.grad.double() - q64.grad).abs().max() < 2e-4 * max(1.0, float(q64.grad.abs().max()))
     assert (rpb.grad.double() - r64.grad).abs().max() < 2e-4 * max(1.0, float(r64.grad.abs().max()))
+
+
+def test_na2d_backward_bf16_workspace_and_reproducibility(dev):
+    """bfloat16 tensors (float32 arithmetic) against the float32 run on the same values; the rpb gradient is bit-identical from
+    run to run (fixed summation order, no atomics); a workspace smaller than ppn_na2d_bwd_workspace says is refused."""
+    import ctypes
+    import torch
+    from ppnet_amd import _lib as L
+    from ppnet_amd.na import na2d_autograd
+    torch.manual_seed(3)
+    B, H, W, heads, d = 2, 19, 23, 2, 1
+    C = heads * 32
+    q16 = torch.randn(B, H, W, 3 * C, device=dev).to(torch.bfloat16)
+    rpb = torch.randn(heads, 13, 13, device=dev) * 0.5
+    gout = torch.randn(B, H, W, C, device=dev).to(torch.bfloat16)
+    grads = []
+    for dt in (torch.float32, torch.bfloat16, torch.float32):
+        q = q16.detach().to(dt).clone().requires_grad_(True)
+        r = rpb.clone().requires_grad_(True)
+        na2d_autograd(q, r, heads, d, 32 ** -0.5).backward(gout.to(dt))
+        grads.append((q.grad.float(), r.grad.clone()))
+    assert (grads[1][0] - grads[0][0]).abs().max() < 2e-2 * float(grads[0][0].abs().max())      # bf16-rounded outputs
+    assert (grads[1][1] - grads[0][1]).abs().max() < 1e-3 * max(1.0, float(grads[0][1].abs().max()))
+    assert torch.equal(grads[2][0], grads[0][0]) and torch.equal(grads[2][1], grads[0][1])
+    need = L.lib.ppn_na2d_bwd_workspace(B, H, W, heads, d)
+    assert need == B * heads * H * W * 4 + 3 * 3 * B * heads * 169
+    assert L.lib.ppn_na2d_bwd_workspace(B, 6, W, heads, d) < 0
+    q = q16.float()
+    dq, dr, ws = torch.empty_like(q), torch.empty_like(rpb), torch.empty(need, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert L.lib.ppn_na2d_bwd(p(q), p(rpb), p(gout.float()), p(dq), p(dr), p(ws), need - 1, B, H, W, heads, d, 32 ** -0.5, 0, None) == -1      # PPN_E_INVALID
 
 
 def test_na_module_trains_through_padding(dev):

@@ -27,14 +27,15 @@ def timeit(step, n):
     return (time.perf_counter() - t) / n
 
 
-for batch, amp in ((8, None), (64, None), (64, torch.bfloat16)):
+ONLY = os.environ.get("TRAIN_TIMING_ONLY", "")                      # "segnet" / "gennet": one model only (profiler passes)
+for batch, amp in (() if ONLY == "segnet" else ((8, None), (64, None), (64, torch.bfloat16))):
     grid, space, path = pairs(batch // 8, 8, 1)
     net = AEViT(1, 1, img_resolution=R, dim=24).to(dev)
     opt = train.gennet_optimizer(net); sch = train.PolyLR(opt, 1000)
     dt = timeit(lambda: train.gennet_train_step(net, opt, sch, space, path, amp_dtype=amp), 10)
     print("GenNet train step: batch %3d %s  %.1f ms  %.0f maps/s" % (batch, "bf16 autocast" if amp else "fp32", dt * 1e3, batch / dt))
 
-for batch in (8,):
+for batch in (() if ONLY == "gennet" else (8,)):
     grid, space, path = pairs(1, batch, 2)
     seg = SegNet().to(dev)
     trainer = train.segnet_trainer(seg)
