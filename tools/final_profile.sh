@@ -1,6 +1,7 @@
 #!/bin/bash
-# Round-end measurement set (run on the GPU box from the repo root): bench line, kernel stats, HBM traffic and SQ counters of the
-# maps kernel, PPNet per-kernel breakdown, matrix-pipe counters of the MFMA kernels, NA kernel counters.
+# Round-end measurement set (run on the GPU box from the repo root): bench line (default window and the driver's own command, plain
+# and under the kernel tracer), kernel stats, HBM traffic and SQ counters of the maps kernel, PPNet per-kernel breakdown, matrix-pipe
+# counters of the MFMA kernels, NA kernel timings and counters, the NAT projection kernels against the vendor GEMM, training steps.
 # Outputs land in gpurun_out/final/; copy the summaries to profiles/ (tools/final_profile.sh TAG names them).
 set -e
 TAG=${1:-r03}
@@ -37,6 +38,12 @@ cd $ROOT
 GEMM_ONE_TILE_PER_BLOCK=1 tools/micro/gemm_bench > $OUT/gemm_bench.txt 2>&1 || true
 tools/micro/gemm_bench >> $OUT/gemm_bench.txt 2>&1 || true
 python3 tools/gemm_vs_lib.py > $OUT/gemm_vs_lib.txt 2>&1 || true
+python3 tools/natgemm_timing.py > $OUT/natgemm_timing.txt 2>&1 || true
+python3 tools/ppnet_ab.py > $OUT/ppnet_ab.txt 2>&1 || true
+NA_SHAPE=64,1 bash tools/na_pmc.sh > $OUT/na2d_halo16_pmc.txt 2>&1 || true
+NA_SHAPE=64,1 bash tools/na_fetch.sh >> $OUT/na2d_halo16_pmc.txt 2>&1 || true
+python3 tools/train_timing.py > $OUT/train_timing.txt 2>&1 || true
+python3 tools/na_bwd_timing.py >> $OUT/train_timing.txt 2>&1 || true
 python3 tools/graph_latency.py > $OUT/graph_latency.txt 2>&1 || true
 bash tools/steps_sweep.sh > $OUT/steps_sweep.txt 2>&1 || true
 tail -c 900 $OUT/bench.json
