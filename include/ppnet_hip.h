@@ -426,7 +426,9 @@ int ppn_nat128_proj_add_bf16(void* s, const void* a, const void* w, int64_t toke
  * epilogue: 0 = + bias[n]; 1 = gelu(+ bias[n]) (erf form); 2 = c += (the residual stream accumulates, bias unused);
  * 3 = max(+ bias[n], 0) (a 1x1 ConvModule: convolution + folded BatchNorm + ReLU, mmseg/models/decode_heads/uper_head.py:40-63).
  * K % 64 == 0, K >= 128, N % 8 == 0.  persistent_blocks: 0 = one tile per workgroup; else the number of workgroups (a multiple
- * of 8, normally the CU count) that walk the tiles with the LDS-DMA stream running across tile boundaries (M, N % 256 == 0). */
+ * of 8, normally the CU count) that walk the tiles with the LDS-DMA stream running across tile boundaries (M, N % 256 == 0).
+ * Few rows (fewer than 64 tiles of 256 x 256, N % 64 == 0: batches of 1-16 problems) go to a kernel of their own whatever
+ * persistent_blocks says: a workgroup per 32 x 64 block of c, its four waves splitting K (csrc/gemm_small.hip). */
 int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int32_t N, int32_t K, int32_t epilogue,
                   int32_t persistent_blocks, void* stream);
 

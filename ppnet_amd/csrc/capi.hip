@@ -580,7 +580,11 @@ int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int6
         (epilogue != 2 && !bias) || persistent_blocks < 0 || (persistent_blocks % 8) != 0)
         return PPN_E_INVALID;
     if (M * K * 2 >= (1LL << 32) || (long long)N * K * 2 >= (1LL << 32)) return PPN_E_UNSUPPORTED;
-    const int e = ppn::gemm_mfma_launch(a, w, bias, c, M, N, K, epilogue, persistent_blocks, (hipStream_t)stream);
+    // few rows (small batches): the wave-per-block kernel of gemm_small.hip instead of a handful of 256 x 256 tiles
+    static const bool no_small = getenv("PPNET_NO_SMALL_GEMM") != nullptr;       // A/B
+    const int e = (!no_small && ppn::gemm_small_wanted(M, N, K))
+                      ? ppn::gemm_small_launch(a, w, bias, c, M, N, K, epilogue, (hipStream_t)stream)
+                      : ppn::gemm_mfma_launch(a, w, bias, c, M, N, K, epilogue, persistent_blocks, (hipStream_t)stream);
     if (e != 0) return hip_fail((hipError_t)e);
     return PPN_OK;
 }

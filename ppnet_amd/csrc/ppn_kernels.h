@@ -110,6 +110,8 @@ int nat128_ln_mlp_launch(void* s, const float* off, const void* lnw, const void*
                          long long tokens, float eps, hipStream_t stream);
 int nat128_proj_add_launch(void* s, const void* a, const void* w, long long tokens, hipStream_t stream);
 int gennet_trunk_launch(const void* x, void* y, const float* params, int B, int N, int n_blocks, hipStream_t stream);
+bool gemm_small_wanted(long long M, int N, int K);
+int gemm_small_launch(const void* a, const void* w, const float* bias, void* c, long long M, int N, int K, int epilogue, hipStream_t stream);
 int nat_gemm_launch(const void* a, const void* w, const float* bias, const float* colsum, const float* stats_in, int p_in,
                     float* stats_out, void* c, long long M, int N, int K, int mode, float eps, hipStream_t stream);
 int row_stats_launch(const void* x, long long rows, int C, float* stats, hipStream_t stream);

@@ -305,11 +305,13 @@ class NATBlock(nn.Module):
 
     def _ln_folded_ok(self, x):
         """The level runs on ppn_nat_gemm_bf16 (csrc/nat_gemm.hip): folded bfloat16 inference, C and the MLP width multiples of
-        256, whole 256-token tiles."""
+        256, whole 256-token tiles — and at least 64 of them in the narrowest projection (tokens x C): the persistent kernels walk
+        256 x 256 tiles one per CU, and a batch of 1-16 problems has a handful (a level-2 projection at batch 1 is TWO tiles, each
+        walking K alone: 34 us where the wave-per-block kernel of gemm_small.hip behind a LayerNorm launch takes 12)."""
         b0 = self.blocks[0]
         C = x.shape[-1]
         return (b0.folded and x.is_cuda and x.dtype == torch.bfloat16 and b0.attn.qkv.weight.dtype == torch.bfloat16 and C % 256 == 0
-                and (x.numel() // C) % 256 == 0 and b0.mlp.fc1.out_features % 256 == 0 and b0.mlp._erf_gelu() and x.is_contiguous()
+                and (x.numel() // C) % 256 == 0 and (x.numel() // C // 256) * (C // 256) >= int(os.environ.get("PPNET_SMALL_GEMM_TILES", "64")) and b0.mlp.fc1.out_features % 256 == 0 and b0.mlp._erf_gelu() and x.is_contiguous()
                 and not torch.is_grad_enabled() and not os.environ.get("PPNET_LIBRARY_GEMM") and not os.environ.get("PPNET_NO_LN_FOLD"))
 
     def _forward_ln_folded(self, x, out_norm):

@@ -56,7 +56,9 @@ def test_conv3x3_relu_classify2_vs_torch():
 
 
 @pytest.mark.parametrize("M,N,K,persistent", [(300, 264, 128, 0), (512, 256, 192, 0), (256 * 40, 768, 192, 256), (256 * 33, 512, 320, 256),
-                                              (65536, 512, 512, 0), (65536, 512, 512, 256)])
+                                              (65536, 512, 512, 0), (65536, 512, 512, 256),
+                                              # few rows (batches of 1-16): the wave-per-block kernel of gemm_small.hip
+                                              (49, 1024, 4096, 0), (196, 1536, 512, 0), (784, 768, 256, 0), (3136, 512, 2048, 0), (33, 64, 128, 0)])
 def test_gemm_bf16_epilogues_vs_torch(M, N, K, persistent):
     from ppnet_amd import fused
     torch.manual_seed(M % 97 + N)
@@ -66,6 +68,7 @@ def test_gemm_bf16_epilogues_vs_torch(M, N, K, persistent):
     lin = a.float() @ w.float().t()
     _close(fused.gemm_bf16(a, w, b, "bias", persistent_blocks=persistent), lin + b)
     _close(fused.gemm_bf16(a, w, b, "bias_gelu", persistent_blocks=persistent), F.gelu(lin + b))
+    _close(fused.gemm_bf16(a, w, b, "bias_relu", persistent_blocks=persistent), F.relu(lin + b))
     c0 = torch.randn(M, N, device="cuda").to(BF)
     c = c0.clone()
     out = fused.gemm_bf16(a, w, None, "accum", out=c, persistent_blocks=persistent)
