@@ -84,6 +84,26 @@ def test_padded_grid_queries_only_real_tokens(dev, H, W, Hr, Wr, d, heads):
     assert np.abs(got - want).max() < 2e-5
 
 
+@pytest.mark.parametrize("B,side,C,heads,d,pad", [(256, 64, 128, 4, 1, 0), (64, 56, 128, 4, 1, 0), (8, 32, 256, 8, 1, 0), (4, 40, 64, 2, 2, 0),
+                                                  (3, 33, 64, 2, 1, 0), (2, 30, 64, 2, 2, 34)])
+def test_persistent_halo_kernel_is_bit_identical_to_the_per_tile_kernel(dev, B, side, C, heads, d, pad, monkeypatch):
+    """na2d_halo16_kernel (persistent, LDS-DMA staging, tile descriptors) computes block for block what na2d_mfma_kernel<16> does:
+    the outputs are EQUAL, at the bench's full size (256 x 64 x 64 x 4 heads), on partial tiles, dilation groups of unequal size
+    and virtual padding — a size-independent property the oracle is too slow to give."""
+    import torch
+    from ppnet_amd.na import na2d_forward
+    torch.manual_seed(side + d)
+    qkv = torch.randn(B, side, side, 3 * C, device=dev, dtype=torch.bfloat16)
+    rpb = torch.randn(heads, 13, 13, device=dev)
+    kw = dict(pad_kv=torch.randn(3 * C, device=dev, dtype=torch.bfloat16), padded_hw=(pad, pad)) if pad else {}
+    monkeypatch.setenv("PPNET_NA_RT", "16")                      # both runs on 16 x 16 regions
+    monkeypatch.delenv("PPNET_NA_HALO16", raising=False)
+    a = na2d_forward(qkv, rpb, heads, d, 32 ** -0.5, **kw)
+    monkeypatch.setenv("PPNET_NA_HALO16", "0")
+    b = na2d_forward(qkv, rpb, heads, d, 32 ** -0.5, **kw)
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+
+
 def test_no_cpu_fallback():
     import torch
     from ppnet_amd import na
