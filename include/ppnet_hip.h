@@ -432,6 +432,11 @@ int ppn_nat128_proj_add_bf16(void* s, const void* a, const void* w, int64_t toke
 int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int32_t N, int32_t K, int32_t epilogue,
                   int32_t persistent_blocks, void* stream);
 
+/* Row-statistics partials per row that the accumulating mode of ppn_nat_gemm_bf16 writes for a residual stream of width C (and
+ * that the LayerNorm modes expect to read for K = C): one per 128 columns on the small-tile kernel (C <= 512), one per 256 on the
+ * persistent one.  C % 256 == 0; < 0: invalid. */
+int32_t ppn_nat_gemm_partials(int32_t C);
+
 /* The dense half of a NAT layer at C = 256 / 512 / 1024 with everything between two projections in the GEMMs' epilogues
  * (SegNet/nat.py:62-85 `Mlp.forward`, :140-153 `NATLayer.forward`; csrc/nat_gemm.hip).  a [M][K], w [N][K] (torch Linear
  * layout), c [M][N], all bfloat16; M, N % 256 == 0, K % 64 == 0.
@@ -440,10 +445,12 @@ int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int6
  *           every row of a (1 <= partials_in <= 4, summed in order; the LayerNorm is over the K features, eps as given):
  *           c = rstd (a w^T - mean colsum) + bias.  K >= 192.
  *   mode 1: c = gelu(mode 0) (erf form; evaluated through a logistic fit of erf, |error| < 3e-5).
- *   mode 2: c += a w^T + bias IN PLACE, and stats_out [N / 256][M][2] receives, per 256-column tile, (sum, sum of squares) of every
- *           row of the NEW c over the tile's columns — of the bfloat16 values stored: what mode 0 / 1 of the next projection
- *           reads as stats_in with partials_in = N / 256.  colsum / stats_in unused.
- * Persistent: one workgroup per CU; bit-reproducible (no atomics). */
+ *   mode 2: c += a w^T + bias IN PLACE, and stats_out [P][M][2], P = ppn_nat_gemm_partials(N), receives per column tile (sum, sum of
+ *           squares) of every row of the NEW c over the tile's columns — of the bfloat16 values stored: what mode 0 / 1 of the
+ *           next projection reads as stats_in with partials_in = P.  colsum / stats_in unused.
+ * Two kernels behind it: stream widths <= 512 (HBM-bound: levels 1-2) on 128 x 128 tiles, three workgroups per CU
+ * (csrc/nat_gemm128.hip); wider ones on the persistent 256 x 256 kernel, one workgroup per CU (csrc/nat_gemm.hip).  Bit-reproducible
+ * (no atomics). */
 int ppn_nat_gemm_bf16(const void* a, const void* w, const float* bias, const float* colsum, const float* stats_in, int32_t partials_in,
                       float* stats_out, void* c, int64_t M, int32_t N, int32_t K, int32_t mode, float eps, void* stream);
 

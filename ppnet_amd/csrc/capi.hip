@@ -597,10 +597,18 @@ int ppn_nat_gemm_bf16(const void* a, const void* w, const float* bias, const flo
     if (mode != 2 && (!colsum || !stats_in || partials_in < 1 || partials_in > 4 || K / 64 < 3)) return PPN_E_INVALID;
     if (mode == 2 && !stats_out) return PPN_E_INVALID;
     if ((long long)N * 2 * 8 >= (1LL << 31) || (long long)K * 2 * 8 >= (1LL << 31)) return PPN_E_UNSUPPORTED;     // per-lane 32-bit offsets
-    const int e = ppn::nat_gemm_launch(a, w, bias, colsum, stats_in, partials_in, stats_out, c, M, N, K, mode, eps, (hipStream_t)stream);
+    // the HBM-bound levels (stream width <= 512) run on the small-tile kernel of nat_gemm128.hip, the rest on nat_gemm.hip's persistent one
+    const int e = ppn::nat_gemm128_wanted(N, K, mode)
+                      ? ppn::nat_gemm128_launch(a, w, bias, colsum, stats_in, partials_in, stats_out, c, M, N, K, mode, eps, (hipStream_t)stream)
+                      : ppn::nat_gemm_launch(a, w, bias, colsum, stats_in, partials_in, stats_out, c, M, N, K, mode, eps, (hipStream_t)stream);
     if (e == -2) return hip_fail(hipErrorInvalidDevice);
     if (e != 0) return hip_fail((hipError_t)e);
     return PPN_OK;
+}
+
+int32_t ppn_nat_gemm_partials(int32_t C) {
+    if (C <= 0 || (C % 256) != 0) return -1;
+    return ppn::nat_gemm128_partials(C) ? C / 128 : C / 256;
 }
 
 int ppn_row_stats_bf16(const void* x, int64_t rows, int32_t C, float* stats, void* stream) {

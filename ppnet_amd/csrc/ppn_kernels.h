@@ -112,6 +112,10 @@ int nat128_proj_add_launch(void* s, const void* a, const void* w, long long toke
 int gennet_trunk_launch(const void* x, void* y, const float* params, int B, int N, int n_blocks, hipStream_t stream);
 bool gemm_small_wanted(long long M, int N, int K);
 int gemm_small_launch(const void* a, const void* w, const float* bias, void* c, long long M, int N, int K, int epilogue, hipStream_t stream);
+bool nat_gemm128_wanted(int N, int K, int mode);
+bool nat_gemm128_partials(int C);
+int nat_gemm128_launch(const void* a, const void* w, const float* bias, const float* colsum, const float* stats_in, int p_in, float* stats_out,
+                       void* c, long long M, int N, int K, int mode, float eps, hipStream_t stream);
 int nat_gemm_launch(const void* a, const void* w, const float* bias, const float* colsum, const float* stats_in, int p_in,
                     float* stats_out, void* c, long long M, int N, int K, int mode, float eps, hipStream_t stream);
 int row_stats_launch(const void* x, long long rows, int C, float* stats, hipStream_t stream);

@@ -370,7 +370,7 @@ def nat_gemm(a, w, bias32, mode, out, colsum=None, stats_in=None, stats_out=None
     """The NAT projections with the LayerNorm / residual / statistics in the epilogue (ppn_nat_gemm_bf16, csrc/nat_gemm.hip).
     mode "ln": out = LN(a) W0^T + b0 from the raw rows of a (w = W0 diag(gamma), bias32 = b0 + W0 beta, colsum, stats_in
     [P, M, 2]); "ln_gelu": gelu of that; "acc": out += a w^T + bias32 in place, row partials of the new out -> stats_out
-    [N / 256, M, 2]."""
+    [nat_partials(N), M, 2]."""
     md = {"ln": 0, "ln_gelu": 1, "acc": 2}[mode]
     M, K = a.shape
     N = w.shape[0]
@@ -382,12 +382,21 @@ def nat_gemm(a, w, bias32, mode, out, colsum=None, stats_in=None, stats_out=None
         assert stats_in.dtype == torch.float32 and stats_in.is_contiguous() and stats_in.dim() == 3 and stats_in.shape[1:] == (M, 2)
         P = stats_in.shape[0]
     else:
-        assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.shape == (N // 256, M, 2)
+        assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.shape == (nat_partials(N), M, 2)
     with torch.cuda.device(a.device):
         rc = L.lib.ppn_nat_gemm_bf16(_p(a), _p(w), _p(bias32), _p(colsum), _p(stats_in), P, _p(stats_out), _p(out), M, N, K, md, float(eps),
                                      ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream))
     L.check(rc, "ppn_nat_gemm_bf16")
     return out
+
+
+def nat_partials(C):
+    """Row-statistics partials per row of a residual stream of width C (ppn_nat_gemm_partials: one per 128 columns on the small-tile
+    kernel that serves C <= 512, one per 256 on the persistent one)."""
+    n = L.lib.ppn_nat_gemm_partials(C)
+    if n < 0:
+        raise ValueError(f"ppn_nat_gemm_partials({C})")
+    return n
 
 
 def nat_gemm_ok(M, N, K, acc):

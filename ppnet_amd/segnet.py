@@ -329,7 +329,7 @@ class NATBlock(nn.Module):
         M = B * H * W
         s2 = x.view(M, C)
         st = fused.row_stats(s2)                                            # the level's first stream came from a LayerNorm kernel
-        P = C // 256
+        P = fused.nat_partials(C)
         st_mid = torch.empty(P, M, 2, dtype=torch.float32, device=x.device)
         st_out = torch.empty(P, M, 2, dtype=torch.float32, device=x.device)
         for blk in self.blocks:

@@ -66,13 +66,14 @@ def test_accumulating_projection_and_row_partials(M, N, K):
     g = torch.Generator(device="cuda").manual_seed(4)
     s0 = (torch.randn(M, N, device="cuda", generator=g) * 2.0).to(torch.bfloat16)
     s = s0.clone()
-    st = torch.full((N // 256, M, 2), float("nan"), dtype=torch.float32, device="cuda")
+    P = fused.nat_partials(N)                                  # one partial per 128 columns (N <= 512) or per 256
+    st = torch.full((P, M, 2), float("nan"), dtype=torch.float32, device="cuda")
     fused.nat_gemm(a, w, b, "acc", s, stats_out=st)
     ref = s0.double() + a.double() @ w.double().t() + b.double()
     err = (s.double() - ref).abs()
     tol = 2.0 ** -8 * ref.abs() + 2e-3
     assert bool((err <= tol).all()), float((err - tol).max())
-    sd = s.double().view(M, N // 256, 256)
+    sd = s.double().view(M, P, N // P)
     assert torch.allclose(st[:, :, 0].double().t(), sd.sum(2), rtol=1e-5, atol=2e-3)
     assert torch.allclose(st[:, :, 1].double().t(), (sd * sd).sum(2), rtol=1e-5, atol=2e-3)
     s2 = s0.clone()
@@ -90,7 +91,7 @@ def test_chain_equals_layernorm_then_projection():
     _, w1, b1 = _ops(M, 2 * C, C, 6)
     g = torch.Generator(device="cuda").manual_seed(7)
     s = torch.randn(M, C, device="cuda", generator=g).to(torch.bfloat16)
-    st = torch.empty(C // 256, M, 2, dtype=torch.float32, device="cuda")
+    st = torch.empty(fused.nat_partials(C), M, 2, dtype=torch.float32, device="cuda")
     fused.nat_gemm(a, wp, bp, "acc", s, stats_out=st)
     out = torch.empty(M, 2 * C, dtype=torch.bfloat16, device="cuda")
     fused.nat_gemm(s, w1, b1, "ln", out, colsum=w1.float().sum(1).contiguous(), stats_in=st, eps=1e-5)

@@ -23,7 +23,7 @@ for mode in ("ln", "ln_gelu", "acc"):
         b32 = torch.randn(N, device=dev)
         out = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
         if mode == "acc":
-            st = torch.empty(N // 256, M, 2, dtype=torch.float32, device=dev)
+            st = torch.empty(fused.nat_partials(N), M, 2, dtype=torch.float32, device=dev)
             t = timeit(lambda: fused.nat_gemm(a, w, b32, "acc", out, stats_out=st))
         else:
             st = fused.row_stats(a); cs = w.float().sum(1).contiguous()

@@ -42,7 +42,7 @@ for lvl, (M, C, depth) in enumerate([(262144, 256, 4), (65536, 512, 18), (16384,
         out = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
         if mode == "acc":
             lib = lambda: out.addmm_(a, w.t())
-            st = torch.empty(N // 256, M, 2, dtype=torch.float32, device=dev)
+            st = torch.empty(fused.nat_partials(N), M, 2, dtype=torch.float32, device=dev)
             own = lambda: fused.nat_gemm(a, w, b32, "acc", out, stats_out=st)
         else:
             lib = (lambda: F.linear(a, w, b16)) if mode == "ln" else (lambda: torch._addmm_activation(b16, a, w.t(), use_gelu=True))
