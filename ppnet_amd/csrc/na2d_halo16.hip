@@ -5,22 +5,25 @@
 // computes; 80 KB of LDS hold two workgroups per CU, their staging phases collide, and the staging's address arithmetic is a third
 // of the kernel's vector instructions — it ran at 0.3 of the HBM roofline with the matrix and vector pipes each a third busy.
 // Here one workgroup of 16 waves owns a CU for the whole launch and walks its share of the (tile, head) items:
-//   stage(i + 1)   66 KB of K and V rows + this head's 2.8 KB bias tables, copied HBM -> LDS by global_load_lds (LDS-DMA: 16 B per
-//                  lane, lane-linear in LDS, no VGPRs), 3 wave instructions per wave, into the OTHER of two LDS buffers
+//   stage(i + 1)   66 KB of K and V rows, copied HBM -> LDS by global_load_lds (LDS-DMA: 16 B per lane, lane-linear in LDS, no
+//                  VGPRs), 2 - 3 pairs of wave instructions per wave, into the OTHER of two LDS buffers
 //   compute(i)     wave w = block (w / 4, w % 4) of the tile: 10 + 15 MFMAs, the softmax of 16 queries (na2d_mfma.hip's block)
 // with ONE barrier per tile (after it every wave has finished tile i - 1, so its buffer may be overwritten; the stage of tile i was
 // issued a whole tile earlier).  The per-lane part of a piece's address (halo row t, column sc, chunk) does not depend on the tile;
-// what does comes from a 64-byte descriptor per tile that a preparation kernel writes once per launch (with the bias tables): byte
-// offsets of its halo, query and output origins and its geometry — a tile costs one scalar load instead of nine integer divisions,
-// and a piece of the halo two compares (its class: stored token / padded token / zeros) before a DMA from a uniform base.
+// what does comes from a 64-byte descriptor per tile (byte offsets of its halo, query and output origins, its geometry) that a
+// preparation kernel writes ONCE PER GEOMETRY — the launcher keeps the tables — so a tile costs one scalar load instead of nine integer
+// divisions, a piece of the halo two compares (its class: stored token / padded token / zeros) before a DMA from a uniform base, and a
+// launch neither allocates nor prepares anything (a captured HIP graph holds the kernel alone).
 //
-// LDS (141,824 B): 2 x { K image 22 x 24 slots x 64 B | V image (both with the 32-byte halves of a row swapped on every other
-// group of 4 slots: conflict-free fragment reads) | 4 zero slots | BT, BTM 2 x 16 x 24 f32 }.  The column pitch is 24 slots for 22 loaded: a block reads 16 slots from
+// LDS (138,752 B): 2 x { K image 22 x 24 slots x 64 B | V image (both with the 32-byte halves of a row swapped on every other
+// group of 4 slots: conflict-free fragment reads) | 4 zero slots } | BT, BTM 2 x 16 x 24 f32 of the workgroup's head.  The column pitch is 24 slots for 22 loaded: a block reads 16 slots from
 // column co <= 12, so its last 4 run into the next halo row (the V image / the zero slots behind the last row) — finite values
 // whose logits carry the window mask, i.e. probability exactly 0.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include "ppn_device.h"
 #include "ppn_kernels.h"
 
@@ -41,7 +44,8 @@ constexpr int SLOTS = HROWS * PC;      // 528 = 33 x 16
 constexpr int IMG = SLOTS * KB;
 constexpr int TAIL = 4 * KB;
 constexpr int TBL = 2 * BT_ROWS * BT_PITCH * 4;
-constexpr int BUF = 2 * IMG + TAIL + TBL;
+constexpr int BUF = 2 * IMG + TAIL;                  // a tile: K image | V image | 4 zero slots
+constexpr int LDS_TOTAL = 2 * BUF + TBL;             // two tiles | the head's two bias tables
 constexpr int NPAIR = SLOTS / 16;      // wave instructions per image
 constexpr int NW = 16, NTHR = NW * 64;
 constexpr int PPW = (NPAIR + NW - 1) / NW;
@@ -69,22 +73,10 @@ __device__ __forceinline__ float max3(float a, float b, float c) {        // (fm
 }
 }  // namespace
 
-// Once per launch: blocks [0, heads) write the two bias tables of a head in the units of the raw product ([heads][2][16][24] f32:
-// rpb[h] / scale zero-padded; the same inside the centred 7 x 7 window and -1e30 elsewhere = bias AND window mask of a query whose
-// window the border does not clamp); the blocks behind them write one descriptor per tile.
-__global__ __launch_bounds__(BT_ROWS * BT_PITCH) void na2d_halo16_prep_kernel(const float* __restrict__ rpb, float* __restrict__ table, int* __restrict__ desc,
-                                                                              int heads, float scale, int H, int W, int Hr, int Wr, int dil, int tiles_y,
-                                                                              int tiles_x, int total_tiles, int padded) {
-    const int t = threadIdx.x;
-    if ((int)blockIdx.x < heads) {
-        const int h = blockIdx.x;
-        const int a = t / BT_PITCH, b = t - a * BT_PITCH;
-        const float v = (a < 13 && b < 13) ? rpb[(size_t)h * 169 + a * 13 + b] / scale : 0.f;
-        table[((size_t)h * 2) * BT_ROWS * BT_PITCH + t] = v;
-        table[((size_t)h * 2 + 1) * BT_ROWS * BT_PITCH + t] = (a >= MN && a <= 3 * MN && b >= MN && b <= 3 * MN) ? v : -1.0e30f;
-        return;
-    }
-    const int gtile = ((int)blockIdx.x - heads) * (BT_ROWS * BT_PITCH) + t;
+// One descriptor per tile: it depends on the launch's geometry only (not on the data), so a launcher-side cache keeps it per shape.
+__global__ __launch_bounds__(256) void na2d_halo16_prep_kernel(int* __restrict__ desc, int heads, int H, int W, int Hr, int Wr, int dil, int tiles_y, int tiles_x,
+                                                               int total_tiles, int padded) {
+    const int gtile = (int)blockIdx.x * 256 + threadIdx.x;
     if (gtile >= total_tiles) return;
     const int ntiles = tiles_y * tiles_x;
     const int bz = gtile / ntiles, tile_id = gtile - bz * ntiles;
@@ -133,7 +125,7 @@ __device__ __forceinline__ Tile load_tile(const int* __restrict__ desc, int gtil
 }
 
 __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pad_kv, __bf16* __restrict__ out,
-                                                           const float* __restrict__ bt_table, const int* __restrict__ desc, int Wr, int Ws, int heads,
+                                                           const float* __restrict__ rpb, const int* __restrict__ desc, int Wr, int Ws, int heads,
                                                            int dil, float scale, int n_items, const __bf16* __restrict__ zero) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nl[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -205,8 +197,6 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
                 }
             }
         }
-        if (wave < 3 && wave * 64 + lane < TBL / 16)                       // this head's two tables
-            dma16(bt_table + (size_t)T.h * (TBL / 4), (unsigned)(wave * 64 + lane) * 16, buf + 2 * IMG + TAIL + wave * 1024);
     };
 
     // ---- this wave's block of the tile: rows 4 by .., columns 4 bx ..; lane (j, g): query (jy, jx) of it, quarter g
@@ -225,6 +215,20 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
         return *reinterpret_cast<const bf16x8*>(qkvb + T.q + (unsigned)T.h * (MHD * 2) + qoff);
     };
 
+    // The two bias tables of a head, in the units of the raw product ([2][16][24] f32: rpb[h] / scale zero-padded; the same inside the
+    // centred 7 x 7 window and -1e30 elsewhere = bias AND window mask of a query whose window the border does not clamp), built by the
+    // workgroup itself: its items are 32 apart (a multiple of every power-of-two head count), so the head changes rarely or never
+    float* const BTL = reinterpret_cast<float*>(nl + 2 * BUF);
+    auto build_tables = [&](int hh) __attribute__((always_inline)) {
+        if (threadIdx.x < 2 * BT_ROWS * BT_PITCH) {
+            const int which = threadIdx.x >= BT_ROWS * BT_PITCH, t = threadIdx.x - which * BT_ROWS * BT_PITCH;
+            const int a = t / BT_PITCH, b = t - a * BT_PITCH;
+            const float v = (a < 13 && b < 13) ? rpb[(size_t)hh * 169 + a * 13 + b] / scale : 0.f;
+            BTL[threadIdx.x] = (which == 0 || (a >= MN && a <= 3 * MN && b >= MN && b <= 3 * MN)) ? v : -1.0e30f;
+        }
+    };
+    int h_tab = h;
+    build_tables(h_tab);
     Tile cur = load_tile(desc, gtile, h);
     stage(cur, lds0);
     bf16x8 q_next = q_request(cur);
@@ -240,6 +244,11 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
         bf16x8 qf = q_next;
         asm volatile("" : "+v"(qf));
         __syncthreads();
+        if (cur.h != h_tab) {                                              // workgroup-uniform, rare: every wave has left the old tables
+            h_tab = cur.h;
+            build_tables(h_tab);
+            __syncthreads();
+        }
         const unsigned char* buf = nl + bsel * BUF;
         const int nitem = item + nx;
         const bool more = nitem < end;                                     // workgroup-uniform
@@ -258,7 +267,7 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
         if (T.valid && ti0 < T.hq && tj0 < T.wq) {                         // wave-uniform
             const unsigned char* Kimg = buf;
             const unsigned char* Vimg = buf + IMG;
-            const unsigned char* BT = buf + 2 * IMG + TAIL;
+            const unsigned char* BT = nl + 2 * BUF;
             const int hs = T.hs, ws = T.ws, hq = T.hq, wq = T.wq;
             const bool cut = ti0 + TQ > hq || tj0 + TQ > wq;               // wave-uniform: the image ends inside this block
             const int jyc = cut ? min(jy, hq - 1 - ti0) : jy, jxc = cut ? min(jx, wq - 1 - tj0) : jx;
@@ -370,6 +379,41 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
     }
 }
 
+namespace {
+// The descriptor tables, one per launch geometry, kept for the life of the process (a PPNet / DiNAT forward has a handful of
+// geometries; 64 bytes per tile).  A table is built on first use with hipMalloc + the preparation kernel + a stream synchronise —
+// never inside a stream capture (hipMalloc is illegal there): a geometry first met while capturing is declined (-1: the caller's
+// per-tile kernel runs), the warm-up pass in front of a capture has normally met it already.  Nothing is allocated or freed per
+// launch, so a captured graph holds no allocation nodes of this kernel.
+struct DescKey {
+    int dev, B, H, W, Hr, Wr, heads, dil, padded;
+    bool operator<(const DescKey& o) const {
+        const int a[9] = {dev, B, H, W, Hr, Wr, heads, dil, padded}, b[9] = {o.dev, o.B, o.H, o.W, o.Hr, o.Wr, o.heads, o.dil, o.padded};
+        for (int i = 0; i < 9; ++i)
+            if (a[i] != b[i]) return a[i] < b[i];
+        return false;
+    }
+};
+std::mutex g_desc_mutex;
+std::map<DescKey, int*> g_desc;
+
+const int* descriptors(const DescKey& k, int tiles_y, int tiles_x, long long total, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_desc_mutex);
+    const auto it = g_desc.find(k);
+    if (it != g_desc.end()) return it->second;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    if (g_desc.size() >= 512) return nullptr;                               // (a process that meets this many geometries keeps the per-tile kernel for the rest)
+    int* d = nullptr;
+    if (hipMalloc((void**)&d, (size_t)total * DESC * 4) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(na2d_halo16_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d, k.heads, k.H, k.W, k.Hr, k.Wr, k.dil, tiles_y,
+                       tiles_x, (int)total, k.padded);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    g_desc[k] = d;
+    return d;
+}
+}  // namespace
+
 // 0 = launched; -1 = shape outside this kernel (the caller falls back to na2d_mfma_kernel<16>)
 int na2d_halo16_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int H, int W, int Hr, int Wr, int heads, int dil,
                        float scale, const void* zero, hipStream_t stream) {
@@ -381,34 +425,26 @@ int na2d_halo16_launch(const void* qkv, const void* pad_kv, const float* rpb, vo
     // a piece's offset from its tile's halo origin, and a query's from its tile's, are 32-bit (bytes)
     if (items >= (1LL << 30) || heads > 255 || (long long)(HROWS + 2) * dil * Ws * 3 * heads * MHD * 2 >= (1LL << 31)) return -1;
     static std::atomic<int> state{0};                                        // 0 unknown, 1 ready, -1 unavailable
-    static int n_cu = 0;
+    static std::atomic<int> n_cu{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorUnknown;
     if (!state.load()) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorUnknown;
-        n_cu = prop.multiProcessorCount & ~7;
-        const hipError_t e = hipFuncSetAttribute((const void*)na2d_halo16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
-        state.store(e == hipSuccess && n_cu >= 8 ? 1 : -1);
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorUnknown;
+        n_cu.store(prop.multiProcessorCount & ~7);
+        const hipError_t e = hipFuncSetAttribute((const void*)na2d_halo16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+        state.store(e == hipSuccess && n_cu.load() >= 8 ? 1 : -1);
     }
     if (state.load() < 0) return -1;
-    const size_t tbl_bytes = (size_t)heads * TBL, desc_bytes = (size_t)total * DESC * 4;
-    unsigned char* ws = nullptr;                                             // stream-ordered scratch, freed behind the attention kernel
-    hipError_t e = hipMallocAsync((void**)&ws, tbl_bytes + desc_bytes, stream);
-    if (e != hipSuccess) return (int)e;
-    float* table = reinterpret_cast<float*>(ws);
-    int* desc = reinterpret_cast<int*>(ws + tbl_bytes);
-    constexpr int PT = BT_ROWS * BT_PITCH;
-    hipLaunchKernelGGL(na2d_halo16_prep_kernel, dim3(heads + (unsigned)((total + PT - 1) / PT)), dim3(PT), 0, stream, rpb, table, desc, heads, scale, H, W,
-                       Hr, Wr, dil, tiles_y, tiles_x, (int)total, pad_kv ? 1 : 0);
+    const int* desc = descriptors(DescKey{dev, B, H, W, Hr, Wr, heads, dil, pad_kv ? 1 : 0}, tiles_y, tiles_x, total, stream);
+    if (!desc) return -1;
     // whole XCD rows of workgroups, no more than the items of an XCD's run
     const long long per = (items + 7) / 8;
-    int grid = n_cu;
+    int grid = n_cu.load();
     if (per * 8 < grid) grid = (int)per * 8;
-    hipLaunchKernelGGL(na2d_halo16_kernel, dim3(grid), dim3(NTHR), 2 * BUF, stream, (const __bf16*)qkv, (const __bf16*)pad_kv, (__bf16*)out,
-                       (const float*)table, (const int*)desc, Wr, Ws, heads, dil, scale, (int)items, (const __bf16*)zero);
-    e = hipGetLastError();
-    const hipError_t f = hipFreeAsync(ws, stream);
-    return (int)(e != hipSuccess ? e : f);
+    hipLaunchKernelGGL(na2d_halo16_kernel, dim3(grid), dim3(NTHR), LDS_TOTAL, stream, (const __bf16*)qkv, (const __bf16*)pad_kv, (__bf16*)out, rpb, desc, Wr,
+                       Ws, heads, dil, scale, (int)items, (const __bf16*)zero);
+    return (int)hipGetLastError();
 }
 
 }  // namespace ppn
