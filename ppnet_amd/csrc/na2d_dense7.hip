@@ -10,8 +10,8 @@
 //   ppn_na2d_fwd_vpad; slots 49..63 read a zero line), V rows by global_load_lds into the wave's private 4 KB of LDS and back
 //   transposed (ds_read_b64_tr_b16), Q as the B operand (only the REAL queries: 16 per group at dilation 16 / 8 / 4 / 2),
 //   S^T = K . Q^T (4 MFMAs per 16 queries), logits = S^T * scale * log2 e + T with T[head][query position][key slot] a small
-//   float32 table built per launch (rpb gathered by relative position, -1e30 outside the window and on slots 49..63) whose rows for
-//   the workgroup's head live in LDS, exact softmax over the 64 slots, O^T = V^T . P^T (4 MFMAs).  ~100 VALU instructions per 16
+//   float32 table (rpb gathered by relative position, -1e30 outside the window and on slots 49..63) that the workgroup builds for
+//   its head in LDS at start (no per-launch table kernel or allocation), exact softmax over the 64 slots, O^T = V^T . P^T (4 MFMAs).  ~100 VALU instructions per 16
 //   queries; one memory round trip per item, so the kernel runs at the latency x occupancy product: 3.3-4.2 TB/s of algorithmic bytes.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
@@ -31,27 +31,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int HD7 = 32, D7_WAVES = 8;
 }  // namespace
 
-// T[h][u * G + v][slot]: rpb[h][kr - u + 6][kc - v + 6] / scale (the units of the raw product: the table is the logits' initial
-// accumulator) for key slot = kr * G + kc inside the query's window
-// (start clamp(u - 3, 0, G - 7) per axis: the whole group for G = 7), -1e30 outside it and on slots >= G * G
-template <int G>
-__global__ __launch_bounds__(256) void na2d_dense_table_kernel(const float* __restrict__ rpb, float* __restrict__ table, int heads, float inv_scale) {
-    constexpr int NK = G * G;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= heads * NK * 64) return;
-    const int slot = idx & 63, qp = (idx >> 6) % NK, h = idx / (NK * 64);
-    float v = -1.0e30f;
-    if (slot < NK) {
-        const int u = qp / G, w = qp - u * G, kr = slot / G, kc = slot - kr * G;
-        const int wu = min(max(u - 3, 0), G - 7), ww = min(max(w - 3, 0), G - 7);
-        if (kr >= wu && kr < wu + 7 && kc >= ww && kc < ww + 7) v = rpb[(size_t)h * 169 + (kr - u + 6) * 13 + (kc - w + 6)] * inv_scale;
-    }
-    table[idx] = v;
-}
-
 template <int G7>
 __global__ __launch_bounds__(64 * D7_WAVES, 6) void na2d_dense7_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pad_kv,
-                                                                    const float* __restrict__ table, __bf16* __restrict__ out, int B, int Hr, int Wr,
+                                                                    const float* __restrict__ rpb, __bf16* __restrict__ out, int B, int Hr, int Wr,
                                                                     int heads, int dil, float scale, long long n_items, const __bf16* __restrict__ zero) {
     constexpr int NK = G7 * G7;                                            // 49 or 64 key slots in use
     constexpr int TP = 68;                                                 // table row pitch in floats: 16 consecutive rows start on 16 different bank groups
@@ -71,7 +53,23 @@ __global__ __launch_bounds__(64 * D7_WAVES, 6) void na2d_dense7_kernel(const __b
     // take the same groups with neighbouring heads, so the two heads of a 128-byte line still meet in one L2.
     const int h = (int)((blockIdx.x >> 3) % heads);
     const long long slot0 = (long long)(blockIdx.x / (8 * heads)) * 8 + (blockIdx.x & 7), nslots = (long long)(gridDim.x / (8 * heads)) * 8;
-    for (int i = threadIdx.x; i < NK * 64; i += 64 * D7_WAVES) tl[(i >> 6) * TP + (i & 63)] = table[(size_t)h * NK * 64 + i];
+    // T[u * G + v][slot] = rpb[h][kr - u + 6][kc - v + 6] / scale (the units of the raw product: the table is the logits' initial
+    // accumulator) for key slot = kr * G + kc inside the query's window (start clamp(u - 3, 0, G - 7) per axis: the whole group for
+    // G = 7), -1e30 outside it and on slots >= G * G.  Built by the workgroup from its head's 169 values: nothing is prepared or
+    // allocated per launch (a captured graph holds this kernel alone)
+    {
+        const float inv_scale = 1.0f / scale;
+        for (int i = threadIdx.x; i < NK * 64; i += 64 * D7_WAVES) {
+            const int slot = i & 63, qp = i >> 6;
+            float v = -1.0e30f;
+            if (slot < NK) {
+                const int u = qp / G7, w = qp - u * G7, kr = slot / G7, kc = slot - kr * G7;
+                const int wu = min(max(u - 3, 0), G7 - 7), ww = min(max(w - 3, 0), G7 - 7);
+                if (kr >= wu && kr < wu + 7 && kc >= ww && kc < ww + 7) v = rpb[(size_t)h * 169 + (kr - u + 6) * 13 + (kc - w + 6)] * inv_scale;
+            }
+            tl[qp * TP + slot] = v;
+        }
+    }
     __syncthreads();
     for (long long gq = slot0; gq * D7_WAVES < n_items; gq += nslots) {
         const long long grp = gq * D7_WAVES + wave;                          // n_items = number of (image, group) pairs
@@ -172,11 +170,6 @@ template <int G>
 static int launch_dense_groups(const void* qkv, const void* pad_kv, const float* rpb, void* out, int B, int Hr, int Wr, int heads, int dil, float scale,
                                const __bf16* zero, hipStream_t stream) {
     const long long groups = (long long)B * dil * dil;
-    float* table = nullptr;                                                    // stream-ordered scratch, freed behind the attention kernel
-    const int n = heads * G * G * 64;
-    hipError_t e = hipMallocAsync((void**)&table, (size_t)n * sizeof(float), stream);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(na2d_dense_table_kernel<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rpb, table, heads, 1.0f / scale);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
@@ -186,10 +179,8 @@ static int launch_dense_groups(const void* qkv, const void* pad_kv, const float*
     const long long per_set = 8LL * heads, want_sets = ((groups + D7_WAVES - 1) / D7_WAVES + 7) / 8;
     long long sets = std::max<long long>(1, std::min<long long>(want_sets, ((long long)cus * 3) / per_set));
     hipLaunchKernelGGL(na2d_dense7_kernel<G>, dim3((unsigned)(sets * per_set)), dim3(64 * D7_WAVES), 0, stream, (const __bf16*)qkv, (const __bf16*)pad_kv,
-                       table, (__bf16*)out, B, Hr, Wr, heads, dil, scale, groups, zero);
-    e = hipGetLastError();
-    const hipError_t f = hipFreeAsync(table, stream);
-    return (int)(e != hipSuccess ? e : f);
+                       rpb, (__bf16*)out, B, Hr, Wr, heads, dil, scale, groups, zero);
+    return (int)hipGetLastError();
 }
 
 // Serves a launch when every dilation group is 7 x 7 (H == W == 7 * dil: the padded grid of the vpad entry point, or a real grid of
