@@ -576,11 +576,7 @@ def main():
     while True:
         # N > 1: every step carries a collective, so all ranks must run the SAME number of warm steps — the decision to go on is
         # taken on the slowest rank's clock (one all-reduce per chunk of 25 steps, outside the timed region)
-        elapsed_w = time.perf_counter() - tw
-        if world > 1:
-            tflag = torch.tensor([elapsed_w], dtype=torch.float64, device=dev)
-            dist.all_reduce(tflag, op=dist.ReduceOp.MAX)
-            elapsed_w = float(tflag.item())
+        elapsed_w = shard.agreed_max(time.perf_counter() - tw, world, dev)
         if elapsed_w >= warm_target_s:
             break
         for _ in range(25 * GROUP):

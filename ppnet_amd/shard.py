@@ -76,3 +76,13 @@ def gather_records(rec, world, sizes=None, group=None, out=None, always_collecti
     out = torch.empty(world * m, rec.shape[1], dtype=rec.dtype, device=rec.device)
     dist.all_gather_into_tensor(out, pad, group=group)
     return torch.cat([out[r * m:r * m + sizes[r]] for r in range(world)])
+
+
+def agreed_max(value, world, device=None):
+    """The largest `value` over the ranks, on every rank (one all-reduce; `value` itself when world == 1).  bench.py decides with it
+    whether the untimed clock-warm phase goes on: every step carries a collective at N > 1, so all ranks must take the same number."""
+    if world <= 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

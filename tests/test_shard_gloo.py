@@ -47,6 +47,34 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _warm_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # bench.py's clock-warm loop with each rank on its own (skewed) clock: the chunks every rank runs must be the same number
+    clock, chunks = 0.0, 0
+    while True:
+        if shard.agreed_max(clock, world) >= 1.0:
+            break
+        chunks += 1
+        clock += 0.21 if rank == 0 else 0.34          # rank 1's steps are slower
+        dist.all_reduce(torch.zeros(1))               # the collective a step carries: a rank that ran one more would hang here
+    with open(os.path.join(out_dir, f"warm{rank}.txt"), "w") as f:
+        f.write(str(chunks))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_clock_warm_phase_takes_the_same_steps_on_every_rank(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_warm_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = (int(open(tmp_path / f"warm{r}.txt").read()) for r in range(2))
+    assert a == b == 3                                # the slowest clock decides: 0.34, 0.68, 1.02
+    assert shard.agreed_max(0.5, 1) == 0.5
+
+
 def test_shard_ranges_cover_exactly():
     for n, w in [(100, 1), (100, 8), (5, 2), (7, 4), (3, 8)]:
         seen = []
