@@ -49,13 +49,17 @@ constexpr int LDS_TOTAL = 2 * BUF + TBL;             // two tiles | the head's t
 constexpr int NPAIR = SLOTS / 16;      // wave instructions per image
 constexpr int NW = 16, NTHR = NW * 64;
 constexpr int PPW = (NPAIR + NW - 1) / NW;
-constexpr int DESC = 16;               // ints per tile descriptor
+constexpr int DESC = 32;               // ints per tile descriptor
 static_assert(SLOTS % 16 == 0 && TBL % 16 == 0 && (PC & 7) == 0, "staging layout");
 static_assert(PPW * 10 <= 32 && HROWS + 2 <= 32 && PC <= 32, "packed staging coordinates");
 
 // descriptor of a tile (what of it does not depend on the head): byte offsets of the halo origin's k row (head 0), of the tile
 // origin's q row and of its output row; the halo extent and its real part (virtual padding), packed; the tile's geometry
-enum { D_KV = 0, D_Q = 2, D_O = 4, D_EXT = 6, D_TY0, D_TX0, D_HS, D_WS, D_HQ, D_WQ, D_R0, D_C0, D_VALID };
+enum { D_KV = 0, D_Q = 2, D_O = 4, D_EXT = 6, D_TY0, D_TX0, D_HS, D_WS, D_HQ, D_WQ, D_R0, D_C0, D_VALID, D_ROW = 16, D_COL = 20 };
+// D_ROW + by / D_COL + bx: the geometry of block row by / block column bx of the tile, so that a wave derives its block's from two
+// words instead of a dozen clamps and compares: window origin r0 (16 bits) | its place in the halo ro << 16 (4) | bias-table row
+// r0 - ti0 + 6 << 20 (4) | the block row holds queries << 24 | the image ends inside it << 25 | no query's window is clamped << 26
+enum { B_LIVE = 1 << 24, B_CUT = 1 << 25, B_INT = 1 << 26 };
 
 __device__ __forceinline__ int clampm(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -105,14 +109,24 @@ __global__ __launch_bounds__(256) void na2d_halo16_prep_kernel(int* __restrict__
     d[D_O] = (int)(unsigned)oo; d[D_O + 1] = (int)(unsigned)(oo >> 32);
     d[D_EXT] = NR | (NC << 8) | (NRr << 16) | (NCr << 24);
     d[D_TY0] = ty0; d[D_TX0] = tx0; d[D_HS] = hs; d[D_WS] = ws; d[D_HQ] = hq; d[D_WQ] = wq; d[D_R0] = R0; d[D_C0] = C0; d[D_VALID] = 1;
+    for (int k = 0; k < RT / TQ; ++k) {
+        const int ti0 = ty0 + k * TQ, tj0 = tx0 + k * TQ;
+        const int r0 = clampm(ti0 - MN, 0, hs - MK), c0 = clampm(tj0 - MN, 0, ws - MK);          // the block's window origin
+        const int rl = ti0 < hq, cl = tj0 < wq;
+        d[D_ROW + k] = rl ? (r0 | ((r0 - R0) << 16) | ((r0 - ti0 + MK - 1) << 20) | B_LIVE | (ti0 + TQ > hq ? B_CUT : 0) |
+                             (ti0 >= MN && ti0 + TQ - 1 + MN <= hs - 1 ? B_INT : 0)) : 0;
+        d[D_COL + k] = cl ? (c0 | ((c0 - C0) << 16) | ((c0 - tj0 + MK - 1) << 20) | B_LIVE | (tj0 + TQ > wq ? B_CUT : 0) |
+                             (tj0 >= MN && tj0 + TQ - 1 + MN <= ws - 1 ? B_INT : 0)) : 0;
+    }
+    for (int k = D_COL + RT / TQ; k < DESC; ++k) d[k] = 0;
 }
 
 struct Tile {
     unsigned long long kv, q, o;
-    int ext, ty0, tx0, hs, ws, hq, wq, R0, C0, valid, h;
+    int ext, ty0, tx0, hs, ws, hq, wq, R0, C0, valid, h, row, col;       // row / col: D_ROW / D_COL of the loading wave's block
 };
 
-__device__ __forceinline__ Tile load_tile(const int* __restrict__ desc, int gtile, int h) {
+__device__ __forceinline__ Tile load_tile(const int* __restrict__ desc, int gtile, int h, int by, int bx) {
     const int* d = desc + (size_t)gtile * DESC;
     Tile t;
     t.h = h;
@@ -121,6 +135,7 @@ __device__ __forceinline__ Tile load_tile(const int* __restrict__ desc, int gtil
     t.o = (unsigned long long)(unsigned)d[D_O] | ((unsigned long long)(unsigned)d[D_O + 1] << 32);
     t.ext = d[D_EXT]; t.ty0 = d[D_TY0]; t.tx0 = d[D_TX0]; t.hs = d[D_HS]; t.ws = d[D_WS]; t.hq = d[D_HQ]; t.wq = d[D_WQ];
     t.R0 = d[D_R0]; t.C0 = d[D_C0]; t.valid = d[D_VALID];
+    t.row = d[D_ROW + by]; t.col = d[D_COL + bx];
     return t;
 }
 
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
     };
     int h_tab = h;
     build_tables(h_tab);
-    Tile cur = load_tile(desc, gtile, h);
+    Tile cur = load_tile(desc, gtile, h, by, bx);
     stage(cur, lds0);
     bf16x8 q_next = q_request(cur);
     int bsel = 0;
@@ -257,23 +272,23 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
             gtile += step_t;
             h += step_h;
             if (h >= heads) { h -= heads; ++gtile; }
-            nxt = load_tile(desc, gtile, h);
+            nxt = load_tile(desc, gtile, h, by, bx);
             stage(nxt, lds0 + (bsel ^ 1) * BUF);
             q_next = q_request(nxt);
         }
 
         const Tile& T = cur;
-        const int ti0 = T.ty0 + by * TQ, tj0 = T.tx0 + bx * TQ;
-        if (T.valid && ti0 < T.hq && tj0 < T.wq) {                         // wave-uniform
+        if (T.row & T.col & B_LIVE) {                                      // wave-uniform: the block holds queries (an invalid tile's words are 0)
             const unsigned char* Kimg = buf;
             const unsigned char* Vimg = buf + IMG;
             const unsigned char* BT = nl + 2 * BUF;
+            const int ti0 = T.ty0 + by * TQ, tj0 = T.tx0 + bx * TQ;
             const int hs = T.hs, ws = T.ws, hq = T.hq, wq = T.wq;
-            const bool cut = ti0 + TQ > hq || tj0 + TQ > wq;               // wave-uniform: the image ends inside this block
+            const bool cut = ((T.row | T.col) & B_CUT) != 0;               // wave-uniform: the image ends inside this block
             const int jyc = cut ? min(jy, hq - 1 - ti0) : jy, jxc = cut ? min(jx, wq - 1 - tj0) : jx;
             const bool qvalid = jyc == jy && jxc == jx;
-            const int r0 = clampm(ti0 - MN, 0, hs - MK), c0 = clampm(tj0 - MN, 0, ws - MK);    // this block's window origin
-            const int ro = r0 - T.R0, co = c0 - T.C0;                      // ... inside the staged halo: ro + 9 < HROWS, co <= 12
+            const int r0 = T.row & 0xffff, c0 = T.col & 0xffff;            // this block's window origin
+            const int ro = (T.row >> 16) & 15, co = (T.col >> 16) & 15;    // ... inside the staged halo: ro + 9 < HROWS, co <= 12
 
             // all LDS reads of the logit phase are issued before the first use (K fragments: slot j of halo row ro + t, channels
             // 8g .. 8g+7; the 40 bias values of this lane), then S^T: key tile t = halo row ro + t, slots co .. co + 15
@@ -285,8 +300,8 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
             // logit is (q.k + b) * scale * log2 e).  A block none of whose 16 queries has its window clamped by the border
             // (wave-uniform) takes the table whose entries outside the centred 7 x 7 window are -1e30: bias and window mask are then
             // one function of the key's offset from the query (na2d_mfma.hip)
-            const bool interior = ti0 >= MN && ti0 + TQ - 1 + MN <= hs - 1 && tj0 >= MN && tj0 + TQ - 1 + MN <= ws - 1 && !cut;
-            const int bts = ((interior ? BT_ROWS * BT_PITCH : 0) + (r0 - ti0 + MK - 1) * BT_PITCH + (c0 - tj0 + MK - 1)) * 4;   // uniform
+            const bool interior = (T.row & T.col & B_INT) != 0 && !cut;
+            const int bts = ((interior ? BT_ROWS * BT_PITCH : 0) + ((T.row >> 20) & 15) * BT_PITCH + ((T.col >> 20) & 15)) * 4;   // uniform
             const int btl = cut ? (-jyc * BT_PITCH - jxc + 4 * g) * 4 : btl_full;
             const float* bt = reinterpret_cast<const float*>(BT + bts + btl);
 #pragma unroll
