@@ -21,4 +21,10 @@ run PPNET_LIBRARY_NAT128=1 $S
 run PPNET_TOKENIZER_TWO_KERNELS=1 $S
 run PPNET_LIBRARY_TOKENIZER=1 $S
 run PPNET_NO_FOLD=1 $S
+run PPNET_NA_HALO16=0 tests/test_gpu_na.py $S
+run PPNET_NO_LN_FOLD=1 $S tests/test_gpu_natgemm.py
+run PPNET_LIBRARY_GEMM=1 $S
+run PPNET_NAT_GEMM128=0 $S tests/test_gpu_natgemm.py
+run PPNET_NAT_GEMM128=all $S tests/test_gpu_natgemm.py
+run PPNET_NO_SMALL_GEMM=1 $S tests/test_gpu_mfma.py
 exit $rc
