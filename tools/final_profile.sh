@@ -25,7 +25,7 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -- python3 $ROOT/tools/p
 python3 $ROOT/tools/kernel_breakdown.py /tmp/pp extract_paths_kernel 2 45 > $OUT/ppnet_kernel_breakdown_b256.txt
 grep "ms per batch" $OUT/pp.log >> $OUT/ppnet_kernel_breakdown_b256.txt
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d /tmp/ppm -- python3 $ROOT/tools/profile_ppnet.py 256 > $OUT/ppm.log 2>&1
-python3 $ROOT/tools/pmc_avg.py /tmp/ppm | grep -i "gemm_bf16\|na2d\|gennet\|Cijk" > $OUT/ppnet_pmc_mfma.txt || true
+python3 $ROOT/tools/pmc_avg.py /tmp/ppm | grep -i "gemm\|na2d\|gennet\|nat128\|Cijk" > $OUT/ppnet_pmc_mfma.txt || true
 # NA kernels on every (level, dilation) shape + their counters
 python3 $ROOT/tools/na_timing.py > $OUT/na_timing.txt 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY --output-format csv -d /tmp/na_sq -- python3 $ROOT/tools/na_timing.py > $OUT/na_sq.log 2>&1
