@@ -7,10 +7,12 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 Pinned: tests/test_oracle_golden.py checks every function here against tests/golden/*.npz,
 which were captured from the reference's own modules (tests/golden/make_fixtures.py).
 
-NOT pinned ("parity unpinned"): the two rasters the reference delegates to
-third-party code that is absent here and not integer-reproducible —
-  * torchvision rotate/affine of the corridor mask (Path.py:160-161,175; MapGenerate.py:103-106)
-    -> restated as an explicit nearest-neighbour inverse map (`rotate_nearest`, `translate_nearest`)
+Pinned to the primitive: torchvision rotate/affine of the corridor mask (Path.py:160-161,175; MapGenerate.py:103-106) —
+torchvision is absent, but its tensor path is a published composition of torch primitives that ARE importable;
+`rotate_nearest` / `translate_nearest` restate it in float32 and are bit-equal to that composition (see "rasters").
+
+NOT pinned ("parity unpinned"): the raster the reference delegates to
+third-party code that is not integer-reproducible —
   * matplotlib->JPEG->PIL('1')->crop->Resize obstacle raster (Path.py:36-49)
     -> restated as "the data point the pixel centre shows lies inside the inked ellipse" (`disc_raster`, `raster_geometry`).
 
@@ -387,42 +389,102 @@ def convexhull(pathpoint_world, R, map_size, order="canonical"):
     return hull.astype(np.float64)
 
 
-# --------------------------------------------------------------------------- rasters (own rule)
+# --------------------------------------------------------------------------- rasters
+# Corridor resample: torchvision 0.12's TENSOR path, restated from its published algorithm and pinned bit for bit to the
+# primitives it calls (tests/test_oracle_golden.py::test_resample_rule_is_torchvisions_tensor_path builds that path from
+# torch.linspace / bmm / torch.nn.functional.grid_sample, which are importable, and compares source indices):
+#   F.rotate(img, angle)       -> matrix = _get_inverse_affine_matrix([0, 0], -angle, [0, 0], 1, [0, 0])
+#   F.affine(img, 0, [tx, ty]) -> matrix = _get_inverse_affine_matrix([0, 0], 0, [tx, ty], 1, [0, 0])
+#   theta = float32(matrix) [2,3];  base grid x_j = j + 0.5 - w/2, y_i = i + 0.5 - h/2 (torch.linspace, exact in float32)
+#   rescaled theta: row 0 / (0.5 w), row 1 / (0.5 h)  (float32 divisions)
+#   grid = base.bmm(rescaled theta^T)  -- sgemm with K = 3, an FMA chain in k order:  g = fl(fma(y, b, fl(x a)) + c)
+#   grid_sample(nearest, zeros, align_corners=False):  u = fl(fl((g + 1) (size / 2)) - 0.5);  index = nearbyint(u)
+# The float64 form of the same map (rounds 1-3) differs from it on ~5 pixels per million of a dense random image (near-ties
+# of the rounding) and on none of the 11 golden corridor canvases.
+F32 = np.float32
+
+
 def _nearbyint(x):
     return np.rint(x)      # round half to even, like std::nearbyint in grid_sample's nearest mode
 
 
-def rotate_nearest(img, angle_deg):
-    """Nearest-neighbour rotation by `angle_deg` counter-clockwise about the image centre, zero
-    fill — the explicit rule that stands in for torchvision.transforms.functional.rotate
-    (tensor path, torchvision 0.12: inverse affine grid + grid_sample(nearest, zeros,
-    align_corners=False)). out[i,j] = img[ni(ys + h/2 - 0.5), ni(xs + w/2 - 0.5)],
-    (xs, ys) = (c*xo - s*yo, s*xo + c*yo), xo = j + 0.5 - w/2, yo = i + 0.5 - h/2."""
-    h, w = img.shape
-    b = angle_deg * np.pi / 180.0
-    c, s = np.cos(b), np.sin(b)
-    yo = (np.arange(h) + 0.5 - h / 2)[:, None]
-    xo = (np.arange(w) + 0.5 - w / 2)[None, :]
-    xs = c * xo - s * yo
-    ys = s * xo + c * yo
-    jj = _nearbyint(xs + (w / 2 - 0.5)).astype(np.int64)
-    ii = _nearbyint(ys + (h / 2 - 0.5)).astype(np.int64)
-    ok = (ii >= 0) & (ii < h) & (jj >= 0) & (jj < w)
-    out = np.zeros_like(img)
-    out[ok] = img[ii[ok], jj[ok]]
-    return out
+def _fma32(y, b, p):
+    """fl32(y * b + p) for float32 arrays, exactly: the product of two float32 is exact in float64; the float64 sum s
+    carries the TwoSum error e, and rounding s to float32 equals rounding s + e unless s sits exactly on a float32
+    rounding boundary, where e decides the direction."""
+    yb = y.astype(np.float64) * np.float64(b)
+    p64 = p.astype(np.float64)
+    s = yb + p64
+    bb = s - yb
+    e = (yb - (s - bb)) + (p64 - bb)
+    r = s.astype(F32)                                  # round-half-even of s
+    d = s - r.astype(np.float64)                       # exact
+    cand = (d != 0) & (e != 0)
+    if cand.any():
+        # s = r + d; if s is exactly the midpoint of r and its neighbour nxt = r + 2d, the true value s + e lies on the
+        # side e points to: nxt when e and d have the same sign, r otherwise
+        nxt = np.nextafter(r, np.where(d > 0, F32(np.inf), F32(-np.inf)).astype(F32))
+        half = np.abs(nxt.astype(np.float64) - r.astype(np.float64)) * 0.5
+        r = np.where(cand & (np.abs(d) == half) & (np.sign(e) == np.sign(d)), nxt, r)
+    return r.astype(F32)
 
 
-def translate_nearest(img, tx, ty, out_h, out_w):
-    """torchvision affine(angle=0, translate=[tx,ty]) then crop [0:out_h,0:out_w]:
-    out[i,j] = img[ni(i - ty), ni(j - tx)], zero fill."""
+def inverse_affine_matrix(angle_deg, translate):
+    """torchvision.transforms.functional._get_inverse_affine_matrix(center=[0, 0], angle, translate, scale=1, shear=[0, 0])
+    in Python floats, as published (torchvision 0.12 functional.py)."""
+    rot = math.radians(angle_deg)
+    tx, ty = float(translate[0]), float(translate[1])
+    a = math.cos(rot - 0.0) / math.cos(0.0)
+    b = -math.cos(rot - 0.0) * math.tan(0.0) / math.cos(0.0) - math.sin(rot)
+    c = math.sin(rot - 0.0) / math.cos(0.0)
+    d = -math.sin(rot - 0.0) * math.tan(0.0) / math.cos(0.0) + math.cos(rot)
+    m = [d, -b, 0.0, -c, a, 0.0]
+    m[2] += m[0] * (-0.0 - tx) + m[1] * (-0.0 - ty)
+    m[5] += m[3] * (-0.0 - tx) + m[4] * (-0.0 - ty)
+    m[2] += 0.0
+    m[5] += 0.0
+    return m
+
+
+def affine_source_index(h, w, matrix):
+    """Source (row, col) index arrays [h,w] of torchvision's tensor-path affine grid + nearest grid_sample for an h x w
+    image and a 2x3 inverse matrix (see the block comment above).  Out-of-image indices are returned as they are."""
+    th = np.asarray(matrix, dtype=np.float64).astype(F32).reshape(2, 3)
+    x = (np.arange(w, dtype=np.float64) + (0.5 - w * 0.5)).astype(F32)[None, :] + np.zeros([h, 1], F32)
+    y = (np.arange(h, dtype=np.float64) + (0.5 - h * 0.5)).astype(F32)[:, None] + np.zeros([1, w], F32)
+    out = []
+    for k, size in ((0, w), (1, h)):
+        den = F32(0.5 * size)
+        a, b, c = th[k, 0] / den, th[k, 1] / den, th[k, 2] / den
+        g = _fma32(y, b, x * a) + c
+        u = (g + F32(1)) * F32(size / 2) - F32(0.5)
+        out.append(_nearbyint(u).astype(np.int64))
+    return out[1], out[0]
+
+
+def _gather(img, ii, jj, out_h, out_w):
     h, w = img.shape
-    ii = _nearbyint(np.arange(out_h) - ty).astype(np.int64)[:, None] + np.zeros([1, out_w], np.int64)
-    jj = _nearbyint(np.arange(out_w) - tx).astype(np.int64)[None, :] + np.zeros([out_h, 1], np.int64)
+    ii, jj = ii[:out_h, :out_w], jj[:out_h, :out_w]
     ok = (ii >= 0) & (ii < h) & (jj >= 0) & (jj < w)
     out = np.zeros([out_h, out_w], dtype=img.dtype)
     out[ok] = img[ii[ok], jj[ok]]
     return out
+
+
+def rotate_nearest(img, angle_deg):
+    """torchvision.transforms.functional.rotate(img, angle_deg, NEAREST) on a tensor (what T.RandomRotation(degrees=
+    (a, a)) applies, Path.py:160-161, MapGenerate.py:103-104): counter-clockwise about the image centre, zero fill."""
+    h, w = img.shape
+    ii, jj = affine_source_index(h, w, inverse_affine_matrix(-angle_deg, [0.0, 0.0]))
+    return _gather(img, ii, jj, h, w)
+
+
+def translate_nearest(img, tx, ty, out_h, out_w):
+    """torchvision affine(img, angle=0, translate=[tx, ty], scale=1, shear=0) on a tensor, then the crop
+    [0:out_h, 0:out_w] (Path.py:175,178; MapGenerate.py:105-106): out[i, j] = img[~(i - ty), ~(j - tx)], zero fill."""
+    h, w = img.shape
+    ii, jj = affine_source_index(h, w, inverse_affine_matrix(0.0, [tx, ty]))
+    return _gather(img, ii, jj, out_h, out_w)
 
 
 def raster_geometry(R):

@@ -63,7 +63,8 @@ __host__ __device__ constexpr int maps_tab_bytes(int K) {
 
 // The corridor-touch margin's rounding budget (see the clearance filter): five nearest-neighbour roundings of <= sqrt(2) / 2 px
 // (corridor canvas, path-point lattice, two mask rotations, one fractional mask translation) and the half-pixel offset between
-// the label frame and the pixel-centre frame: 6 * 0.7072 = 4.2432.
+// the label frame and the pixel-centre frame: 6 * 0.7072 = 4.2432 (the float32 arithmetic of torchvision's maps moves a
+// source coordinate by < 1e-3 px, inside the remainder).
 #define PPN_TOUCH_ROUNDINGS 4.25
 
 // 8 occupancy bits -> 8 grid bytes: bit k set (= occupied) -> byte k 0x00, clear -> 0xFF.  Read-only device table (2 KB, L1 /
@@ -244,8 +245,8 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
             if (lane == 0) {
                 bc[0] = angle; bc[6] = ca; bc[7] = sa;
                 if constexpr (PHASE & 2) {
-                    double s3, c3;
-                    sincos_small((-angle) * PI / 180.0, s3, c3);              // rotate_nearest(space, -angle)
+                    double s3, c3;                                            // rotate_nearest(space, -angle): F.rotate's inverse
+                    sincos_small(angle * PPN_DEG2RAD, s3, c3);                // matrix [c, s, 0; -s, c, 0] of radians(angle)
                     bc[8] = c3; bc[9] = s3;
                 }
                 bci[0] = t0; bci[1] = t1; bci[2] = attempts; bci[3] = (int)flags;
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
             bc[2] = O.segpoint[(size_t)m * 22];      bc[3] = O.segpoint[(size_t)m * 22 + 1];        // init = segpoint[0]
             bc[4] = O.segpoint[(size_t)m * 22 + 20]; bc[5] = O.segpoint[(size_t)m * 22 + 21];       // end  = segpoint[10]
             double s3v, c3v;
-            sincos_small((-O.angle[m]) * PI / 180.0, s3v, c3v);           // rotate_nearest(space, -angle)
+            sincos_small(O.angle[m] * PPN_DEG2RAD, s3v, c3v);             // rotate_nearest(space, -angle), as in the placement half
             bc[8] = c3v; bc[9] = s3v;
         }
     }
@@ -544,17 +545,20 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
         // (MapGenerate.py:111 saturating sum): inverse-map the occupied pixels into the target path's mask,
         // one lane per pixel, 64 consecutive pixels per wave step.  Skipped when no obstacle can touch it.
         if (compose) {
+            const TvAxis rcol = tv_axis(c3, s3, 0.0, R), rrow = tv_axis(-s3, c3, 0.0, R);
+            const float ctr = 0.5f - 0.5f * (float)R;
             for (int base = wv * 64; base < R * R; base += NT) {
                 const int px = base + lane;
                 const int i = px / R, j = px - i * R;
                 const uint32_t wbits = occw[px >> 5];
                 bool clr = false;
                 if ((wbits >> (px & 31)) & 1u) {
-                    const int i1 = i - t1, j1 = j - t0;                       // translate: (tx, ty) = (translation[0], [1])
+                    // torchvision's float32 maps (ppn_device.h tv_src): the integer translate (tx, ty) = (translation[0], [1])
+                    // is exactly j - tx, i - ty under that rule (checked for every R and shift in the oracle), then the rotation
+                    const int i1 = i - t1, j1 = j - t0;
                     if (i1 >= 0 && i1 < R && j1 >= 0 && j1 < R) {
-                        const double yo = ((double)i1 + 0.5) - half, xo = ((double)j1 + 0.5) - half;
-                        const double xs = c3 * xo - s3 * yo, ys = s3 * xo + c3 * yo;
-                        const int jj = (int)rint(xs + (half - 0.5)), ii = (int)rint(ys + (half - 0.5));
+                        const float yo = (float)i1 + ctr, xo = (float)j1 + ctr;
+                        const int jj = tv_src(rcol, xo, yo), ii = tv_src(rrow, xo, yo);
                         if (ii >= 0 && ii < R && jj >= 0 && jj < R) {
                             const int bit = ii * R + jj;
                             clr = (P.space_bits[(size_t)pj * words + (bit >> 5)] >> (bit & 31)) & 1u;   // rare pass: straight from L2
@@ -681,14 +685,15 @@ __global__ __launch_bounds__(NT) void label_masks_kernel(ppn_paths_t P, ppn_maps
     extern __shared__ uint32_t lm_space[];
     const int m = blockIdx.x, tid = threadIdx.x, pj = m / placements;
     const int words = R * R / 32;
-    const double half = (double)R / 2.0;
     if (mask_space) {
         for (int w = tid; w < words; w += NT) lm_space[w] = P.space_bits[(size_t)pj * words + w];
         __syncthreads();
         const double angle = M.angle[m];
         const int t0 = M.translation[(size_t)m * 2], t1 = M.translation[(size_t)m * 2 + 1];
         double c3, s3;
-        sincos_small((-angle) * PI / 180.0, s3, c3);
+        sincos_small(angle * PPN_DEG2RAD, s3, c3);
+        const TvAxis rcol = tv_axis(c3, s3, 0.0, R), rrow = tv_axis(-s3, c3, 0.0, R);
+        const float ctr = 0.5f - 0.5f * (float)R;
         uint8_t* g = mask_space + (size_t)m * R * R;
         const int cpr = R / 16;
         for (int ch = tid; ch < R * cpr; ch += NT) {
@@ -696,13 +701,12 @@ __global__ __launch_bounds__(NT) void label_masks_kernel(ppn_paths_t P, ppn_maps
             const int i1 = i - t1;
             uint32_t bits = 0u;
             if (i1 >= 0 && i1 < R) {
-                const double yo = ((double)i1 + 0.5) - half;
+                const float yo = (float)i1 + ctr;
                 for (int k = 0; k < 16; ++k) {
                     const int j1 = j0 + k - t0;
                     if (j1 < 0 || j1 >= R) continue;
-                    const double xo = ((double)j1 + 0.5) - half;
-                    const double xs = c3 * xo - s3 * yo, ys = s3 * xo + c3 * yo;
-                    const int jj = (int)rint(xs + (half - 0.5)), ii = (int)rint(ys + (half - 0.5));
+                    const float xo = (float)j1 + ctr;
+                    const int jj = tv_src(rcol, xo, yo), ii = tv_src(rrow, xo, yo);
                     if (ii < 0 || ii >= R || jj < 0 || jj >= R) continue;
                     const int bit = ii * R + jj;
                     bits |= ((lm_space[bit >> 5] >> (bit & 31)) & 1u) << k;

@@ -449,8 +449,8 @@ __global__ __launch_bounds__(NT, PPN_PATHS_WAVES_PER_EU) void edage_paths_kernel
         const double t0 = Rd / 2.0 - mx, t1 = Rd / 2.0 - my;      // (t_row, t_col)
         for (int i = 0; i < hn; ++i) { hull[i][0] = hull[i][0] + t0; hull[i][1] = hull[i][1] + t1; }
         bc[0] = rotation; bc[1] = c; bc[2] = s; bc[3] = t0; bc[4] = t1;
-        const double b = (-rotation) * 3.141592653589793 / 180.0;       // rotate_nearest(canvas, -rotation)
-        bc[5] = cos(b); bc[6] = sin(b);
+        const double b = rotation * PPN_DEG2RAD;                 // rotate_nearest(canvas, -rotation): F.rotate's matrix is
+        bc[5] = cos(b); bc[6] = sin(b);                          // [cos b, sin b, 0; -sin b, cos b, 0], b = radians(rotation)
         O.rotation[p] = rotation;
         O.trans_rc[(size_t)p * 2] = t0; O.trans_rc[(size_t)p * 2 + 1] = t1;
         O.hull_n[p] = hn;
@@ -507,20 +507,26 @@ __global__ __launch_bounds__(NT, PPN_PATHS_WAVES_PER_EU) void edage_paths_kernel
             }
         }
         __syncthreads();
-        const double c2 = bc[5], s2 = bc[6];
+        // torchvision's float32 maps (ppn_device.h tv_axis / tv_src): translate [tx, ty] = [t_col, t_row] on the 2R canvas,
+        // then the rotation about its centre
+        const int S2 = 2 * R;
+        const TvAxis tcol = tv_axis(1.0, 0.0, -t_col, S2), trow = tv_axis(0.0, 1.0, -t_row, S2);
+        const TvAxis rcol = tv_axis(bc[5], bc[6], 0.0, S2), rrow = tv_axis(-bc[6], bc[5], 0.0, S2);
+        const float ctr = 0.5f - (float)R;                       // pixel k of the canvas has centre coordinate k + ctr
         const int words = R * R / 32, wpr = R / 32;
         const int live_cap = (PPN_PATH_POINTS * 8 - 512) / 2;      // entries the lat region holds behind ctile
         for (int w = tid; w < words; w += NT) {
             const int i = w / wpr, j0 = (w - i * wpr) * 32;
-            const int i1 = (int)rint((double)i - t_row);         // translate_nearest: ty = t_row
+            const int i1 = tv_src(trow, 0.0f, (float)i + ctr);   // translate: row i of the output shows row i1 of the rotated canvas
             bool maybe = false;
-            if (i1 >= 0 && i1 < 2 * R) {
-                const double yo = ((double)i1 + 0.5) - Rd;
-                const double xa = (rint((double)j0 - t_col) + 0.5) - Rd, xb = (rint((double)(j0 + 31) - t_col) + 0.5) - Rd;
-                const int ja = (int)rint(c2 * xa - s2 * yo + (Rd - 0.5)), ia = (int)rint(s2 * xa + c2 * yo + (Rd - 0.5));
-                const int jb = (int)rint(c2 * xb - s2 * yo + (Rd - 0.5)), ib = (int)rint(s2 * xb + c2 * yo + (Rd - 0.5));
-                const int x0 = max(min(ja, jb) - 1, 0), x1 = min(max(ja, jb) + 1, 2 * R - 1);
-                const int y0 = max(min(ia, ib) - 1, 0), y1 = min(max(ia, ib) + 1, 2 * R - 1);
+            if (i1 >= 0 && i1 < S2) {
+                const float yo = (float)i1 + ctr;
+                const int j1a = tv_src(tcol, (float)j0 + ctr, 0.0f), j1b = tv_src(tcol, (float)(j0 + 31) + ctr, 0.0f);
+                const float xa = (float)j1a + ctr, xb = (float)j1b + ctr;
+                const int ja = tv_src(rcol, xa, yo), ia = tv_src(rrow, xa, yo);
+                const int jb = tv_src(rcol, xb, yo), ib = tv_src(rrow, xb, yo);
+                const int x0 = max(min(ja, jb) - 1, 0), x1 = min(max(ja, jb) + 1, S2 - 1);
+                const int y0 = max(min(ia, ib) - 1, 0), y1 = min(max(ia, ib) + 1, S2 - 1);
                 for (int ty = y0 >> 4; ty <= (y1 >> 4); ++ty)
                     for (int tx = x0 >> 4; tx <= (x1 >> 4); ++tx) {
                         const int t = ty * tps + tx;
@@ -534,14 +540,14 @@ __global__ __launch_bounds__(NT, PPN_PATHS_WAVES_PER_EU) void edage_paths_kernel
             else slot = -2;                                       // list full (cannot happen for R <= 256): do it here
             if (slot == -2) {
                 uint32_t m = 0u;
-                const double yo = ((double)i1 + 0.5) - Rd;
+                const float yo = (float)i1 + ctr;
                 for (int b = 0; b < 32; ++b) {
-                    const int j1 = (int)rint((double)(j0 + b) - t_col);
-                    if (j1 < 0 || j1 >= 2 * R) continue;
-                    const double xo = ((double)j1 + 0.5) - Rd;
-                    const int jj = (int)rint(c2 * xo - s2 * yo + (Rd - 0.5)), ii = (int)rint(s2 * xo + c2 * yo + (Rd - 0.5));
-                    if (ii < 0 || ii >= 2 * R || jj < 0 || jj >= 2 * R) continue;
-                    const int bit = ii * 2 * R + jj;
+                    const int j1 = tv_src(tcol, (float)(j0 + b) + ctr, 0.0f);
+                    if (j1 < 0 || j1 >= S2) continue;
+                    const float xo = (float)j1 + ctr;
+                    const int jj = tv_src(rcol, xo, yo), ii = tv_src(rrow, xo, yo);
+                    if (ii < 0 || ii >= S2 || jj < 0 || jj >= S2) continue;
+                    const int bit = ii * S2 + jj;
                     m |= ((canvas[bit >> 5] >> (bit & 31)) & 1u) << b;
                 }
                 O.space_bits[(size_t)p * words + w] = m;
@@ -552,17 +558,16 @@ __global__ __launch_bounds__(NT, PPN_PATHS_WAVES_PER_EU) void edage_paths_kernel
         for (int e = tid; e < nl; e += NT) {
             const int w = live[e];
             const int i = w / wpr, j0 = (w - i * wpr) * 32;
-            const int i1 = (int)rint((double)i - t_row);
-            const double yo = ((double)i1 + 0.5) - Rd;
+            const int i1 = tv_src(trow, 0.0f, (float)i + ctr);
+            const float yo = (float)i1 + ctr;
             uint32_t m = 0u;
             for (int b = 0; b < 32; ++b) {
-                const int j1 = (int)rint((double)(j0 + b) - t_col);
-                if (j1 < 0 || j1 >= 2 * R) continue;
-                const double xo = ((double)j1 + 0.5) - Rd;
-                const double xs = c2 * xo - s2 * yo, ys = s2 * xo + c2 * yo;
-                const int jj = (int)rint(xs + (Rd - 0.5)), ii = (int)rint(ys + (Rd - 0.5));
-                if (ii < 0 || ii >= 2 * R || jj < 0 || jj >= 2 * R) continue;
-                const int bit = ii * 2 * R + jj;
+                const int j1 = tv_src(tcol, (float)(j0 + b) + ctr, 0.0f);
+                if (j1 < 0 || j1 >= S2) continue;
+                const float xo = (float)j1 + ctr;
+                const int jj = tv_src(rcol, xo, yo), ii = tv_src(rrow, xo, yo);
+                if (ii < 0 || ii >= S2 || jj < 0 || jj >= S2) continue;
+                const int bit = ii * S2 + jj;
                 m |= ((canvas[bit >> 5] >> (bit & 31)) & 1u) << b;
             }
             O.space_bits[(size_t)p * words + w] = m;

@@ -368,8 +368,8 @@ int gennet_dec_final_launch(const void* x, const void* wt, const float* bias, fl
                             hipStream_t stream) {
     const long long tiles = (long long)B * ((2 * H + DF_H - 1) / DF_H) * ((2 * W + DF_W - 1) / DF_W);
     if (tiles >= (1LL << 31)) return (int)hipErrorInvalidValue;
-    static int cus = 0;
-    if (!cus) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; else cus = 256; }
+    int cus = device_cu_count();
+    if (!cus) cus = 256;
     const long long grid = tiles < 2LL * cus ? tiles : 2LL * cus;          // 2 workgroups per CU (212 VGPRs: two waves per SIMD)
     hipLaunchKernelGGL(gennet_dec_final_kernel, dim3((unsigned)grid), dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)wt, bias, slope, w1, bias1,
                        (__bf16*)y, B, H, W);

@@ -512,13 +512,9 @@ int gennet_trunk_launch(const void* x, void* y, const float* params, int B, int 
     static const bool t512 = getenv("PPNET_TRUNK_512") != nullptr;
     if (!valu && N % 64 == 0) {
         const size_t lds_m = (size_t)N * 144 + 64 + (size_t)N * 12 + 16 * 3 * 4;      // Q, K, V rows + slack, |q| per (token, head), per-wave max |k|^2
-        static std::atomic<int> attr_m{0};
-        if (!attr_m.load()) {
-            hipError_t e = hipFuncSetAttribute((const void*)gennet_trunk_mfma_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024 + 64 + 192);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gennet_trunk_mfma_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024 + 64 + 192);
-            if (e != hipSuccess) return (int)e;
-            attr_m.store(1);
-        }
+        static DeviceOnce attr_512, attr_1024;
+        if (const int e = dynamic_lds_once(attr_512, (const void*)gennet_trunk_mfma_kernel<512>, 156 * 1024 + 64 + 192)) return e;
+        if (const int e = dynamic_lds_once(attr_1024, (const void*)gennet_trunk_mfma_kernel<1024>, 156 * 1024 + 64 + 192)) return e;
         // PPNET_TRUNK_EXACT_MAX=1: always take the exact row maximum (the two-pass softmax) instead of the norm bound — A/B and tests
         const float bound_max = getenv("PPNET_TRUNK_EXACT_MAX") ? -1.0f : 40.0f;
         if (t512) hipLaunchKernelGGL(gennet_trunk_mfma_kernel<512>, dim3(B), dim3(512), lds_m, stream, (const __bf16*)x, (__bf16*)y, params, N, n_blocks, bound_max);
@@ -526,12 +522,8 @@ int gennet_trunk_launch(const void* x, void* y, const float* params, int B, int 
         return (int)hipGetLastError();
     }
     const size_t lds = (size_t)N * 48 + (size_t)3 * (N / 2) * 8 * 4;
-    static std::atomic<int> attr{0};
-    if (!attr.load()) {
-        const hipError_t e = hipFuncSetAttribute((const void*)gennet_trunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr.store(1);
-    }
+    static DeviceOnce attr;
+    if (const int e = dynamic_lds_once(attr, (const void*)gennet_trunk_kernel, 96 * 1024)) return e;
     hipLaunchKernelGGL(gennet_trunk_kernel, dim3(B), dim3(512), lds, stream, (const __bf16*)x, (__bf16*)y, params, N, n_blocks);
     return (int)hipGetLastError();
 }

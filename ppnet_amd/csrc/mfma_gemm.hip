@@ -13,13 +13,15 @@ namespace ppn {
 
 // >= 256 bytes of zeros in device memory (the source of out-of-image taps / out-of-halo slots)
 const void* zero_line() {
-    static std::atomic<void*> z{nullptr};
-    void* p = z.load();
+    static DeviceBuffer z;                                                   // one line per device
+    const int dev = current_device();
+    if (dev < 0) return nullptr;
+    void* p = z.p[dev].load();
     if (!p) {
         void* q = nullptr;
         if (hipMalloc(&q, 256) != hipSuccess || hipMemset(q, 0, 256) != hipSuccess) return nullptr;
         void* expect = nullptr;
-        if (!z.compare_exchange_strong(expect, q)) { (void)hipFree(q); q = expect; }
+        if (!z.p[dev].compare_exchange_strong(expect, q)) { (void)hipFree(q); q = expect; }
         p = q;
     }
     return p;
@@ -28,13 +30,8 @@ const void* zero_line() {
 namespace {
 template <int AMODE, int EPI>
 int launch(const gemm::Params& p, int persistent, hipStream_t stream) {
-    static std::atomic<int> attr{0};
-    if (!attr.load()) {
-        const hipError_t e = hipFuncSetAttribute((const void*)gemm::gemm_bf16_kernel<AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 gemm::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr.store(1);
-    }
+    static DeviceOnce attr;
+    if (const int e = dynamic_lds_once(attr, (const void*)gemm::gemm_bf16_kernel<AMODE, EPI>, gemm::LDS_BYTES)) return e;
     const int tiles = ((p.M + gemm::BM - 1) / gemm::BM) * ((p.N + gemm::BN - 1) / gemm::BN);
     int grid = tiles;
     if (persistent > 0 && tiles > persistent && p.M % gemm::BM == 0 && p.N % gemm::BN == 0) grid = persistent;   // one block per CU

@@ -312,15 +312,9 @@ static int bwd_typed(const void* qkv, const float* rpb, const void* dout, void* 
     float4* stats = reinterpret_cast<float4*>(ws);
     float* partial = ws + (size_t)B * heads * H * W * 4;
     constexpr int LDS_Q = (2 * QH * QH * BHD + TR * TR * BK * BK + 176) * 4, LDS_K = (2 * KH * KH * BHD + KH * KH * 4 + 176) * 4;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)na2d_bwd_query_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_Q);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)na2d_bwd_query_kernel<__hip_bfloat16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_Q);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)na2d_bwd_key_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_K);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)na2d_bwd_key_kernel<__hip_bfloat16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_K);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static DeviceOnce attr_q, attr_k;
+    if (const int e = dynamic_lds_once(attr_q, (const void*)na2d_bwd_query_kernel<T>, LDS_Q)) return e;
+    if (const int e = dynamic_lds_once(attr_k, (const void*)na2d_bwd_key_kernel<T>, LDS_K)) return e;
     const dim3 grid((unsigned)nwg, heads);
     hipLaunchKernelGGL((na2d_bwd_query_kernel<T>), grid, dim3(NTHR), LDS_Q, stream, (const T*)qkv, rpb, (const T*)dout, (T*)dqkv, stats, partial, H, W,
                        heads, dil, scale, tiles_y, tiles_x);

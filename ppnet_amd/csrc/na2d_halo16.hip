@@ -439,23 +439,16 @@ int na2d_halo16_launch(const void* qkv, const void* pad_kv, const float* rpb, vo
     const int Ws = pad_kv ? Wr : W;                                          // stored token grid
     // a piece's offset from its tile's halo origin, and a query's from its tile's, are 32-bit (bytes)
     if (items >= (1LL << 30) || heads > 255 || (long long)(HROWS + 2) * dil * Ws * 3 * heads * MHD * 2 >= (1LL << 31)) return -1;
-    static std::atomic<int> state{0};                                        // 0 unknown, 1 ready, -1 unavailable
-    static std::atomic<int> n_cu{0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorUnknown;
-    if (!state.load()) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorUnknown;
-        n_cu.store(prop.multiProcessorCount & ~7);
-        const hipError_t e = hipFuncSetAttribute((const void*)na2d_halo16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-        state.store(e == hipSuccess && n_cu.load() >= 8 ? 1 : -1);
-    }
-    if (state.load() < 0) return -1;
+    static DeviceOnce attr;                                                  // per device, like the descriptor tables (DescKey.dev)
+    const int dev = current_device();
+    if (dev < 0) return (int)hipErrorInvalidDevice;
+    const int n_cu = device_cu_count() & ~7;
+    if (n_cu < 8 || dynamic_lds_once(attr, (const void*)na2d_halo16_kernel, LDS_TOTAL) != 0) return -1;
     const int* desc = descriptors(DescKey{dev, B, H, W, Hr, Wr, heads, dil, pad_kv ? 1 : 0}, tiles_y, tiles_x, total, stream);
     if (!desc) return -1;
     // whole XCD rows of workgroups, no more than the items of an XCD's run
     const long long per = (items + 7) / 8;
-    int grid = n_cu.load();
+    int grid = n_cu;
     if (per * 8 < grid) grid = (int)per * 8;
     hipLaunchKernelGGL(na2d_halo16_kernel, dim3(grid), dim3(NTHR), LDS_TOTAL, stream, (const __bf16*)qkv, (const __bf16*)pad_kv, (__bf16*)out, rpb, desc, Wr,
                        Ws, heads, dil, scale, (int)items, (const __bf16*)zero);

@@ -262,12 +262,8 @@ static int launch_rt(const void* qkv, const void* pad_kv, const float* rpb, void
     const long long total = (long long)tiles_y * tiles_x * B * dil * dil;
     if (total >= (1LL << 31) - 8) return -1;
     const size_t lds = (size_t)2 * BT_ROWS * BT_COLS * 4 + (size_t)TPW * 2 * (RT + 6) * (RT + 12) * KB;
-    static std::atomic<int> attr{0};
-    if (!attr.load()) {
-        const hipError_t e = hipFuncSetAttribute((const void*)na2d_mfma_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr.store(1);
-    }
+    static DeviceOnce attr;
+    if (const int e = dynamic_lds_once(attr, (const void*)na2d_mfma_kernel<RT>, (int)lds)) return e;
     const long long wgs = (total + TPW - 1) / TPW * heads;
     if (wgs >= (1LL << 31)) return -1;
     const dim3 grid((unsigned)wgs, 1, 1);

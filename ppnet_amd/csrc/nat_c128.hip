@@ -281,22 +281,16 @@ __global__ __launch_bounds__(NAT128_THREADS, 1) void nat128_proj_add_kernel(__hi
 }
 
 static int blocks_for(long long groups) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
+    int cus = device_cu_count();
+    if (!cus) cus = 256;
     const long long need = (groups + NAT128_WAVES - 1) / NAT128_WAVES;
     return (int)(need < cus ? need : cus);
 }
 
 int nat128_ln_qkv_launch(const void* s, const float* off, const void* lnw, const void* lnb, const void* w, const void* bias, void* qkv, long long tokens,
                          float eps, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)nat128_ln_qkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, QKV_LDS) != hipSuccess) return (int)hipGetLastError();
-        attr = true;
-    }
+    static DeviceOnce attr;
+    if (const int e = dynamic_lds_once(attr, (const void*)nat128_ln_qkv_kernel, QKV_LDS)) return e;
     const long long groups = tokens / 16;
     hipLaunchKernelGGL(nat128_ln_qkv_kernel, dim3(blocks_for(groups)), dim3(NAT128_THREADS), QKV_LDS, stream, (const __hip_bfloat16*)s, off,
                        (const __hip_bfloat16*)lnw, (const __hip_bfloat16*)lnb, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, (__hip_bfloat16*)qkv,
@@ -305,11 +299,8 @@ int nat128_ln_qkv_launch(const void* s, const float* off, const void* lnw, const
 }
 
 int nat128_proj_add_launch(void* s, const void* a, const void* w, long long tokens, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)nat128_proj_add_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PROJ_LDS) != hipSuccess) return (int)hipGetLastError();
-        attr = true;
-    }
+    static DeviceOnce attr;
+    if (const int e = dynamic_lds_once(attr, (const void*)nat128_proj_add_kernel, PROJ_LDS)) return e;
     const long long groups = tokens / 16;
     // the kernel is HBM-bound and small (32 KB of LDS): several workgroups per CU keep enough loads in flight
     int blocks = blocks_for(groups);
@@ -322,11 +313,8 @@ int nat128_proj_add_launch(void* s, const void* a, const void* w, long long toke
 
 int nat128_ln_mlp_launch(void* s, const float* off, const void* lnw, const void* lnb, const void* w1, const void* b1, const void* w2, const float* add,
                          long long tokens, float eps, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)nat128_ln_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS) != hipSuccess) return (int)hipGetLastError();
-        attr = true;
-    }
+    static DeviceOnce attr;
+    if (const int e = dynamic_lds_once(attr, (const void*)nat128_ln_mlp_kernel, MLP_LDS)) return e;
     const long long groups = tokens / 16;
     hipLaunchKernelGGL(nat128_ln_mlp_kernel, dim3(blocks_for(groups)), dim3(NAT128_THREADS), MLP_LDS, stream, (__hip_bfloat16*)s, off,
                        (const __hip_bfloat16*)lnw, (const __hip_bfloat16*)lnb, (const __hip_bfloat16*)w1, (const __hip_bfloat16*)b1, (const __hip_bfloat16*)w2,

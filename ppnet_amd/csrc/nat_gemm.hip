@@ -643,12 +643,8 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const __bf16* __restrict
 
 template <bool LN, bool GELU, bool ACC>
 int launch(const Params& p, int n_cu, hipStream_t stream) {
-    static std::atomic<int> attr{0};
-    if (!attr.load()) {
-        const hipError_t e = hipFuncSetAttribute((const void*)nat_gemm_kernel<LN, GELU, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(ACC));
-        if (e != hipSuccess) return (int)e;
-        attr.store(1);
-    }
+    static DeviceOnce attr;
+    if (const int e = dynamic_lds_once(attr, (const void*)nat_gemm_kernel<LN, GELU, ACC>, lds_bytes(ACC))) return e;
     const int tiles = (p.M / BM) * (p.N / BN);
     int grid = tiles < n_cu ? tiles : n_cu;
     if (grid > 8) grid &= ~7;                                        // the XCD-aware tile order wants a multiple of 8
@@ -659,9 +655,12 @@ int launch(const Params& p, int n_cu, hipStream_t stream) {
 }  // namespace ngemm
 
 namespace {
-// the 256 x 256 bf16 identity the accumulating mode multiplies the old C by (128 KB of device memory, built once per process)
+// the 256 x 256 bf16 identity the accumulating mode multiplies the old C by (128 KB of device memory, built once per device)
 const void* identity_256() {
-    static std::atomic<void*> z{nullptr};
+    static DeviceBuffer zb;
+    const int dev = current_device();
+    if (dev < 0) return nullptr;
+    std::atomic<void*>& z = zb.p[dev];
     void* p = z.load();
     if (!p) {
         void* q = nullptr;
@@ -688,15 +687,8 @@ int nat_gemm_launch(const void* a, const void* w, const float* bias, const float
         p.ident = (const __bf16*)identity_256();
         if (!p.ident) return (int)hipErrorOutOfMemory;
     }
-    static std::atomic<int> cus{0};
-    int n_cu = cus.load();
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
-        n_cu = prop.multiProcessorCount;
-        cus.store(n_cu);
-    }
+    const int n_cu = device_cu_count();
+    if (!n_cu) return -2;
     switch (mode) {
         case 0: return ngemm::launch<true, false, false>(p, n_cu, stream);
         case 1: return ngemm::launch<true, true, false>(p, n_cu, stream);

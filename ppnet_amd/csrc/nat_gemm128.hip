@@ -205,12 +205,8 @@ __global__ __launch_bounds__(NTHR, SLOTS == 2 ? 4 : 3) void nat_gemm128_kernel(c
 
 template <int MODE, int SLOTS>
 static int launch_s(const Params& p, hipStream_t stream) {
-    static std::atomic<int> attr{0};
-    if (!attr.load()) {
-        const hipError_t e = hipFuncSetAttribute((const void*)nat_gemm128_kernel<MODE, SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(SLOTS));
-        if (e != hipSuccess) return (int)e;
-        attr.store(1);
-    }
+    static DeviceOnce attr;
+    if (const int e = dynamic_lds_once(attr, (const void*)nat_gemm128_kernel<MODE, SLOTS>, lds_bytes(SLOTS))) return e;
     const int tiles = (p.M / TM) * (p.N / TN);
     hipLaunchKernelGGL((nat_gemm128_kernel<MODE, SLOTS>), dim3(tiles), dim3(NTHR), lds_bytes(SLOTS), stream, p);
     return (int)hipGetLastError();

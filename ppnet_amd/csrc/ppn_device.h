@@ -195,6 +195,28 @@ __device__ __forceinline__ void sincos_small(double x, double& sn, double& cs) {
     cs = q == 0 ? c : q == 1 ? -s : q == 2 ? -c : s;
 }
 
+// Corridor resample = torchvision 0.12's TENSOR path (functional.rotate / functional.affine -> _gen_affine_grid ->
+// grid_sample(nearest, zeros, align_corners=False); Path.py:160-161,175, MapGenerate.py:103-106), in the float32 operations of
+// the torch primitives it calls — stated and pinned in oracle/edage_np.py ("rasters": affine_source_index; the CPU test
+// test_resample_rule_is_torchvisions_tensor_path_* compares that statement with torch's own linspace / bmm / grid_sample).
+// One axis of the map: (a, b, c) = a row of the float32 inverse matrix divided by half the image size, hs = size / 2;
+// source index of the output pixel whose centre is (x, y) = (j + 0.5 - w/2, i + 0.5 - h/2):
+//   g = fl(fma(y, b, fl(x a)) + c);  u = fl(fl((g + 1) hs) - 0.5);  index = nearbyint(u).
+struct TvAxis { float a, b, c, hs; };
+constexpr double PPN_DEG2RAD = 3.141592653589793 / 180.0;              // math.radians: x * (pi / 180)
+__device__ __forceinline__ TvAxis tv_axis(double ma, double mb, double mc, int size) {
+    const float den = 0.5f * (float)size;
+    TvAxis t;
+    t.a = __fdiv_rn((float)ma, den); t.b = __fdiv_rn((float)mb, den); t.c = __fdiv_rn((float)mc, den);
+    t.hs = (float)size * 0.5f;
+    return t;
+}
+__device__ __forceinline__ int tv_src(const TvAxis& t, float x, float y) {
+    const float g = __fadd_rn(__fmaf_rn(y, t.b, __fmul_rn(x, t.a)), t.c);
+    const float u = __fsub_rn(__fmul_rn(__fadd_rn(g, 1.0f), t.hs), 0.5f);
+    return (int)rintf(u);
+}
+
 // Geometry of the reference's obstacle raster (Path.plot_obstacles, Path.py:36-49): see oracle/edage_np.py raster_geometry for
 // the derivation.  Output pixel (i, j) shows the data point X = (j + 0.5) * ax + bx, Y = (i + 0.5) * ay + by and a circle of radius r
 // inks the ellipse with semi-axes r + sx, r + sy around its centre; carried into the pixel-centre frame that is the axis-aligned

@@ -11,6 +11,39 @@
 
 namespace ppn {
 
+// ---- per-device launcher state.  Function attributes, device-resident constants and CU counts belong to the device that is
+// current at the call; a process that drives several GPUs gets one slot per device ordinal (nothing here is shared between
+// devices, and nothing is keyed by "first caller").
+constexpr int PPN_MAX_DEVICES = 64;
+inline int current_device() {
+    int d = 0;
+    return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < PPN_MAX_DEVICES) ? d : -1;
+}
+struct DeviceOnce { std::atomic<int> done[PPN_MAX_DEVICES]; };       // static storage: zero-initialised
+struct DeviceBuffer { std::atomic<void*> p[PPN_MAX_DEVICES]; };
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): 0 or the HIP error
+inline int dynamic_lds_once(DeviceOnce& o, const void* fn, int bytes) {
+    const int d = current_device();
+    if (d < 0) return (int)hipErrorInvalidDevice;
+    if (o.done[d].load(std::memory_order_acquire)) return 0;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    o.done[d].store(1, std::memory_order_release);
+    return 0;
+}
+// compute units of the current device (cached per device; 0 when the query fails)
+inline int device_cu_count() {
+    static std::atomic<int> cus[PPN_MAX_DEVICES];
+    const int d = current_device();
+    if (d < 0) return 0;
+    int v = cus[d].load(std::memory_order_relaxed);
+    if (!v) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) return 0;
+        cus[d].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 struct PathsParams {
     ppn_paths_t out;
     int n_paths;

@@ -215,11 +215,8 @@ __global__ __launch_bounds__(TOKF_THREADS, 1) void tokenizer_fused_kernel(const 
 
 int tokenizer_fused_launch(const uint8_t* grid, const void* lut, const void* w2p, const float* vec, void* out, int B, int H, int W, float eps,
                            hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)tokenizer_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TOKF_LDS) != hipSuccess) return (int)hipGetLastError();
-        attr = true;
-    }
+    static DeviceOnce attr;
+    if (const int e = dynamic_lds_once(attr, (const void*)tokenizer_fused_kernel, TOKF_LDS)) return e;
     const long long groups = (long long)B * (H / 4) * (W / 4 / 16);
     if (groups >= (1LL << 31)) return (int)hipErrorInvalidValue;
     int dev = 0, cus = 256;

@@ -21,10 +21,21 @@ class WeightCache:
     """A value derived from module parameters (a packed / folded / converted copy for a kernel), rebuilt whenever a source changes:
     the key holds each source tensor's device, `_version` (bumped by every in-place update: optimizer.step, load_state_dict's
     copy_) and `data_ptr` (a new storage after .to(dtype) / .to(device) or re-assignment).  An eval -> step -> eval flow therefore
-    never runs a kernel on stale weights."""
-    __slots__ = ("key", "value")
+    never runs a kernel on stale weights.  NOT covered: writes through `param.data` (EMA / weight-tying code, legacy checkpoint
+    loaders) — `.data` is a separate tensor object with its own version counter, so neither the version nor the pointer of the
+    parameter moves.  After such a write call `invalidate_caches()` (or `WeightCache.clear()` on the one cache)."""
+    __slots__ = ("key", "value", "__weakref__")
+    _all = None            # weak set of every live cache (invalidate_caches)
 
     def __init__(self):
+        self.key = self.value = None
+        if WeightCache._all is None:
+            import weakref
+            WeightCache._all = weakref.WeakSet()
+        WeightCache._all.add(self)
+
+    def clear(self):
+        """Forget the derived value: the next get() rebuilds it."""
         self.key = self.value = None
 
     def get(self, sources, build, *extra):
@@ -32,6 +43,14 @@ class WeightCache:
         if key != self.key:
             self.value, self.key = build(), key
         return self.value
+
+
+def invalidate_caches():
+    """Drop every packed / folded / converted weight copy in the process (all WeightCache instances).  Needed only after
+    in-place writes through `param.data`, which no key can see; ordinary updates (optimizer.step, load_state_dict, .to()) are
+    tracked by themselves."""
+    for c in list(WeightCache._all or ()):
+        c.clear()
 
 
 _PADDED = {}

@@ -691,13 +691,20 @@ class SegNet(nn.Module):
     def _narrow_levels(self, inference=False):
         """The backbone evaluates only the levels a head reads (their output norm + the NHWC -> NCHW view): SETR-UP reads the last
         one; the auxiliary head's level joins while it can be trained (not after prepare_inference)."""
-        n = self.backbone.num_levels
-        idx = lambda i: i % n
-        ii = self.decode_head.in_index
-        need = {idx(i) for i in (ii if isinstance(ii, (tuple, list)) else (ii,))}
+        outs = tuple(self.backbone.out_indices)        # a head's in_index selects a SLOT of the backbone's output list
+
+        def levels(ii):
+            ii = ii if isinstance(ii, (tuple, list)) else (ii,)
+            for i in ii:
+                if not -len(outs) <= i < len(outs):
+                    raise ValueError(f"head in_index {i} outside the backbone's {len(outs)} outputs (out_indices {outs})")
+            return {outs[i] for i in ii}
+
+        need = levels(self.decode_head.in_index)
         if not inference:
-            need |= {idx(h.in_index) for h in self._aux_heads()}
-        self.backbone.compute_indices = tuple(sorted(need & set(self.backbone.out_indices)))
+            for h in self._aux_heads():
+                need |= levels(h.in_index)
+        self.backbone.compute_indices = tuple(sorted(need))
 
     @classmethod
     def from_config(cls, cfg):
@@ -827,11 +834,19 @@ class SegNet(nn.Module):
                                                        for i, h in enumerate(self._aux_heads())]
         for name, head, w in heads:
             logit = F.interpolate(head(feats).float(), gt.shape[-2:], mode="bilinear", align_corners=head.align_corners)
-            losses[f"{name}.loss_ce"] = w * F.cross_entropy(logit, gt, ignore_index=255)
-            with torch.no_grad():
-                valid = gt != 255
-                losses[f"{name}.acc_seg"] = 100.0 * ((logit.argmax(1) == gt) & valid).sum() / valid.sum().clamp(min=1)
+            losses[f"{name}.loss_ce"], losses[f"{name}.acc_seg"] = decode_losses(logit, gt, w)
         return losses
+
+
+def decode_losses(logit, gt, loss_weight=1.0, ignore_index=255):
+    """(loss_ce, acc_seg) of BaseDecodeHead.losses (decode_head.py:231-265) for resized logits [B,C,H,W] and labels [B,H,W].
+    mmseg's CrossEntropyLoss is F.cross_entropy(reduction='none', ignore_index) followed by a mean over ALL pixels — ignored
+    ones contribute 0 to the sum and still count in the divisor (losses/cross_entropy_loss.py:20-31, losses/utils.py:66-68);
+    accuracy() is called without an ignore index and divides by target.numel() (decode_head.py:264, losses/accuracy.py:39-49)."""
+    loss = loss_weight * F.cross_entropy(logit, gt, ignore_index=ignore_index, reduction="none").mean()
+    with torch.no_grad():
+        acc = (logit.argmax(1) == gt).float().sum() * (100.0 / gt.numel())
+    return loss, acc
 
 
 def _meta(img_meta):

@@ -6,6 +6,7 @@ bit for bit; 1e-11 absolute (pixels / world units) absorbs torch.mean-vs-numpy s
 in the hull centre (Path.py:167).  Integer results (canvas pixel set, hull vertices, isle slice
 bounds, accept masks, RNG stream position) must be exact.
 """
+import math
 import os
 
 import numpy as np
@@ -243,6 +244,88 @@ def test_rotate_translate_rules():
     t = E.translate_nearest(img, 1, 2, 9, 9)                # tx -> columns, ty -> rows
     assert t.sum() == 1 and t[4, 7]
     assert E.translate_nearest(img, 5, 0, 9, 9).sum() == 0  # shifted out: zero fill
+
+
+# The corridor resample pinned to the primitives torchvision calls.  torchvision is absent here, but its 0.12 tensor path
+# (functional.rotate / functional.affine -> functional_tensor._gen_affine_grid -> grid_sample) is a published composition of
+# torch ops that ARE importable; the helpers below state that composition with torch itself doing the arithmetic
+# (linspace, the float32 division of theta, bmm, grid_sample(nearest, zeros, align_corners=False)).
+def _tv_grid_sample(img, matrix):
+    import torch
+    import torch.nn.functional as F
+    x = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))[None, None]
+    h, w = x.shape[-2:]
+    theta = torch.tensor(matrix, dtype=torch.float32).reshape(1, 2, 3)
+    base = torch.empty(1, h, w, 3, dtype=torch.float32)
+    base[..., 0].copy_(torch.linspace(-w * 0.5 + 0.5, w * 0.5 + 0.5 - 1, steps=w))
+    base[..., 1].copy_(torch.linspace(-h * 0.5 + 0.5, h * 0.5 + 0.5 - 1, steps=h).unsqueeze_(-1))
+    base[..., 2].fill_(1)
+    rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h], dtype=torch.float32)
+    grid = base.view(1, h * w, 3).bmm(rescaled).view(1, h, w, 2)
+    return F.grid_sample(x, grid, mode="nearest", padding_mode="zeros", align_corners=False)[0, 0].numpy()
+
+
+def _tv_rotate(img, angle):            # functional.rotate: matrix for -angle about the centre
+    return _tv_grid_sample(img, E.inverse_affine_matrix(-angle, [0.0, 0.0]))
+
+
+def _tv_translate(img, tx, ty):        # functional.affine(angle=0, translate=[tx, ty], scale=1, shear=0)
+    return _tv_grid_sample(img, E.inverse_affine_matrix(0.0, [tx, ty]))
+
+
+def test_inverse_affine_matrix_closed_forms():
+    m = E.inverse_affine_matrix(30.0, [0.0, 0.0])
+    c, s = math.cos(math.radians(30.0)), math.sin(math.radians(30.0))
+    _close(m, [c, s, 0.0, -s, c, 0.0], 0.0)
+    _close(E.inverse_affine_matrix(0.0, [3.0, -2.5]), [1.0, 0.0, -3.0, 0.0, 1.0, 2.5], 0.0)
+
+
+def test_resample_rule_is_torchvisions_tensor_path_on_goldens(golden_dir):
+    """Path.py:160-161,175 on the 11 golden corridor canvases at their recorded Rotation / Translation."""
+    g = _load(golden_dir, "g2_paths.npz")
+    for case in [str(c) for c in g["cases"]]:
+        R = int(case.split("_")[1][1:])
+        nz = g[case + "/canvas_nz"]
+        canvas = np.zeros([2 * R, 2 * R], bool)
+        canvas[nz[:, 0], nz[:, 1]] = True
+        rot = float(np.asarray(g[case + "/rotation"]).reshape(-1)[0])
+        tx, ty = (float(v) for v in g[case + "/translation"])          # Path.Translation = [t_col, t_row]
+        want_rot = _tv_rotate(canvas, -rot) > 0.5
+        got_rot = E.rotate_nearest(canvas, -rot)
+        assert np.array_equal(got_rot, want_rot), case
+        want = _tv_translate(want_rot, tx, ty)[:R, :R] > 0.5
+        assert np.array_equal(E.translate_nearest(got_rot, tx, ty, R, R), want), case
+        assert want.sum() > 0
+
+
+@pytest.mark.parametrize("R", [64, 224, 256])
+def test_resample_rule_is_torchvisions_tensor_path_on_placements(R):
+    """MapGenerate.py:102-106 on 100 random placements; dense random images, so every pixel of the map is a witness
+    (the float64 form of the same map differs from the primitive on ~5 pixels per million of such images)."""
+    rng = np.random.default_rng(R)
+    for _ in range(100 if R == 64 else 34):
+        img = rng.random([R, R]) < 0.5
+        angle = rng.uniform(-180.0, 180.0)                                  # MapGenerate.py:63
+        t = [int(rng.random() ** 2 * R - R / 2), int(rng.random() ** 2 * R - R / 2)]
+        want = _tv_translate(_tv_rotate(img, -angle), t[0], t[1]) > 0.5
+        got = E.translate_nearest(E.rotate_nearest(img, -angle), float(t[0]), float(t[1]), R, R)
+        assert np.array_equal(got, want)
+
+
+def test_affine_source_index_equals_grid_sample():
+    """The source index of every output pixel (an index image makes grid_sample return it), for matrices with rotation
+    AND fractional translation, non-square and non-power-of-two sizes: pins the operation order of the float32 grid
+    (k-ordered FMA chain of the sgemm) and of the unnormalisation."""
+    rng = np.random.default_rng(7)
+    for (h, w) in ((128, 128), (224, 224), (100, 300), (330, 444), (512, 512)):
+        for _ in range(4):
+            m = E.inverse_affine_matrix(rng.uniform(-180, 180), [rng.uniform(-w / 2, w / 2), rng.uniform(-h / 2, h / 2)])
+            idx = np.arange(1, h * w + 1, dtype=np.float32).reshape(h, w)
+            want = _tv_grid_sample(idx, m).astype(np.int64) - 1          # -1: zero fill
+            ii, jj = E.affine_source_index(h, w, m)
+            ok = (ii >= 0) & (ii < h) & (jj >= 0) & (jj < w)
+            got = np.where(ok, ii * w + jj, -1)
+            assert np.array_equal(got, want)
 
 
 def test_disc_raster_rule():

@@ -129,3 +129,79 @@ def test_assert_trainable_names_prepared_modules():
         train.assert_trainable(AEViT(1, 1, img_resolution=64, dim=24).eval().prepare_inference())
     with pytest.raises(RuntimeError):
         train.assert_trainable(SegNet(**tiny).eval().prepare_inference())
+
+
+def test_decode_losses_follow_mmseg_with_ignored_pixels():
+    """BaseDecodeHead.losses with ignore (255) labels present: the cross entropy is averaged over ALL pixels (ignored ones add 0
+    to the sum), accuracy divides by target.numel() and has no ignore index (decode_head.py:231-265,
+    losses/cross_entropy_loss.py:20-31, losses/utils.py:66-68, losses/accuracy.py:39-49) — restated here op by op."""
+    from ppnet_amd.segnet import decode_losses
+    g = torch.Generator().manual_seed(3)
+    logit = torch.randn(2, 2, 9, 11, generator=g, dtype=torch.float64)
+    gt = torch.randint(0, 2, (2, 9, 11), generator=g)
+    gt[0, :3] = 255
+    gt[1, 4:, 5:] = 255
+    # the reference's formulae, element by element
+    logp = torch.log_softmax(logit, dim=1)
+    per_px = torch.zeros(2, 9, 11, dtype=torch.float64)
+    correct = 0
+    for b in range(2):
+        for i in range(9):
+            for j in range(11):
+                t = int(gt[b, i, j])
+                if t != 255:
+                    per_px[b, i, j] = -logp[b, t, i, j]
+                correct += int(int(logit[b, :, i, j].argmax()) == t)
+    want_loss = 0.4 * per_px.sum() / per_px.numel()
+    want_acc = 100.0 * correct / gt.numel()
+    loss, acc = decode_losses(logit, gt, 0.4)
+    assert float(loss) == pytest.approx(float(want_loss), rel=1e-12)
+    assert float(acc) == pytest.approx(want_acc, rel=1e-6)
+    # without ignored pixels both reduce to the plain mean / plain accuracy
+    gt2 = gt.clamp(max=1)
+    loss2, _ = decode_losses(logit, gt2)
+    assert float(loss2) == pytest.approx(float(torch.nn.functional.cross_entropy(logit, gt2)), rel=1e-12)
+
+
+def test_weight_cache_invalidation():
+    """WeightCache follows optimizer-style in-place updates by itself; a write through `.data` needs invalidate_caches()."""
+    from ppnet_amd import fused
+    p = torch.nn.Parameter(torch.ones(4))
+    cache, builds = fused.WeightCache(), []
+
+    def build():
+        builds.append(1)
+        return p.detach() * 2
+
+    assert torch.equal(cache.get((p,), build), torch.full((4,), 2.0)) and len(builds) == 1
+    cache.get((p,), build)
+    assert len(builds) == 1                                         # unchanged sources: no rebuild
+    with torch.no_grad():
+        p.mul_(3)
+    assert torch.equal(cache.get((p,), build), torch.full((4,), 6.0)) and len(builds) == 2
+    p.data.mul_(2)                                                  # invisible to the key
+    stale = cache.get((p,), build)
+    if len(builds) == 2:
+        assert torch.equal(stale, torch.full((4,), 6.0))
+        fused.invalidate_caches()
+    assert torch.equal(cache.get((p,), build), torch.full((4,), 12.0))
+    cache.clear()
+    n = len(builds)
+    cache.get((p,), build)
+    assert len(builds) == n + 1
+
+
+def test_head_in_index_selects_backbone_output_slot():
+    """A head's in_index is a position in the backbone's OUTPUT LIST (nat.py:326-332 returns one entry per out_index), so
+    with out_indices=(1, 2, 3) and in_index=0 the level to compute is 1."""
+    from ppnet_amd.segnet import SegNet
+    cfg = dict(backbone=dict(type="NAT", embed_dim=32, mlp_ratio=2.0, depths=[1, 1, 1, 1], num_heads=[1, 2, 4, 8], kernel_size=7,
+                             out_indices=(1, 2, 3)),
+               decode_head=dict(type="SETRUPHead", in_channels=64, channels=16, in_index=0, num_classes=2, num_convs=1, up_scale=2,
+                                kernel_size=3, norm_cfg=dict(type="BN")),
+               test_cfg=dict(mode="whole"))
+    net = SegNet.from_config(cfg)
+    assert net.backbone.compute_indices == (1,)
+    cfg["decode_head"]["in_index"] = 5
+    with pytest.raises(ValueError):
+        SegNet.from_config(cfg)
