@@ -198,18 +198,75 @@ def ppnet_cpu_baseline(torch, grids_u8, heat_ridge, init, end, obs, n_obs, R_):
             "host_cores": os.cpu_count()}
 
 
+PARITY_PROBLEMS = 16            # problems of the batch on which the bf16 leg is compared with the float32 leg
 MFMA_PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: float32-input MFMA = the float32 vector rate
 
 
-def ppnet_fp32_leg(torch, dev, grids_u8, batch, steps=3):
+def bench_ppnet(torch, dev, resolution, weights_dtype="bf16"):
+    """The PPNet object every leg times: the reference architectures (DiNAT-B + SETR-UP, AE-ViT dim 24) with seeded random
+    weights — no trained weights ship with the reference — whose NEUTRAL parameters (LayerScale 1e-5, zero biases, unit norms,
+    BatchNorm statistics) are given non-trivial seeded values too (segnet.randomize_neutral_parameters), so the residual
+    branches carry signal as in a trained checkpoint and the bf16-vs-float32 comparison (`ppnet.parity`) means something.
+    The same seeds in every leg: the bf16 and the float32 objects hold the same weights."""
+    from ppnet_amd.gennet import AEViT
+    from ppnet_amd.ppnet import PPNet
+    from ppnet_amd.segnet import SegNet, randomize_neutral_parameters
+    torch.manual_seed(0)
+    seg = randomize_neutral_parameters(SegNet().eval(), seed=1)
+    gen = randomize_neutral_parameters(AEViT(1, 1, resolution, 24).eval(), seed=2)
+    kw = {} if weights_dtype == "bf16" else {"weights_dtype": None}
+    return PPNet(resolution=resolution, segnet=seg, gennet=gen, **kw).to(dev).eval()
+
+
+PARITY_TOLERANCE = {      # what tests/test_ppnet_config3.py asserts for the same objects (bf16 prepared vs float32)
+    "rms_logit_rel_max": 0.08, "label_agreement_min": 0.97, "labels_agree_where_margin_exceeds_rms_x": 6.0,
+    "heat_u8_max_code_diff_max": 16, "heat_u8_rms_code_diff_max": round(0.03 * 255, 2),
+}
+
+
+def ppnet_parity(torch, model16, model32, grids):
+    """The bf16 leg's outputs against the float32 (reference-precision) leg's on the same grids, outside any clock: SegNet
+    logits (rms error relative to the logit rms), labels (agreement overall and wherever the float32 margin exceeds 6 x the rms
+    error), and GenNet's 8-bit heat map on the SAME mask (the float32 labels), so each network's own precision is isolated;
+    `heat_u8_end_to_end` chains the bf16 labels into the bf16 GenNet.  The tolerance is the one the GPU tests assert."""
+    from ppnet_amd import fused
+    from ppnet_amd.segnet import IMG_MEAN, IMG_STD
+    with torch.no_grad():
+        l32 = model32.segnet.encode_decode(fused.grid_to_image(grids, IMG_MEAN, IMG_STD, torch.float32)).float()
+        l16 = model16.segnet.encode_decode(fused.grid_to_image(grids, IMG_MEAN, IMG_STD, torch.bfloat16)).float()
+        lab32, lab16 = model32.segment_u8(grids).long(), model16.segment_u8(grids).long()
+        h32, h16 = model32.heatmap(lab32).int(), model16.heatmap(lab32).int()
+        h16e = model16.heatmap(lab16).int()
+    rms = float((l16 - l32).pow(2).mean().sqrt())
+    rel = rms / max(float(l32.pow(2).mean().sqrt()), 1e-30)
+    agree = lab16 == lab32
+    margin = (l32[:, 1] - l32[:, 0]).abs()
+    if tuple(margin.shape[-2:]) != tuple(agree.shape[-2:]):           # logits come at the head's resolution: compare labels at the input's
+        margin = torch.nn.functional.interpolate(margin[:, None], agree.shape[-2:], mode="bilinear", align_corners=False)[:, 0]
+    sure = margin > PARITY_TOLERANCE["labels_agree_where_margin_exceeds_rms_x"] * rms
+    d, de = (h16 - h32).abs().float(), (h16e - h32).abs().float()
+    out = {"problems": int(grids.shape[0]), "rms_logit_rel": round(rel, 5), "logit_rms_fp32": round(float(l32.pow(2).mean().sqrt()), 4),
+           "label_agreement_vs_fp32": round(float(agree.float().mean()), 5),
+           "labels_agree_where_margin_exceeds_6rms": bool(agree[sure].all()), "pixels_with_such_margin": round(float(sure.float().mean()), 4),
+           "free_fraction_fp32": round(float(lab32.float().mean()), 4),
+           "heat_u8_max_code_diff": int(d.max()), "heat_u8_rms_code_diff": round(float(d.pow(2).mean().sqrt()), 3),
+           "heat_u8_end_to_end": {"max_code_diff": int(de.max()), "rms_code_diff": round(float(de.pow(2).mean().sqrt()), 3)},
+           "tolerance_stated": PARITY_TOLERANCE}
+    out["within_tolerance"] = bool(rel < PARITY_TOLERANCE["rms_logit_rel_max"]
+                                   and out["label_agreement_vs_fp32"] > PARITY_TOLERANCE["label_agreement_min"]
+                                   and out["labels_agree_where_margin_exceeds_6rms"]
+                                   and out["heat_u8_max_code_diff"] <= PARITY_TOLERANCE["heat_u8_max_code_diff_max"]
+                                   and out["heat_u8_rms_code_diff"] <= PARITY_TOLERANCE["heat_u8_rms_code_diff_max"])
+    return out
+
+
+def ppnet_fp32_leg(torch, dev, grids_u8, batch, steps=3, parity_with=None):
     """The same two networks at the REFERENCE's precision (GenNet/predict.py:46-52,88 and SegNet/test.py:181-191 run float32):
     PPNet(weights_dtype=None) on the same batch — a reported leg, not a tuning target.  It makes the bfloat16 figure a stated
     speed-up over a same-precision run.  On this path the convolutions and projections are ROCm library calls (MIOpen,
     hipBLASLt / rocBLAS through PyTorch) in float32; the neighbourhood attention (ppn_na2d_fwd, float32 form), the fused residual /
     LayerNorm / up-sampling / label kernels are the build's own.  The kernel names of one batch are listed from the profiler."""
-    from ppnet_amd.ppnet import PPNet
-    torch.manual_seed(0)
-    model = PPNet(resolution=R, weights_dtype=None).to(dev).eval()
+    model = bench_ppnet(torch, dev, R, weights_dtype="f32")
     # PPNet(weights_dtype=None) asks MIOpen for its exhaustive algorithm search (140 s on a fresh box for a 6 % faster batch:
     # 147 -> ~138 ms): a reported leg of a bench that has to finish in minutes takes the heuristic pick
     torch.backends.cudnn.benchmark = bool(os.environ.get("BENCH_FP32_MIOPEN_SEARCH"))
@@ -244,9 +301,15 @@ def ppnet_fp32_leg(torch, dev, grids_u8, batch, steps=3):
         lib_ms, own_ms = sum(lib.values()) / 1e3, sum(own.values()) / 1e3
     except Exception as e:                                               # the list is an extra: never fail the bench line over it
         lib_kernels, lib_ms, own_ms = [f"profiler unavailable: {e!r}"[:160]], None, None
+    parity = None
+    if parity_with is not None and parity_with.get("model") is not None:
+        try:
+            parity = ppnet_parity(torch, parity_with["model"], model, grids_u8[:PARITY_PROBLEMS])
+        except Exception as e:
+            parity = {"error": repr(e)[:300]}
     del model
     torch.cuda.empty_cache()
-    return {"metric": "ppnet_plans_per_sec_fp32", "value": round(batch / (ms * 1e-3), 1), "unit": "plans/s", "ms_per_batch": round(ms, 2),
+    return {"metric": "ppnet_plans_per_sec_fp32", "parity": parity, "value": round(batch / (ms * 1e-3), 1), "unit": "plans/s", "ms_per_batch": round(ms, 2),
             "steps": steps, "dtype": "f32", "first_batch_s": round(first_s, 1),
             "what": "SegNet + GenNet forward only (the planner tail is identical to the bf16 leg's), PPNet(weights_dtype=None)",
             "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
@@ -303,7 +366,158 @@ def segnet_nat_uper_leg(torch, dev, grids_u8, batch, steps=5):
     return out
 
 
-def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg):
+R5, PATHS5, PLACEMENTS5 = 512, 16, 16      # BASELINE config 5 per GPU: 512 x 512 maps, 16 target paths x 16 placements = 256 problems per step
+
+
+def end_to_end_cpu_baseline(torch, model_cfg_R, grids_u8, ridge, init, end, obs, n_obs):
+    """Config 5's CPU leg on the host cores, a bounded sample (~30 s): the NumPy port of the generator on 1 target path + 4
+    placements at R = 512, the float32 PyTorch-CPU composition of the reference's SegNet (oracle/segnet_ref.py) on 1 problem,
+    the reference-architecture AE-ViT (PyTorch-CPU float32, R = 512) on 2, the NumPy planner tail on 4 ridge heat maps."""
+    import numpy as np
+    from oracle import edage_np as E
+    from oracle import plan_np as PN
+    from oracle import segnet_ref as SR
+    from ppnet_amd import edage
+    from ppnet_amd.gennet import AEViT
+    from ppnet_amd.segnet import DINAT_BASE, SegNet, normalize_images
+    Rr = model_cfg_R
+    src = E.PhiloxSource(SEED)
+    t0 = time.perf_counter()
+    precs = E.generate_paths(src, 1, Rr, MAP_SIZE, CLEARANCE, first_path_id=7)
+    t1 = time.perf_counter()
+    maps = E.generate_maps(src, precs, Rr, MAP_SIZE, OBST_SIZE, K, CLEARANCE, 4, first_map_id=7 * PLACEMENTS5)
+    t2 = time.perf_counter()
+    t_gen = (t1 - t0) / PLACEMENTS5 + (t2 - t1) / len(maps)              # stage A amortised over the placements of a path
+    torch.manual_seed(0)
+    seg = SegNet().eval()
+    img = normalize_images(edage.grid_to_rgb(grids_u8[:1]) * 255.0).cpu()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        SR.segnet_logits_fp64(seg, DINAT_BASE, img, dtype=torch.float32)
+        t_seg = time.perf_counter() - t0
+        gen = AEViT(1, 1, Rr, 24).eval()
+        x = torch.rand(2, 1, Rr, Rr).round()
+        gen(x)
+        t0 = time.perf_counter()
+        gen(x)
+        t_gn = (time.perf_counter() - t0) / 2
+    hh, ih, eh = ridge[:4].cpu().numpy(), init[:4].cpu().numpy(), end[:4].cpu().numpy()
+    oh, nh = obs[:4].cpu().numpy().astype(np.float32), n_obs[:4].cpu().numpy()
+    t0 = time.perf_counter()
+    for i in range(4):
+        ok, path = PN.extract_path(hh[i], ih[i], eh[i], down_sample_rate=2)
+        if ok:
+            p32 = path.astype(np.float32)
+            for j in range(len(path) - 1):
+                if PN.collision_check_circle_edge(p32[j], p32[j + 1], oh[i, :nh[i]], Rr / 50, bound=Rr):
+                    break
+    t_tail = (time.perf_counter() - t0) / 4
+    per = t_gen + t_seg + t_gn + t_tail
+    return {"value": round(1.0 / per, 4), "unit": "instances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"R={Rr}: generator (oracle/edage_np.py, 1 core, 1 path + 4 maps) {t_gen * 1e3:.0f} ms per instance; SegNet "
+                      f"(oracle/segnet_ref.py, float32 PyTorch-CPU composition, 1 problem) {t_seg:.1f} s; AE-ViT (PyTorch-CPU float32, 2 "
+                      f"problems) {t_gn * 1e3:.0f} ms each; extract_path + collision (oracle/plan_np.py, 1 core, 4 ridge maps) {t_tail * 1e3:.0f} ms each",
+            "host_cores": os.cpu_count()}
+
+
+def end_to_end_leg(torch, dev, steps, world, rank, cpu_leg):
+    """BASELINE config 5, one GPU's share: EDaGe-PP generation -> PPNet inference -> success rate / path length, at 512 x 512,
+    CHAINED in one timed loop: every step runs stage A (16 target paths) + stage B (16 placements each: 256 maps), SegNet on
+    those grids (segment_u8), GenNet on SegNet's labels (heatmap) and the planner tail (extract_path + collision check) on
+    GenNet's own heat map.  Instances shard by id over the ranks as in config 2; consecutive steps alternate over two HIP
+    streams, each with its own buffers.  instances/s == plans/s here: every generated instance is planned.
+    No trained weights ship with the reference, so the chained tail finds (almost) no plan — `tail_network_output` says so;
+    the success / length criterion of the OMPL harness (reach (1 + eps) x the target length,
+    experiments/ompl_experiments/updated_geometric_planner.py:260-277,349-354) is evaluated on the last batch with ridge heat
+    maps along the label paths (`tail_ridge`, untimed).  OMPL itself is absent: problems are emitted in the harness's JSON
+    schema (dataset.problem_records / solution_records) for an external run."""
+    import torch.distributed as dist
+    from ppnet_amd import dataset, edage, evaluate, shard
+    model = bench_ppnet(torch, dev, R5)
+    n_streams = max(1, int(os.environ.get("PPNET_STREAMS", "2")))
+    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+    n_local = PATHS5 * PLACEMENTS5
+    bufs = [(edage.PathsBatch(PATHS5, R5, MAP_SIZE, CLEARANCE, dev), edage.MapsBatch(n_local, R5, K, dev)) for _ in range(n_streams)]
+
+    def one(it, timers=None):
+        pb, mb = bufs[it % n_streams]
+        first_path, _, first_map = shard.local_ids(PATHS5 * world, PLACEMENTS5, rank, world, batch_index=it)
+        marks = iter(timers) if timers else None
+        r = model.generate_and_plan(pb, mb, PLACEMENTS5, first_path, first_map, seed=SEED + 5, obstacles_size=OBST_SIZE, obstacles_num=K,
+                                    mark=(lambda name: next(marks).record()) if timers else None)
+        return pb, mb, r["heat"], r["result"]
+    for i in range(2 * n_streams):                                   # allocator pools, tile descriptors, library workspaces: outside the clock
+        with torch.cuda.stream(streams[i % n_streams]):
+            one(i)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    one(0, ev)
+    torch.cuda.synchronize()
+    split = [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(steps):
+        with torch.cuda.stream(streams[i % n_streams]):
+            pb, mb, heat, res = one(100 + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank != 0:
+        return None
+    ms = el / steps * 1e3
+    seg_fl, gen_fl = ppnet_flops_per_plan(R5)
+    tflops = (seg_fl + gen_fl) * n_local / (ms * 1e-3) / 1e12
+    target_px = pb.length.repeat_interleave(PLACEMENTS5) * R5 / MAP_SIZE
+    init, end = mb.segpoint[:, 0].contiguous(), mb.segpoint[:, 10].contiguous()
+    obs, n_obs = mb.obstacles, mb.n_obstacles[:, 0].contiguous()
+    ev_net = evaluate.evaluate_plans(res, target_px)
+    ridge = evaluate.label_heatmaps(pb, mb, PLACEMENTS5)
+    res_r = model.plan_tail(ridge, init, end, obs, n_obs)
+    ev_ridge = evaluate.evaluate_plans(res_r, target_px)
+    # the harness's input / output schema for the last batch (updated_geometric_planner.py:500-569): problems as MapGenerate
+    # writes them, PPNet's solution appended the way the harness appends a planner's
+    problems = dataset.problem_records(mb, pb.length, PLACEMENTS5, first_index=0)
+    solved = dataset.solution_records(problems, res_r["success"], res_r["waypoints"], res_r["counts"], ms * 1e-3 / n_local)
+    rnd = lambda d: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()}
+    out = {"metric": "edage_pp_plus_ppnet_end_to_end_instances_per_sec", "value": round(world * n_local * steps / el, 1), "unit": "instances/s",
+           "plans_per_s": round(world * n_local * steps / el, 1), "ms_per_step": round(ms, 2), "steps": steps, "problems_per_step_per_gpu": n_local,
+           "dtype": "f64 generator, bf16 networks (fp32 accumulate)", "streams": n_streams,
+           "config": {"workload": f"BASELINE config 5, one GPU's share: {PATHS5} target paths x {PLACEMENTS5} placements at {R5}x{R5} -> DiNAT-B + SETR-UP "
+                                  "-> AE-ViT (down_time 4) -> extract_path -> collision check, chained", "resolution": R5, "obstacles_num": K,
+                      "clearance": CLEARANCE, "map_size": MAP_SIZE},
+           "ms_generate": round(split[0], 3), "ms_segnet": round(split[1], 2), "ms_gennet": round(split[2], 2), "ms_tail": round(split[3], 3),
+           "tail_network_output": dict(rnd(ev_net), note="the timed chain: GenNet's own heat map (seeded random weights: noise, few plans)"),
+           "tail_ridge": dict(rnd(ev_ridge), note="untimed, last batch: ridge heat maps along the label paths (GenNet's training target, blurred)"),
+           "ompl": "unavailable (no OMPL python bindings in this image): PPNet column only",
+           "harness_records": {"problems": len(problems), "with_solution": sum(1 for q in solved if q["Solution"][-1]["Waypoint"] is not None),
+                               "problem_keys": sorted(problems[0].keys()), "solution_keys": sorted(solved[0]["Solution"][-1].keys())},
+           "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tflops / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "gflop_per_plan": round((seg_fl + gen_fl) / 1e9, 2), "counting": "as executed (ppnet_flops_per_plan)"}}
+    try:
+        own, lib, own_ms, lib_ms = _kernel_split(torch, lambda: one(999), top=6)
+        out["roofline"]["dominant_kernels"] = own
+        out["own_kernels_ms"], out["other_kernels_ms"] = round(own_ms, 2), round(lib_ms, 2)
+    except Exception as e:
+        out["kernel_split_error"] = repr(e)[:200]
+    if cpu_leg:
+        try:
+            out["cpu_baseline"] = end_to_end_cpu_baseline(torch, R5, mb.grid, ridge, init, end, obs, n_obs)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)[:300]}
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None):
     """BASELINE config 3: PPNet inference (SegNet DiNAT-B + SETR-UP -> GenNet AE-ViT -> waypoint extraction ->
     collision check), batch of 256 problems over the 256x256 maps stage B just produced, per GPU.  Weights are
     seeded random initialisations of the reference architectures (no trained weights ship with the reference), so the
@@ -314,9 +528,9 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg):
     the fixed-size plan records (RCCL, own stream) when N > 1."""
     import torch.distributed as dist
     from ppnet_amd import evaluate, na, shard
-    from ppnet_amd.ppnet import PPNet
-    torch.manual_seed(0)
-    model = PPNet(resolution=R).to(dev).eval()
+    model = bench_ppnet(torch, dev, R)
+    if hold is not None:
+        hold["model"] = model                  # the float32 leg compares its outputs with this object's (ppnet.parity)
     g = mb.grid[:batch]
     init, end = mb.segpoint[:batch, 0].contiguous(), mb.segpoint[:batch, 10].contiguous()
     obs, n_obs = mb.obstacles[:batch], mb.n_obstacles[:batch, 0].contiguous()
@@ -407,7 +621,7 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg):
                        + (" -> all-gather of plan records" if world > 1 else ""),
            "ms_segnet": round(t_seg, 2), "ms_gennet": round(t_gen, 2), "ms_tail": round(t_tail, 2),
            "ms_per_batch_hip_graph": round(ms_graph, 2) if ms_graph is not None else None, "streams": n_streams,
-           "weights": "seeded random init (no trained weights in the reference)",
+           "weights": "seeded random init, neutral parameters randomised too (no trained weights in the reference)",
            "tail_input": "ridge heat maps along the label paths (GenNet's training target, blurred); the networks' own output is noise",
            "tail": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ev_tail.items()},
            "extract_ok_rate_network_output": round(float(net_tail["ok"].float().mean().item()), 4),
@@ -421,6 +635,25 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg):
     if cpu_leg:
         out["cpu_baseline"] = ppnet_cpu_baseline(torch, g, ridge, init, end, obs, n_obs, R)
     return out
+
+
+def pick_path_group(warmup, steps):
+    """Steps served by one stage-A launch (BENCH_PATH_GROUP overrides).  Every cross-stream hand-off is a marker packet the
+    compute queue drains before the next kernel starts (~5 us on this runtime): with one stage-A launch, one wait and one
+    release per GROUP steps instead of per step the stage-B kernels run back to back.  The work per step is unchanged; the
+    timed region must hold whole groups, so the group is the largest of 8..1 that divides both --warmup and --steps."""
+    env = os.environ.get("BENCH_PATH_GROUP")
+    if env:
+        return max(1, int(env))
+    import math
+    g = math.gcd(warmup, steps) if warmup else steps
+    for c in range(DEFAULT_PATH_GROUP_MAX, 1, -1):
+        if g % c == 0:
+            return c
+    return 1
+
+
+DEFAULT_PATH_GROUP_MAX = 1      # measured default, see DESIGN.md section 5
 
 
 def main():
@@ -437,6 +670,8 @@ def main():
     ap.add_argument("--ppnet-batch", type=int, default=256)
     ap.add_argument("--ppnet-steps", type=int, default=10)
     ap.add_argument("--no-ppnet-fp32", action="store_true", help="skip the float32 (reference-precision) PPNet leg")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the config-5 leg (generate -> PPNet -> success rate at 512 x 512)")
+    ap.add_argument("--end-to-end-steps", type=int, default=5)
     ap.add_argument("--segnet", choices=["dinat_setr", "nat_uper", "both"], default="both",
                     help="SegNet legs: dinat_setr = BASELINE config 3 (DiNAT-B + SETR-UP, inside the ppnet object); nat_uper = the reference's "
                          "default config (NAT-Base + UPerHead) as a leg of its own; both (default)")
@@ -465,23 +700,24 @@ def main():
     # GROUP > 1: one stage-A launch produces the target paths of GROUP consecutive steps (GROUP x PATHS workgroups instead of
     # PATHS: the latency chains fill the chip for a short while instead of trickling beside every stage-B launch); the steps
     # consume views of that batch.  Work per step is unchanged; a timed region of K steps contains K / GROUP stage-A launches.
-    GROUP = int(os.environ.get("BENCH_PATH_GROUP", "1"))
+    GROUP = pick_path_group(args.warmup, args.steps)
     if GROUP > 1 and (args.warmup % GROUP or args.steps % GROUP):
         raise SystemExit(f"BENCH_PATH_GROUP={GROUP}: --warmup and --steps must be multiples of it (the timed region must hold whole groups)")
-    TIMED_EVERY = 2 if args.steps < 80 else 4      # every 2nd / 4th launch carries a start marker: >= 10 launches averaged from --steps 20 on
+    TIMED_EVERY = 2 if args.steps < 80 else (4 if args.steps < 800 else 8)   # every 2nd / 4th / 8th launch carries a start marker: >= 10 launches averaged from --steps 20 on
     NPB = DEPTH + 1
     pbs = [edage.PathsBatch(PATHS * GROUP, R, MAP_SIZE, CLEARANCE, dev) for _ in range(NPB)]
     pviews = [[pb.view(k * PATHS, PATHS) for k in range(GROUP)] for pb in pbs]
-    # N > 1: the end-of-batch all-gather of the fixed-size records runs on its own stream beside the next batch, so the
-    # maps are double-buffered (batch i+1 must not overwrite the labels batch i's records are packed from).
+    # N > 1: the end-of-batch all-gather of the fixed-size records.  Stage B writes each step's records straight into a slice of
+    # a staging ring (shard.RecordRing) and ONE collective ships the records of GATHER steps — enough steps that a gather carries
+    # >= 1 M instances over all ranks, as SURVEY 8e sizes the exchange — on its own stream beside the next group's steps.
     exchange = world > 1 or bool(os.environ.get("BENCH_FORCE_EXCHANGE"))      # the env knob rehearses the stream logic on one GPU
-    NMB = 2 if exchange else 1
-    mbs = [edage.MapsBatch(PATHS * PLACEMENTS, R, K, dev) for _ in range(NMB)]
-    mb = mbs[0]
+    n_local = PATHS * PLACEMENTS
+    mb = edage.MapsBatch(n_local, R, K, dev)
+    ring, mviews = None, None
     if exchange:
-        s_comm = torch.cuda.Stream(dev)
-        gathered = [torch.empty(max(world, 1) * PATHS * PLACEMENTS, shard.RECORD_WIDTH, dtype=torch.float64, device=dev) for _ in range(NMB)]
-        sent = [None] * NMB       # the records of the batch in maps buffer m have been read by the collective (it may be rewritten)
+        GATHER = int(os.environ.get("BENCH_GATHER_STEPS", "0")) or shard.gather_steps(world, n_local)
+        ring = shard.RecordRing(world, n_local, GATHER, dev, torch.cuda.Stream(dev))
+        mviews = [[mb.with_records(ring.slot_view(sl, k)) for k in range(GATHER)] for sl in range(2)]
     prio = os.environ.get("BENCH_PRIO", "")
     lo_p, hi_p = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
     s_paths = [torch.cuda.Stream(dev, priority=hi_p if prio == "paths" else (lo_p if prio == "maps" else 0)) for _ in range(DEPTH)]
@@ -521,7 +757,6 @@ def main():
             if ea is not None:
                 stage_a_evs.append((ea, ready[b]))
         launched[0] = it
-    n_local = PATHS * PLACEMENTS
 
     def step(it):
         # a fresh batch every step: path / map ids advance so no two steps generate the same instances
@@ -545,23 +780,19 @@ def main():
         if it % TIMED_EVERY == 0 or args.steps < TIMED_EVERY:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record()
-        m = it % NMB
-        if exchange and sent[m] is not None:
-            s_maps.wait_event(sent[m])        # the records of batch it-2 have left this maps buffer
-        edage.generate_maps(pviews[b][sub], PLACEMENTS, OBST_SIZE, K, seed=SEED, first_map_id=first_map, out=mbs[m])
-        ev1 = torch.cuda.Event(enable_timing=ev0 is not None or bool(os.environ.get("BENCH_TIMED_HANDOFF")))   # a timestamp only on the sampled launches
-        ev1.record()
+        target = mb
+        if exchange:
+            ring.begin_step()                 # before a group's first step: the slot's previous collective has read it
+            target = mviews[ring.slot][ring.k]
+        edage.generate_maps(pviews[b][sub], PLACEMENTS, OBST_SIZE, K, seed=SEED, first_map_id=first_map, out=target)
+        ev1 = None
+        if ev0 is not None or sub == GROUP - 1 or os.environ.get("BENCH_TIMED_HANDOFF"):
+            ev1 = torch.cuda.Event(enable_timing=ev0 is not None or bool(os.environ.get("BENCH_TIMED_HANDOFF")))   # a timestamp only on the sampled launches
+            ev1.record()
         if sub == GROUP - 1:
             consumed[b] = ev1                     # the last step of the group releases the path buffer
-        if exchange:                          # end-of-batch gather of the fixed-size records (RCCL over xGMI), off the compute stream
-            with torch.cuda.stream(s_comm):
-                s_comm.wait_event(ev1)
-                if world > 1:                 # stage B wrote the packed records itself (ppn_maps_t.records): no pack pass
-                    shard.gather_records(mbs[m].records, world, out=gathered[m])
-                else:
-                    gathered[m].copy_(mbs[m].records)     # rehearsal stand-in for the collective
-                sent[m] = torch.cuda.Event()
-                sent[m].record(s_comm)
+        if exchange:
+            ring.end_step()                   # after the group's last step: one all-gather on the communication stream
         return ev0, ev1
 
     for it in range(args.warmup):
@@ -585,6 +816,9 @@ def main():
         torch.cuda.synchronize()
     clock_warm_ms = (time.perf_counter() - tw) * 1e3
     first = args.warmup + warm_steps
+    if exchange:
+        ring.flush()                          # the warm steps' partial group leaves outside the clock
+        gathers_before = ring.n_gathers
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -592,6 +826,8 @@ def main():
     t0 = time.perf_counter()
     evs = [step(first + it) for it in range(args.steps)]
     stage_a_on[0] = False
+    if exchange:
+        ring.flush()                          # every record of the timed steps is gathered inside the clock
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -603,7 +839,6 @@ def main():
 
     timed = [(a, b) for a, b in evs if a is not None]
     maps_kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / len(timed)
-    mb = mbs[(first + args.steps - 1) % NMB]     # the newest batch
     stage_a_ms = sum(a.elapsed_time(b) for a, b in stage_a_evs) / len(stage_a_evs) if stage_a_evs else None
     k_tot = float(mb.n_obstacles[:, 0].double().mean().item())
     k_pocket = float(pbs[0].n_obstacles.double().mean().item())
@@ -614,8 +849,9 @@ def main():
     ppnet = None
     if not args.no_ppnet:
         last = first + args.steps - 1
+        hold = {}
         ppnet = ppnet_leg(torch, dev, pviews[(last // GROUP) % NPB][last % GROUP], mb, args.ppnet_batch, args.ppnet_steps, world, rank,
-                          cpu_leg=(world == 1 and not args.no_cpu_baseline))
+                          cpu_leg=(world == 1 and not args.no_cpu_baseline), hold=hold)
     if rank == 0:
         bytes_per_launch = algorithmic_bytes_per_map(k_tot, k_pocket) * n_local
         achieved = bytes_per_launch / (maps_kernel_ms * 1e-3) / 1e9
@@ -649,6 +885,11 @@ def main():
                         "note": "a latency chain, one workgroup per path, in flight beside stage B on its own streams"},
             "stage_b": {"kernel": "edage_maps_kernel_t<3>", "kernel_ms": round(maps_kernel_ms, 4),
                         "maps_per_s": round(n_local / (maps_kernel_ms * 1e-3), 1)},
+            "exchange": ({"gather_every_steps": ring.G, "gathers_in_timed_region": ring.n_gathers - gathers_before,
+                          "bytes_per_rank_per_gather": ring.G * n_local * shard.RECORD_WIDTH * 8,
+                          "collective": "all_gather_into_tensor (RCCL)" if world > 1 else "copy (BENCH_FORCE_EXCHANGE rehearsal on one GPU)"}
+                         if exchange else None),
+            "path_group": GROUP,
             "placement_success": round(placed, 4),
             "mean_obstacles_per_map": round(k_tot, 2),
         }
@@ -661,13 +902,26 @@ def main():
                     out["segnet_nat_uper"] = {"error": repr(e)[:300]}
             if world == 1 and not args.no_ppnet_fp32:
                 try:
-                    f32 = ppnet_fp32_leg(torch, dev, mb.grid, args.ppnet_batch)
+                    f32 = ppnet_fp32_leg(torch, dev, mb.grid, args.ppnet_batch, parity_with=hold)
+                    # the bf16 figure's tolerance, measured in this run against the float32 leg on the same grids
+                    ppnet["parity"] = f32.pop("parity")
                     f32["bf16_speedup"] = round(ppnet["ms_segnet"] + ppnet["ms_gennet"] and f32["ms_per_batch"] / (ppnet["ms_segnet"] + ppnet["ms_gennet"]), 2)
                     out["ppnet_fp32"] = f32
                 except Exception as e:
                     out["ppnet_fp32"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+    if not args.no_ppnet and not args.no_end_to_end:
+        hold = None                            # (the config-3 object is no longer needed)
+        try:
+            e2e = end_to_end_leg(torch, dev, args.end_to_end_steps, world, rank, cpu_leg=(world == 1 and not args.no_cpu_baseline))
+        except Exception as e:
+            if world > 1:
+                raise                          # a rank that skipped the leg's collectives would hang the others
+            e2e = {"error": repr(e)[:300]}
+        if rank == 0:
+            out["end_to_end_r512"] = e2e
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

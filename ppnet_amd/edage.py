@@ -109,6 +109,17 @@ class MapsBatch:
         self.records = e(n, 26, **f64)             # shard.RECORD_WIDTH: angle, flags, translation, segpoint (all-gather unit)
         self.struct = L.MapsStruct(**{name: _ptr(getattr(self, name)) for name, _ in L.MapsStruct._fields_})
 
+    def with_records(self, records):
+        """This batch with its all-gather records written somewhere else: `records` is a contiguous [n, 26] float64 device
+        tensor, typically one step's slice of a staging ring that holds the records of several steps until ONE collective
+        ships them (shard.RecordRing).  No copies: the same tensors, a new pointer struct."""
+        assert tuple(records.shape) == (self.n, 26) and records.dtype == torch.float64 and records.is_contiguous()
+        v = object.__new__(MapsBatch)
+        v.__dict__.update(self.__dict__)
+        v.records = records
+        v.struct = L.MapsStruct(**{name: _ptr(getattr(v, name)) for name, _ in L.MapsStruct._fields_})
+        return v
+
 
 def generate_paths(n_paths, resolution=224, map_size=50, clearance=1, seed=0, first_path_id=0, device="cuda:0",
                    draws=None, pocket_draws=None, debug=False, out=None, force_straight=None, hull_start=None):

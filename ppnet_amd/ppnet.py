@@ -112,6 +112,30 @@ class PPNet(torch.nn.Module):
         return self.plan_tail(heat, init, end, obstacles, n_obstacles, clearance, down_sample_rate)
 
     @torch.no_grad()
+    def generate_and_plan(self, paths, maps, placements, first_path_id=0, first_map_id=0, seed=0, obstacles_size=5, obstacles_num=20,
+                          clearance=None, down_sample_rate=2, mark=None):
+        """BASELINE config 5's chain on the current stream, nothing read back in between: stage A into `paths` (a PathsBatch) ->
+        stage B into `maps` (paths.n x placements maps) -> SegNet labels of those grids -> GenNet heat map of those labels ->
+        extract_path + collision check on that heat map, start / goal / obstacles straight from `maps`
+        (EDaGe-PP/MapGenerate.py:40-124 -> SegNet/test.py -> GenNet/predict.py -> process_map.py:452-506).
+        mark: optional callable(stage name) called between the stages (bench.py records timing events with it).
+        Returns dict(mask, heat, result)."""
+        mark = mark or (lambda name: None)
+        mark("start")
+        edage.generate_paths(paths.n, paths.R, paths.map_size, paths.clearance, seed=seed, first_path_id=first_path_id,
+                             device=paths.device, out=paths)
+        edage.generate_maps(paths, placements, obstacles_size, obstacles_num, seed=seed, first_map_id=first_map_id, out=maps)
+        mark("generated")
+        mask = self.segment_u8(maps.grid)
+        mark("segmented")
+        heat = self.heatmap(mask)
+        mark("heatmap")
+        init, end = maps.segpoint[:, 0].contiguous(), maps.segpoint[:, 10].contiguous()
+        result = self.plan_tail(heat, init, end, maps.obstacles, maps.n_obstacles[:, 0].contiguous(), clearance, down_sample_rate)
+        mark("planned")
+        return dict(mask=mask, heat=heat, result=result)
+
+    @torch.no_grad()
     def capture(self, grid_u8, init, end, obstacles, n_obstacles, tail_heat=None, clearance=None, down_sample_rate=2, warmup=2):
         """The whole batch — segment_u8 -> heatmap -> plan_tail, ~290 kernel launches — recorded once as ONE HIP graph
         (hipStreamBeginCapture through torch.cuda.graph) for this batch shape; returns a CapturedPlan whose replay() is a single

@@ -838,6 +838,30 @@ class SegNet(nn.Module):
         return losses
 
 
+def randomize_neutral_parameters(model, seed=0, gamma=(0.05, 0.3)):
+    """Give every parameter that a fresh initialisation leaves NEUTRAL a non-trivial seeded value, in place: LayerScale
+    (`layer_scale=1e-5`, dinat_base.py:14, makes every residual branch invisible), biases (0), LayerNorm / BatchNorm affine
+    parameters (1 / 0), the relative position bias and the BatchNorm running statistics (0 / 1).  No trained weights ship with
+    the reference; a model initialised this way exercises the arithmetic the way a trained checkpoint does, which is what a
+    precision comparison (bench.py's `ppnet.parity`, tests/test_ppnet_config3.py) needs.  Returns the model."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("gamma1") or name.endswith("gamma2"):
+                p.copy_(torch.empty(p.shape).uniform_(gamma[0], gamma[1], generator=g))
+            elif p.dim() == 1 and name.endswith("bias"):
+                p.copy_(torch.empty(p.shape).uniform_(-0.2, 0.2, generator=g))
+            elif p.dim() == 1 and name.endswith("weight"):
+                p.copy_(torch.empty(p.shape).uniform_(0.7, 1.3, generator=g))
+            elif name.endswith("rpb"):
+                p.copy_(torch.empty(p.shape).normal_(0.0, 0.5, generator=g))
+        for mod in model.modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.empty(mod.running_mean.shape).uniform_(-0.2, 0.2, generator=g))
+                mod.running_var.copy_(torch.empty(mod.running_var.shape).uniform_(0.5, 1.5, generator=g))
+    return model
+
+
 def decode_losses(logit, gt, loss_weight=1.0, ignore_index=255):
     """(loss_ce, acc_seg) of BaseDecodeHead.losses (decode_head.py:231-265) for resized logits [B,C,H,W] and labels [B,H,W].
     mmseg's CrossEntropyLoss is F.cross_entropy(reduction='none', ignore_index) followed by a mean over ALL pixels — ignored

@@ -78,9 +78,92 @@ def gather_records(rec, world, sizes=None, group=None, out=None, always_collecti
     return torch.cat([out[r * m:r * m + sizes[r]] for r in range(world)])
 
 
+def gather_steps(world, rows_per_step, target_rows=1_000_000):
+    """Steps between two end-of-batch gathers: enough that one collective carries the records of >= `target_rows` instances
+    over all ranks (SURVEY 8e sizes the exchange as ONE gather per config-4 batch of 1 M instances, not one per 10 000-map
+    kernel launch: a step is 0.19 ms, a collective launch costs tens of microseconds and CUs beside it)."""
+    return max(1, -(-int(target_rows) // (max(int(world), 1) * int(rows_per_step))))
+
+
+class RecordRing:
+    """The records of G consecutive steps staged in device memory and shipped by ONE all-gather (the end-of-batch exchange),
+    double-buffered: while the collective of group g reads slot g % 2 on the communication stream, the steps of group g + 1
+    write the other slot.  Stage B writes a step's records straight into `slot_view(k)` (ppn_maps_t.records), so there is no
+    pack pass and no copy in front of the collective.
+
+        ring = RecordRing(world, rows_per_step, G, device, comm_stream)
+        for every step:  out = ring.begin_step()      # [rows, width] slice to write; waits (on the current stream) for the
+                         ...launch the producer...     #   slot's previous collective before its first step only
+                         ring.end_step()               # ships the group after its G-th step
+        ring.flush()                                   # ships a partial group (end of a timed region / of the job)
+
+    On a CUDA device the hand-offs are events between the current (compute) stream and `comm_stream`; on the CPU (gloo tests)
+    the same calls run synchronously.  world == 1 with collective=False copies instead of gathering (a one-GPU rehearsal of
+    the stream logic)."""
+
+    def __init__(self, world, rows_per_step, steps, device, comm_stream=None, width=RECORD_WIDTH, group=None, collective=True):
+        self.world, self.rows, self.G, self.width = int(world), int(rows_per_step), int(steps), int(width)
+        self.device, self.comm, self.group = torch.device(device), comm_stream, group
+        self.collective = collective and (self.world > 1 or collective == "always")
+        kw = dict(dtype=torch.float64, device=self.device)
+        self.ring = [torch.empty(self.G * self.rows, self.width, **kw) for _ in range(2)]
+        self.gathered = [torch.empty(max(self.world, 1) * self.G * self.rows, self.width, **kw) for _ in range(2)]
+        self.sent = [None, None]            # event: the slot's records have been read by its collective
+        self.slot, self.k = 0, 0
+        self.n_gathers, self.last = 0, None  # `last` = (gathered rows view, steps in it) of the newest shipped group
+
+    def slot_view(self, slot, k):
+        return self.ring[slot][k * self.rows:(k + 1) * self.rows]
+
+    def begin_step(self):
+        if self.k == 0 and self.sent[self.slot] is not None:
+            if self.device.type == "cuda":
+                torch.cuda.current_stream(self.device).wait_event(self.sent[self.slot])
+            self.sent[self.slot] = None
+        return self.slot_view(self.slot, self.k)
+
+    def end_step(self):
+        self.k += 1
+        if self.k == self.G:
+            self.flush()
+
+    def flush(self):
+        k, slot = self.k, self.slot
+        if k == 0:
+            return None
+        src = self.ring[slot][:k * self.rows]
+        out = self.gathered[slot][:max(self.world, 1) * k * self.rows]
+
+        def ship():
+            if self.collective:
+                dist.all_gather_into_tensor(out, src, group=self.group)
+            else:
+                out.copy_(src)
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()                                     # the group's last producer, on the compute stream
+            comm = self.comm if self.comm is not None else torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev)
+                ship()
+                self.sent[slot] = torch.cuda.Event()
+                self.sent[slot].record(comm)
+        else:
+            ship()
+        self.slot, self.k = slot ^ 1, 0
+        self.n_gathers += 1
+        self.last = (out, k)
+        return out
+
+    def rank_rows(self, out, k, rank, step):
+        """Rows of `rank`'s step `step` inside a gathered group of k steps (all_gather lays ranks out one after the other)."""
+        base = (rank * k + step) * self.rows
+        return out[base:base + self.rows]
+
+
 def agreed_max(value, world, device=None):
     """The largest `value` over the ranks, on every rank (one all-reduce; `value` itself when world == 1).  bench.py decides with it
-    whether the untimed clock-warm phase goes on: every step carries a collective at N > 1, so all ranks must take the same number."""
+    whether the untimed clock-warm phase goes on: the steps feed collectives at N > 1, so all ranks must take the same number."""
     if world <= 1:
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)

@@ -1,0 +1,81 @@
+"""bench.py's own code paths on one GPU: the N > 1 exchange branch rehearsed in a fresh child process (BENCH_FORCE_EXCHANGE:
+record ring, communication stream, events — everything but the collective itself, which tests/test_gpu_rccl.py and
+tests/test_shard_gloo.py cover), and config 5's chain (PPNet.generate_and_plan) against the same stages called one by one."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra_env, *args):
+    env = dict(os.environ)
+    env.update(extra_env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-ppnet", "--no-cpu-baseline", *args],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def test_exchange_branch_runs_in_a_child_process():
+    """The driver's command with and without the exchange branch: rc 0, one JSON line, the forced run within 10 % of the
+    plain one (the gathers ride a side stream), every timed step's records gathered inside the clock."""
+    plain = _bench({})
+    assert plain["exchange"] is None and plain["n_gpus"] == 1 and plain["steps"] == 20
+    forced = _bench({"BENCH_FORCE_EXCHANGE": "1"})
+    ex = forced["exchange"]
+    assert ex["gather_every_steps"] == 100 and ex["gathers_in_timed_region"] == 1      # 20 steps: one partial group, flushed in the clock
+    assert abs(forced["value"] / plain["value"] - 1.0) < 0.10, (forced["value"], plain["value"])
+    small = _bench({"BENCH_FORCE_EXCHANGE": "1", "BENCH_GATHER_STEPS": "8"})
+    assert small["exchange"]["gather_every_steps"] == 8 and small["exchange"]["gathers_in_timed_region"] == 3    # 8 + 8 + 4
+    assert abs(small["value"] / plain["value"] - 1.0) < 0.15
+    for d in (plain, forced, small):
+        assert d["roofline"]["bound"] == "hbm" and 0.2 < d["roofline"]["frac"] < 1.0 and d["placement_success"] > 0.99
+
+
+def test_generate_and_plan_chain_equals_separate_calls():
+    """Config 5's chain at 512 x 512 on two alternating streams (what bench.py's end_to_end_r512 leg times) against the same
+    stages called one by one on the default stream with a synchronise after each: identical grids, labels, heat maps, plans."""
+    from ppnet_amd import edage
+    from ppnet_amd.gennet import AEViT
+    from ppnet_amd.ppnet import PPNet
+    from ppnet_amd.segnet import SegNet, randomize_neutral_parameters
+    dev = torch.device("cuda:0")
+    R, P, Q, K = 512, 2, 4, 20
+    torch.manual_seed(0)
+    model = PPNet(R, segnet=randomize_neutral_parameters(SegNet().eval(), seed=1), gennet=AEViT(1, 1, R, 24).eval()).to(dev).eval()
+    ids = [(0, 0), (P, P * Q), (2 * P, 2 * P * Q)]
+    want = []
+    for fp, fm in ids:
+        pb = edage.generate_paths(P, R, 50, 3, seed=5, first_path_id=fp, device=dev)
+        torch.cuda.synchronize()
+        mb = edage.generate_maps(pb, Q, 5, K, seed=5, first_map_id=fm)
+        torch.cuda.synchronize()
+        mask = model.segment_u8(mb.grid)
+        torch.cuda.synchronize()
+        heat = model.heatmap(mask)
+        torch.cuda.synchronize()
+        res = model.plan_tail(heat, mb.segpoint[:, 0].contiguous(), mb.segpoint[:, 10].contiguous(), mb.obstacles, mb.n_obstacles[:, 0].contiguous())
+        torch.cuda.synchronize()
+        want.append((mb.grid.clone(), mask.clone(), heat.clone(), {k: v.clone() for k, v in res.items()}))
+    streams = [torch.cuda.Stream(dev) for _ in range(2)]
+    bufs = [(edage.PathsBatch(P, R, 50, 3, dev), edage.MapsBatch(P * Q, R, K, dev)) for _ in range(2)]
+    for rep in range(2):
+        got = []
+        for i, (fp, fm) in enumerate(ids):
+            pb, mb = bufs[i % 2]
+            with torch.cuda.stream(streams[i % 2]):
+                r = model.generate_and_plan(pb, mb, Q, fp, fm, seed=5, obstacles_size=5, obstacles_num=K)
+                got.append((mb.grid.clone(), r["mask"].clone(), r["heat"].clone(), {k: v.clone() for k, v in r["result"].items()}))
+        torch.cuda.synchronize()
+        for (g0, m0, h0, r0), (g1, m1, h1, r1) in zip(want, got):
+            assert torch.equal(g0, g1) and torch.equal(m0, m1) and torch.equal(h0, h1)
+            for k in ("ok", "counts", "collision", "success", "waypoints"):
+                assert torch.equal(r0[k], r1[k]), k
+    assert float(want[0][1].float().mean()) not in (0.0, 1.0)                  # the labels are not degenerate

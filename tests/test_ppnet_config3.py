@@ -270,6 +270,44 @@ def test_captured_graph_equals_eager(dev, stage_b, segnet_models):
 
 
 @pytest.mark.gpu
+def test_two_captures_of_different_batch_sizes_in_one_process(dev, stage_b, segnet_models):
+    """Regression cover for round 3's capture fault (HSA memory aperture violation in na2d_halo16_kernel when a second graph, of
+    another batch size, was captured in the same process: tile descriptors used to be graph allocation nodes).  Now the
+    launchers allocate nothing per launch: descriptor tables are cached per geometry, and a geometry FIRST MET WHILE CAPTURING
+    is declined (na2d_halo16_launch returns -1, the per-tile kernel runs — same arithmetic).  Here: a warm capture at batch 4
+    (PPNet.capture), then a COLD capture at batch 6 — a batch size this process has never run, recorded without a warm-up pass,
+    so its geometries are first met inside the capture —, both graphs replayed alternately, compared with eager runs bit for bit."""
+    _, _, p16 = segnet_models
+    pb, mb = stage_b
+    init, end = mb.segpoint[:, 0].contiguous(), mb.segpoint[:, 10].contiguous()
+    obs, n_obs = mb.obstacles, mb.n_obstacles[:, 0].contiguous()
+    g4 = mb.grid[:4].clone()
+    cp4 = p16.capture(g4, init[:4].contiguous(), end[:4].contiguous(), obs[:4].contiguous(), n_obs[:4].contiguous())
+    g6 = mb.grid[2:8].clone()
+    cold = {}
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    torch.cuda.synchronize()
+    graph6 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph6):                                             # no warm-up at this batch size
+        cold["mask"] = p16.segment_u8(g6)
+        cold["heat"] = p16.heatmap(cold["mask"])
+    for rep in range(2):
+        for grid4, grid6 in ((mb.grid[:4], mb.grid[2:8]), (mb.grid[4:8], mb.grid[:6])):
+            cp4.grid.copy_(grid4)
+            g6.copy_(grid6)
+            cp4.replay()
+            graph6.replay()
+            torch.cuda.synchronize()
+            m4, m6 = cp4.mask.clone(), cold["mask"].clone()
+            h4, h6 = cp4.heat.clone(), cold["heat"].clone()
+            want4 = p16.segment_u8(grid4.contiguous())                         # eager (from the second pass on: cached descriptors)
+            want6 = p16.segment_u8(grid6.contiguous())
+            assert torch.equal(m4, want4) and torch.equal(m6, want6)
+            assert torch.equal(h4, p16.heatmap(want4)) and torch.equal(h6, p16.heatmap(want6))
+
+
+@pytest.mark.gpu
 def test_batches_on_two_streams_equal_one_stream(dev, stage_b, segnet_models):
     """bench.py alternates consecutive batches over two HIP streams.  Every buffer of the path belongs to its call (or is keyed
     by the stream), so two batches in flight must produce exactly what they produce one after the other."""

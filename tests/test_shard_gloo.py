@@ -143,3 +143,49 @@ def test_plan_records_gather_two_ranks_gloo(tmp_path):
     r0, o0 = torch.load(os.path.join(tmp_path, "plan0.pt"), weights_only=True)
     r1, o1 = torch.load(os.path.join(tmp_path, "plan1.pt"), weights_only=True)
     assert torch.equal(o0, torch.cat([r0, r1])) and torch.equal(o1, o0)
+
+
+def _ring_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows, G, steps = 4, 3, 8                          # 8 steps = two full groups + a partial one of 2 (flushed at the end)
+    ring = shard.RecordRing(world, rows, G, "cpu")
+    groups = []
+    for it in range(steps):
+        out = ring.begin_step()
+        # what stage B writes for step `it` on this rank: a value that names (rank, step, row, column)
+        out.copy_(torch.arange(rows * shard.RECORD_WIDTH, dtype=torch.float64).reshape(rows, -1) + 1000.0 * it + 100000.0 * rank)
+        before = ring.n_gathers
+        ring.end_step()
+        if ring.n_gathers != before:
+            groups.append((ring.last[0].clone(), ring.last[1]))
+    tail = ring.flush()
+    groups.append((tail.clone(), ring.last[1]))
+    assert ring.flush() is None                        # nothing staged: no collective
+    torch.save(groups, os.path.join(out_dir, f"ring{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_record_ring_ships_groups_of_steps_in_one_collective(tmp_path):
+    """bench.py's end-of-batch exchange at N > 1: the records of G steps staged in a ring, ONE all-gather per group, a partial
+    group flushed at the end; every rank receives every rank's rows of every step, in (rank, step) order."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ring_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(tmp_path / f"ring{r}.pt") for r in range(world)]
+    assert [k for _, k in got[0]] == [3, 3, 2]
+    base = torch.arange(4 * shard.RECORD_WIDTH, dtype=torch.float64).reshape(4, -1)
+    step0 = 0
+    for gi, (out, k) in enumerate(got[0]):
+        assert torch.equal(out, got[1][gi][0])        # both ranks hold the same gathered group
+        assert out.shape == (world * k * 4, shard.RECORD_WIDTH)
+        for r in range(world):
+            for j in range(k):
+                want = base + 1000.0 * (step0 + j) + 100000.0 * r
+                assert torch.equal(out[(r * k + j) * 4:(r * k + j + 1) * 4], want)
+        step0 += k
+    assert shard.gather_steps(8, 10000) == 13 and shard.gather_steps(1, 10000) == 100 and shard.gather_steps(8, 10 ** 7) == 1
