@@ -198,21 +198,29 @@ def ppnet_cpu_baseline(torch, grids_u8, heat_ridge, init, end, obs, n_obs, R_):
             "host_cores": os.cpu_count()}
 
 
+CALIBRATION_PROBLEMS = 4        # grids of the batch the classifier bias is balanced on (bench_ppnet)
 PARITY_PROBLEMS = 16            # problems of the batch on which the bf16 leg is compared with the float32 leg
 MFMA_PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: float32-input MFMA = the float32 vector rate
 
 
-def bench_ppnet(torch, dev, resolution, weights_dtype="bf16"):
+def bench_ppnet(torch, dev, resolution, weights_dtype="bf16", calibrate=None):
     """The PPNet object every leg times: the reference architectures (DiNAT-B + SETR-UP, AE-ViT dim 24) with seeded random
     weights — no trained weights ship with the reference — whose NEUTRAL parameters (LayerScale 1e-5, zero biases, unit norms,
     BatchNorm statistics) are given non-trivial seeded values too (segnet.randomize_neutral_parameters), so the residual
     branches carry signal as in a trained checkpoint and the bf16-vs-float32 comparison (`ppnet.parity`) means something.
-    The same seeds in every leg: the bf16 and the float32 objects hold the same weights."""
+    The same seeds in every leg: the bf16 and the float32 objects hold the same weights.  calibrate: u8 grids [n,R,R] on which
+    the classifier's bias is balanced (segnet.balance_classifier_bias, float32, before anything is folded) — an untrained
+    network otherwise puts every pixel in one class and label agreement would be trivially 1; same grids, same shift, in
+    every leg."""
+    from ppnet_amd import edage
     from ppnet_amd.gennet import AEViT
     from ppnet_amd.ppnet import PPNet
-    from ppnet_amd.segnet import SegNet, randomize_neutral_parameters
+    from ppnet_amd.segnet import SegNet, balance_classifier_bias, normalize_images, randomize_neutral_parameters
     torch.manual_seed(0)
     seg = randomize_neutral_parameters(SegNet().eval(), seed=1)
+    if calibrate is not None:
+        seg.to(dev)
+        balance_classifier_bias(seg, normalize_images(edage.grid_to_rgb(calibrate) * 255.0))
     gen = randomize_neutral_parameters(AEViT(1, 1, resolution, 24).eval(), seed=2)
     kw = {} if weights_dtype == "bf16" else {"weights_dtype": None}
     return PPNet(resolution=resolution, segnet=seg, gennet=gen, **kw).to(dev).eval()
@@ -266,7 +274,7 @@ def ppnet_fp32_leg(torch, dev, grids_u8, batch, steps=3, parity_with=None):
     speed-up over a same-precision run.  On this path the convolutions and projections are ROCm library calls (MIOpen,
     hipBLASLt / rocBLAS through PyTorch) in float32; the neighbourhood attention (ppn_na2d_fwd, float32 form), the fused residual /
     LayerNorm / up-sampling / label kernels are the build's own.  The kernel names of one batch are listed from the profiler."""
-    model = bench_ppnet(torch, dev, R, weights_dtype="f32")
+    model = bench_ppnet(torch, dev, R, weights_dtype="f32", calibrate=grids_u8[:CALIBRATION_PROBLEMS])
     # PPNet(weights_dtype=None) asks MIOpen for its exhaustive algorithm search (140 s on a fresh box for a 6 % faster batch:
     # 147 -> ~138 ms): a reported leg of a bench that has to finish in minutes takes the heuristic pick
     torch.backends.cudnn.benchmark = bool(os.environ.get("BENCH_FP32_MIOPEN_SEARCH"))
@@ -528,7 +536,7 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None)
     the fixed-size plan records (RCCL, own stream) when N > 1."""
     import torch.distributed as dist
     from ppnet_amd import evaluate, na, shard
-    model = bench_ppnet(torch, dev, R)
+    model = bench_ppnet(torch, dev, R, calibrate=mb.grid[:CALIBRATION_PROBLEMS])
     if hold is not None:
         hold["model"] = model                  # the float32 leg compares its outputs with this object's (ppnet.parity)
     g = mb.grid[:batch]

@@ -862,6 +862,17 @@ def randomize_neutral_parameters(model, seed=0, gamma=(0.05, 0.3)):
     return model
 
 
+@torch.no_grad()
+def balance_classifier_bias(segnet, images):
+    """Shift the decode head's class-1 bias so that the two classes split the pixels of `images` ([n,3,R,R], normalised)
+    evenly: an UNTRAINED network labels every pixel alike, which makes any label-agreement figure trivially 1.  Run on the
+    unprepared module (before SegNet.prepare_inference folds anything); returns the shift applied (the median class margin)."""
+    lg = segnet.encode_decode(images).float()
+    d = (lg[:, 1] - lg[:, 0]).flatten().median()
+    segnet.decode_head.conv_seg.bias[1] -= d.to(segnet.decode_head.conv_seg.bias.dtype)
+    return float(d)
+
+
 def decode_losses(logit, gt, loss_weight=1.0, ignore_index=255):
     """(loss_ce, acc_seg) of BaseDecodeHead.losses (decode_head.py:231-265) for resized logits [B,C,H,W] and labels [B,H,W].
     mmseg's CrossEntropyLoss is F.cross_entropy(reduction='none', ignore_index) followed by a mean over ALL pixels — ignored

@@ -45,11 +45,14 @@ def test_generate_and_plan_chain_equals_separate_calls():
     from ppnet_amd import edage
     from ppnet_amd.gennet import AEViT
     from ppnet_amd.ppnet import PPNet
-    from ppnet_amd.segnet import SegNet, randomize_neutral_parameters
+    from ppnet_amd.segnet import SegNet, balance_classifier_bias, normalize_images, randomize_neutral_parameters
     dev = torch.device("cuda:0")
     R, P, Q, K = 512, 2, 4, 20
     torch.manual_seed(0)
-    model = PPNet(R, segnet=randomize_neutral_parameters(SegNet().eval(), seed=1), gennet=AEViT(1, 1, R, 24).eval()).to(dev).eval()
+    seg = randomize_neutral_parameters(SegNet().eval(), seed=1).to(dev)
+    cal = edage.generate_maps(edage.generate_paths(1, R, 50, 3, seed=77, device=dev), 2, 5, K, seed=77)
+    balance_classifier_bias(seg, normalize_images(edage.grid_to_rgb(cal.grid) * 255.0))      # both classes present (untrained weights)
+    model = PPNet(R, segnet=seg, gennet=AEViT(1, 1, R, 24).eval()).to(dev).eval()
     ids = [(0, 0), (P, P * Q), (2 * P, 2 * P * Q)]
     want = []
     for fp, fm in ids:
@@ -78,4 +81,4 @@ def test_generate_and_plan_chain_equals_separate_calls():
             assert torch.equal(g0, g1) and torch.equal(m0, m1) and torch.equal(h0, h1)
             for k in ("ok", "counts", "collision", "success", "waypoints"):
                 assert torch.equal(r0[k], r1[k]), k
-    assert float(want[0][1].float().mean()) not in (0.0, 1.0)                  # the labels are not degenerate
+    assert 0.02 < float(want[0][1].float().mean()) < 0.98                      # the labels are not degenerate
