@@ -454,6 +454,22 @@ int32_t ppn_nat_gemm_partials(int32_t C);
 int ppn_nat_gemm_bf16(const void* a, const void* w, const float* bias, const float* colsum, const float* stats_in, int32_t partials_in,
                       float* stats_out, void* c, int64_t M, int32_t N, int32_t K, int32_t mode, float eps, void* stream);
 
+/* The MLP half of a NAT layer as ONE kernel (SegNet/nat.py:62-85 `Mlp.forward`, :147-153 of `NATLayer.forward`; csrc/nat_mlp.hip):
+ *     s += gelu(LN(s) W1^T + b1) W2^T + b2        in place on the residual stream s [M][C] (bfloat16),
+ * the hidden activation [M][HID] never written: it is produced and consumed chunk by chunk inside the compute unit.
+ * ppn_nat_mlp_supported: 1 when (M, C, HID) is served (C = 256, M % 256 == 0, HID % 32 == 0), else 0 — callers fall back to two
+ *   ppn_nat_gemm_bf16 calls (modes 1 and 2).
+ * ppn_nat_mlp_pack_bf16: wpk [2 * C * HID] bfloat16 <- the two weights in the kernel's streaming order; w1 [HID][C] with the
+ *   LayerNorm folded in (w1 = W1 diag(gamma)), w2 [C][HID] with LayerScale folded in (torch Linear layouts).  Once per weight change.
+ * ppn_nat_mlp_bf16: hb [HID][2] float32 = (colsum_k w1[h][k] of the bfloat16 values, b1[h] + W1[h] . beta); b2 [C] float32;
+ *   stats_out [C / 128][M][2] (or null) receives (sum, sum of squares) of every row of the NEW s per 128 columns, of the bfloat16
+ *   values stored — the stats_in of the next ppn_nat_gemm_bf16 mode-0 call.  LayerNorm over the C features with `eps`; erf-GELU
+ *   through the logistic fit of ppn_nat_gemm_bf16 mode 1.  Bit-reproducible (no atomics). */
+int32_t ppn_nat_mlp_supported(int64_t M, int32_t C, int32_t HID);
+int ppn_nat_mlp_pack_bf16(const void* w1, const void* w2, void* wpk, int32_t C, int32_t HID, void* stream);
+int ppn_nat_mlp_bf16(void* s, const void* wpk, const float* hb, const float* b2, float* stats_out, int64_t M, int32_t C, int32_t HID,
+                     float eps, void* stream);
+
 /* stats[rows][2] = (sum, sum of squares) of every row of the bfloat16 tensor x [rows][C], C % 8 == 0 in [64, 1024]: the
  * stats_in (partials_in = 1) of a level's first projection, whose input no mode-2 GEMM produced. */
 int ppn_row_stats_bf16(const void* x, int64_t rows, int32_t C, float* stats, void* stream);

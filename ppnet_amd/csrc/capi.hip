@@ -611,6 +611,27 @@ int32_t ppn_nat_gemm_partials(int32_t C) {
     return ppn::nat_gemm128_partials(C) ? C / 128 : C / 256;
 }
 
+int32_t ppn_nat_mlp_supported(int64_t M, int32_t C, int32_t HID) { return ppn::nat_mlp_supported(M, C, HID) ? 1 : 0; }
+
+int ppn_nat_mlp_pack_bf16(const void* w1, const void* w2, void* wpk, int32_t C, int32_t HID, void* stream) {
+    if (!w1 || !w2 || !wpk || HID <= 0 || (HID % 32) != 0) return PPN_E_INVALID;
+    const int e = ppn::nat_mlp_pack_launch(w1, w2, wpk, C, HID, (hipStream_t)stream);
+    if (e == -1) return PPN_E_UNSUPPORTED;
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
+int ppn_nat_mlp_bf16(void* s, const void* wpk, const float* hb, const float* b2, float* stats_out, int64_t M, int32_t C, int32_t HID,
+                     float eps, void* stream) {
+    if (!s || !wpk || !hb || !b2 || M <= 0 || M >= (1LL << 31)) return PPN_E_INVALID;
+    if (!ppn::nat_mlp_supported(M, C, HID)) return PPN_E_UNSUPPORTED;
+    const int e = ppn::nat_mlp_launch(s, wpk, hb, b2, stats_out, M, C, HID, eps, (hipStream_t)stream);
+    if (e == -1) return PPN_E_UNSUPPORTED;
+    if (e == -2) return hip_fail(hipErrorInvalidDevice);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
 int ppn_row_stats_bf16(const void* x, int64_t rows, int32_t C, float* stats, void* stream) {
     if (!x || !stats || rows < 0 || C < 64 || C > 1024 || (C % 8) != 0) return PPN_E_INVALID;
     if (rows == 0) return PPN_OK;

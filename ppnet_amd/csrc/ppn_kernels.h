@@ -152,6 +152,10 @@ int nat_gemm128_launch(const void* a, const void* w, const float* bias, const fl
 int nat_gemm_launch(const void* a, const void* w, const float* bias, const float* colsum, const float* stats_in, int p_in,
                     float* stats_out, void* c, long long M, int N, int K, int mode, float eps, hipStream_t stream);
 int row_stats_launch(const void* x, long long rows, int C, float* stats, hipStream_t stream);
+// nat_mlp.hip: the fused MLP of a NAT layer (LN -> fc1 -> GELU -> fc2 -> residual, hidden activation never leaves the CU)
+bool nat_mlp_supported(long long M, int C, int HID);
+int nat_mlp_pack_launch(const void* w1, const void* w2, void* wpk, int C, int HID, hipStream_t stream);
+int nat_mlp_launch(void* s, const void* wpk, const float* hb, const float* b2, float* stats_out, long long M, int C, int HID, float eps, hipStream_t stream);
 int gemm_mfma_launch(const void* a, const void* w, const float* bias, void* c, long long M, int N, int K, int epi, int persistent,
                      hipStream_t stream);
 

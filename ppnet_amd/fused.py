@@ -409,6 +409,39 @@ def nat_gemm(a, w, bias32, mode, out, colsum=None, stats_in=None, stats_out=None
     return out
 
 
+def nat_mlp_ok(M, C, hidden):
+    """Shapes the fused MLP kernel serves (ppn_nat_mlp_supported): C = 256 streams, whole 128-token blocks."""
+    return bool(L.lib.ppn_nat_mlp_supported(int(M), int(C), int(hidden)))
+
+
+def nat_mlp_pack(w1_folded, w2):
+    """The two MLP weights in the fused kernel's streaming order (ppn_nat_mlp_pack_bf16): w1_folded [hidden, C] = W1 diag(gamma)
+    (LayerNorm folded in), w2 [C, hidden] (LayerScale folded in), both bfloat16 -> one bfloat16 tensor of 2 * C * hidden."""
+    hid, Cc = w1_folded.shape
+    assert w1_folded.is_cuda and w1_folded.dtype == w2.dtype == torch.bfloat16 and tuple(w2.shape) == (Cc, hid)
+    w1_folded, w2 = w1_folded.contiguous(), w2.contiguous()
+    out = torch.empty(2 * Cc * hid, dtype=torch.bfloat16, device=w1_folded.device)
+    with torch.cuda.device(out.device):
+        rc = L.lib.ppn_nat_mlp_pack_bf16(_p(w1_folded), _p(w2), _p(out), Cc, hid, ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream))
+    L.check(rc, "ppn_nat_mlp_pack_bf16")
+    return out
+
+
+def nat_mlp_(s2d, wpk, hb, b2, hidden, stats_out=None, eps=1e-5):
+    """s += gelu(LN(s) W1^T + b1) W2^T + b2 in place on the residual stream s2d [M, C] (bfloat16) in ONE kernel — the hidden
+    activation never reaches HBM (ppn_nat_mlp_bf16, csrc/nat_mlp.hip).  wpk from nat_mlp_pack; hb [hidden, 2] float32 =
+    (colsum of the folded w1 rows, b1 + W1 beta); b2 [C] float32; stats_out [C / 128, M, 2] receives the row partials of the new s."""
+    M, Cc = s2d.shape
+    assert s2d.is_cuda and s2d.dtype == torch.bfloat16 and s2d.is_contiguous() and wpk.dtype == torch.bfloat16 and wpk.numel() == 2 * Cc * hidden
+    assert hb.dtype == torch.float32 and hb.is_contiguous() and tuple(hb.shape) == (hidden, 2) and b2.dtype == torch.float32 and b2.numel() == Cc
+    assert stats_out is None or (stats_out.dtype == torch.float32 and stats_out.is_contiguous() and tuple(stats_out.shape) == (Cc // 128, M, 2))
+    with torch.cuda.device(s2d.device):
+        rc = L.lib.ppn_nat_mlp_bf16(_p(s2d), _p(wpk), _p(hb), _p(b2), _p(stats_out), M, Cc, hidden, float(eps),
+                                    ctypes.c_void_p(torch.cuda.current_stream(s2d.device).cuda_stream))
+    L.check(rc, "ppn_nat_mlp_bf16")
+    return s2d
+
+
 def nat_partials(C):
     """Row-statistics partials per row of a residual stream of width C (ppn_nat_gemm_partials: one per 128 columns on the small-tile
     kernel that serves C <= 512, one per 256 on the persistent one)."""

@@ -228,6 +228,20 @@ class NATLayer(nn.Module):
         return self._ln_packs.get((q.weight, q.bias, f1.weight, f1.bias, pj.weight, pj.bias, f2.weight, f2.bias, n1.weight, n1.bias,
                                    n2.weight, n2.bias), build)
 
+    _mlp_packs = None
+
+    def mlp_packs(self):
+        """What ppn_nat_mlp_bf16 reads for this (folded) layer's MLP: (packed weights, hb [hidden, 2] = (colsum, folded bias),
+        b2) — built from ln_packs() on the device, rebuilt when a parameter changes."""
+        if self._mlp_packs is None:
+            self._mlp_packs = fused.WeightCache()
+        f1, f2, n2 = self.mlp.fc1, self.mlp.fc2, self.norm2
+
+        def build():
+            _, _, _, w1, b1, cs1, _, _, w2, b2 = self.ln_packs()
+            return fused.nat_mlp_pack(w1, w2), torch.stack([cs1, b1], dim=1).contiguous(), b2
+        return self._mlp_packs.get((f1.weight, f1.bias, f2.weight, f2.bias, n2.weight, n2.bias), build)
+
     def _streams_c128(self, s):
         return (s.shape[-1] == 128 and s.is_cuda and s.dtype == torch.bfloat16 and (s.numel() // 128) % 16 == 0
                 and self.mlp.fc1.out_features == 256 and isinstance(self.mlp.act, nn.GELU) and self.mlp.act.approximate == "none"
@@ -332,15 +346,21 @@ class NATBlock(nn.Module):
         P = fused.nat_partials(C)
         st_mid = torch.empty(P, M, 2, dtype=torch.float32, device=x.device)
         st_out = torch.empty(P, M, 2, dtype=torch.float32, device=x.device)
+        fused_mlp = (P == C // 128 and fused.nat_mlp_ok(M, C, self.blocks[0].mlp.fc1.out_features) and not os.environ.get("PPNET_NO_FUSED_MLP"))
         for blk in self.blocks:
             wq, bq, csq, w1, b1, cs1, wp, bp, w2, b2 = blk.ln_packs()
             qkv = torch.empty(B, H, W, 3 * C, dtype=x.dtype, device=x.device)
             fused.nat_gemm(s2, wq, bq, "ln", qkv.view(M, 3 * C), colsum=csq, stats_in=st, eps=blk.norm1.eps)
             a = blk.attn.attend(x, qkv=qkv)
             fused.nat_gemm(a.view(M, C), wp, bp, "acc", s2, stats_out=st_mid)
-            h = torch.empty(M, w1.shape[0], dtype=x.dtype, device=x.device)
-            fused.nat_gemm(s2, w1, b1, "ln_gelu", h, colsum=cs1, stats_in=st_mid, eps=blk.norm2.eps)
-            fused.nat_gemm(h, w2, b2, "acc", s2, stats_out=st_out)
+            if fused_mlp:
+                # LN -> fc1 -> GELU -> fc2 -> residual as ONE kernel: the hidden activation never reaches HBM (csrc/nat_mlp.hip)
+                wpk, hb, b2v = blk.mlp_packs()
+                fused.nat_mlp_(s2, wpk, hb, b2v, w1.shape[0], stats_out=st_out, eps=blk.norm2.eps)
+            else:
+                h = torch.empty(M, w1.shape[0], dtype=x.dtype, device=x.device)
+                fused.nat_gemm(s2, w1, b1, "ln_gelu", h, colsum=cs1, stats_in=st_mid, eps=blk.norm2.eps)
+                fused.nat_gemm(h, w2, b2, "acc", s2, stats_out=st_out)
             st = st_out
         xo = fused.layer_norm(x, out_norm) if out_norm is not None else x
         return (x, xo) if self.downsample is None else (self.downsample(x), xo)

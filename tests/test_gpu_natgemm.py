@@ -117,3 +117,58 @@ def test_argument_checks():
     L = _lib.lib
     assert L.ppn_nat_gemm_bf16(None, None, None, None, None, 0, None, None, 256, 256, 256, 0, 1e-5, None) == -1
     assert L.ppn_row_stats_bf16(None, 4, 256, None, None) == -1
+
+
+@pytest.mark.parametrize("M,hidden", [(128, 512), (1280, 512), (256, 64), (36864, 512), (128 * 257, 768)])
+def test_fused_mlp_vs_float64(M, hidden):
+    """ppn_nat_mlp_bf16 (csrc/nat_mlp.hip): s += gelu(LN(s) W1^T + b1) W2^T + b2 in one kernel, C = 256, against the float64
+    definition on the same bfloat16 operands (LayerNorm of the bfloat16 rows, the folded bfloat16 W1 the kernel reads, erf-GELU,
+    the hidden activation NOT rounded: the kernel rounds it to bfloat16 between the products, which the tolerance carries).
+    One workgroup pass (M = 128), several row blocks per workgroup and a partial last round (257 blocks on 256 CUs), a hidden width
+    of two chunks; row partials per 128 columns; bit-reproducible."""
+    from ppnet_amd import fused
+    C = 256
+    g = torch.Generator(device="cuda").manual_seed(11)
+    s0 = (torch.randn(M, C, device="cuda", generator=g) * 1.3 + 0.4).to(torch.bfloat16)
+    w1 = (torch.randn(hidden, C, device="cuda", generator=g) * 0.06).to(torch.bfloat16)
+    b1 = torch.randn(hidden, device="cuda", generator=g) * 0.3
+    gamma = 1.0 + 0.2 * torch.randn(C, device="cuda", generator=g)
+    beta = 0.1 * torch.randn(C, device="cuda", generator=g)
+    w2 = (torch.randn(C, hidden, device="cuda", generator=g) * 0.06).to(torch.bfloat16)
+    b2 = (torch.randn(C, device="cuda", generator=g) * 0.3).contiguous()
+    w1f = (w1.float() * gamma).to(torch.bfloat16).contiguous()
+    b1f = b1 + w1.float() @ beta
+    hb = torch.stack([w1f.float().sum(1), b1f], dim=1).contiguous()
+    assert fused.nat_mlp_ok(M, C, hidden) and not fused.nat_mlp_ok(M + 64, C, hidden) and not fused.nat_mlp_ok(M, 512, hidden)
+    wpk = fused.nat_mlp_pack(w1f, w2)
+    assert torch.equal(wpk.float().sort().values, torch.cat([w1f.flatten(), w2.flatten()]).float().sort().values)   # a permutation of the weights
+    s = s0.clone()
+    st = torch.full((2, M, 2), float("nan"), dtype=torch.float32, device="cuda")
+    fused.nat_mlp_(s, wpk, hb, b2, hidden, stats_out=st, eps=1e-5)
+    sd = s0.double()
+    xn = torch.nn.functional.layer_norm(sd, (C,), None, None, 1e-5)
+    h = torch.nn.functional.gelu(xn @ w1f.double().t() + b1f.double())
+    ref = sd + h @ w2.double().t() + b2.double()
+    err = (s.double() - ref).abs()
+    # one bf16 rounding of the result, one of every hidden value (2^-9 relative each, sqrt(hidden) of them at |w2| ~ 0.06), float32 sums
+    tol = 2.0 ** -8 * ref.abs() + 2.0 ** -8 * 0.06 * (h.abs().pow(2).sum(1, keepdim=True).sqrt()) + 6e-3
+    assert bool((err <= tol).all()), float((err - tol).max())
+    assert float(err.mean()) < 3e-3 * float(ref.abs().mean() + 0.05)
+    # the second output: (sum, sum of squares) of the stored rows per 128 columns
+    so = s.double().view(M, 2, 128)
+    assert torch.allclose(st[:, :, 0].double().t(), so.sum(2), rtol=1e-5, atol=2e-3)
+    assert torch.allclose(st[:, :, 1].double().t(), (so * so).sum(2), rtol=1e-5, atol=2e-3)
+    # against the two-kernel form it replaces (same folded operands, hidden activation through HBM)
+    s_two = s0.clone()
+    hbuf = torch.empty(M, hidden, dtype=torch.bfloat16, device="cuda")
+    if M % 256 == 0 and hidden % 256 == 0:
+        fused.nat_gemm(s_two, w1f, b1f.contiguous(), "ln_gelu", hbuf, colsum=hb[:, 0].contiguous(), stats_in=fused.row_stats(s_two), eps=1e-5)
+        st2 = torch.empty(fused.nat_partials(C), M, 2, dtype=torch.float32, device="cuda")
+        fused.nat_gemm(hbuf, w2, b2, "acc", s_two, stats_out=st2)
+        d = (s.double() - s_two.double()).abs()
+        assert bool((d <= 2.0 ** -7 * ref.abs() + 8e-3).all())
+    s3 = s0.clone()
+    st3 = torch.empty_like(st)
+    fused.nat_mlp_(s3, wpk, hb, b2, hidden, stats_out=st3, eps=1e-5)
+    assert torch.equal(s, s3) and torch.equal(st, st3)          # no atomics: bit-reproducible
+    fused.nat_mlp_(s3, wpk, hb, b2, hidden, stats_out=None)      # the statistics are optional
