@@ -42,6 +42,7 @@ namespace nmlp {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 constexpr int NTHR = 512, NWAVE = 8, TOK = 32;      // 4 pairs of waves x 32 tokens = 128 rows per workgroup pass
 constexpr int HC = 32;                              // hidden units per chunk (two 16-row MFMA tiles = one stage-2 k-step)
@@ -70,8 +71,12 @@ struct Params {
     float eps, inv_c;
 };
 
-__device__ __forceinline__ void glds16(const void* g, unsigned char* lds_uniform) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
+// LDS-DMA of 16 bytes per lane, base + off -> lds_uniform + 16 * lane, as assembly on purpose (na2d_halo16.hip): behind a
+// __builtin_amdgcn_global_load_lds the compiler cannot tell which LDS bytes are in flight and puts `s_waitcnt vmcnt(0)` in front of
+// the next LDS read — here the first read of every chunk iteration, i.e. a full memory round trip per chunk (measured: 2 us per
+// chunk, the whole kernel).  What it does not see it does not wait for; the kernel's own counted waits order the ring.
+__device__ __forceinline__ void dma16(const void* base_uniform, unsigned off, unsigned lds_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base_uniform), "s"(lds_uniform) : "memory");
 }
 // erf-GELU through a logistic fit of erf (nat_gemm.hip: |error| < 3e-5), one v_exp + one v_rcp
 __device__ __forceinline__ float gelu_logistic(float x) {
@@ -81,6 +86,7 @@ __device__ __forceinline__ float gelu_logistic(float x) {
 }
 // LDS reads through the fragment type: hipcc drains the LDS-DMA queue (vmcnt(0)) in front of float4-typed LDS reads
 __device__ __forceinline__ f32x4 lds_f4(const void* ptr) { return __builtin_bit_cast(f32x4, *reinterpret_cast<const bf16x8*>(ptr)); }
+__device__ __forceinline__ uint2 lds_u2(const void* ptr) { return __builtin_bit_cast(uint2, *reinterpret_cast<const bf16x4*>(ptr)); }
 __device__ __forceinline__ bf16x8 frag(const unsigned char* slot, int f, int lane) {
     return *reinterpret_cast<const bf16x8*>(slot + f * 1024 + lane * 16);
 }
@@ -113,12 +119,14 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
     const int total = my_blocks * p.NCH;                               // chunks this workgroup walks
 
     // this wave's share of a chunk's DMA: fragments [wave * DMA_PER_WAVE, +DMA_PER_WAVE)
-    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.wpk) + (size_t)wave * G::DMA_PER_WAVE * 1024 + lane * 16;
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.wpk) + (size_t)wave * G::DMA_PER_WAVE * 1024;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned loff = (unsigned)lane * 16;
     auto dma = [&](int j, int slot) __attribute__((always_inline)) {
         const unsigned char* src = wsrc + (size_t)j * CHUNK;
-        unsigned char* dst = ring + slot * CHUNK + wave * G::DMA_PER_WAVE * 1024;
+        const unsigned dst = lds0 + slot * CHUNK + wave * G::DMA_PER_WAVE * 1024;
 #pragma unroll
-        for (int f = 0; f < G::DMA_PER_WAVE; ++f) glds16(src + f * 1024, dst + f * 1024);
+        for (int f = 0; f < G::DMA_PER_WAVE; ++f) dma16(src + f * 1024, loff, dst + f * 1024);
     };
     int jn = 0;                                                        // chunk index of the next DMA (t + 2 in steady state)
     dma(jn, 0);
@@ -201,39 +209,43 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
             const bool first = (j == 0);
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                const uint2 o = *reinterpret_cast<const uint2*>(x_par + par_prev + tt * 64 * 8);
+                const uint2 o = lds_u2(x_par + par_prev + tt * 64 * 8);
                 uint4 v = hw ? make_uint4(o.x, o.y, hown[tt].x, hown[tt].y) : make_uint4(hown[tt].x, hown[tt].y, o.x, o.y);
                 if (first) v = make_uint4(0u, 0u, 0u, 0u);
                 hf[tt] = __builtin_bit_cast(bf16x8, v);
             }
             const unsigned char* s2 = first ? cur : prev;
+            // ---- all LDS reads of the iteration are issued before its first MFMA (the latency of a fragment read is ~10 MFMAs: a
+            // read-then-use order leaves the matrix pipe idle most of the time; 16 fragments = 64 registers, which the pair design
+            // has): this wave's stage-1 fragments (hidden tile hw of chunk t), its stage-2 fragments (output tiles of chunk t-1),
+            // (colsum, b1') of this lane's four hidden units 32 j + 16 hw + 4 g + r
+            bf16x8 a1[KS], a2[OTW];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a1[ks] = frag(cur, hw * KS + ks, lane);
+#pragma unroll
+            for (int o = 0; o < OTW; ++o) a2[o] = frag(s2, 2 * KS + OTW * hw + o, lane);
+            const float* hbj = hbl + (size_t)(HC * j + 16 * hw + 4 * g) * 2;
+            const f32x4 c0 = lds_f4(hbj), c1 = lds_f4(hbj + 4);
+            const float cs[4] = {c0[0], c0[2], c1[0], c1[2]}, bs[4] = {c0[1], c0[3], c1[1], c1[3]};
+            __builtin_amdgcn_sched_barrier(0);
             // ---- stage 1: P[tt] = W1'[32 j + 16 hw ..][:] . s^T (this wave's hidden tile)
             f32x4 P[2];
             P[0] = f32x4{0.f, 0.f, 0.f, 0.f}; P[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 a = frag(cur, hw * KS + ks, lane);
-                P[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, sraw[0][ks]), P[0], 0, 0, 0);
-                P[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, sraw[1][ks]), P[1], 0, 0, 0);
-                if (ks & 1) __builtin_amdgcn_sched_barrier(0);          // keep later fragment reads from being hoisted
+                P[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ks], __builtin_bit_cast(bf16x8, sraw[0][ks]), P[0], 0, 0, 0);
+                P[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ks], __builtin_bit_cast(bf16x8, sraw[1][ks]), P[1], 0, 0, 0);
             }
-            // (colsum, b1') of this lane's four hidden units 32 j + 16 hw + 4 g + r
-            const float* hbj = hbl + (size_t)(HC * j + 16 * hw + 4 * g) * 2;
-            const f32x4 c0 = lds_f4(hbj), c1 = lds_f4(hbj + 4);
-            const float cs[4] = {c0[0], c0[2], c1[0], c1[2]}, bs[4] = {c0[1], c0[3], c1[1], c1[3]};
-
             // ---- stage 2 of chunk t-1 (O += W2'[:, chunk] . h) with the GELU of this chunk's P between its MFMAs
             float hv[2][4];
 #pragma unroll
             for (int o = 0; o < OTW; ++o) {
-                const bf16x8 a = frag(s2, 2 * KS + OTW * hw + o, lane);
-                acc[o][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, hf[0], acc[o][0], 0, 0, 0);
-                acc[o][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, hf[1], acc[o][1], 0, 0, 0);
+                acc[o][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[o], hf[0], acc[o][0], 0, 0, 0);
+                acc[o][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[o], hf[1], acc[o][1], 0, 0, 0);
                 {                                                       // value (tt = o >> 2, r = o & 3) of the 8 this lane owns
                     const int tt = o >> 2, r = o & 3;
                     hv[tt][r] = gelu_logistic(fmaf(P[tt][r], rstd[tt], fmaf(nmr[tt], cs[r], bs[r])));
                 }
-                if (o & 1) __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
@@ -252,7 +264,7 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
             bf16x8 hf[2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                const uint2 o = *reinterpret_cast<const uint2*>(x_par + par_prev + tt * 64 * 8);
+                const uint2 o = lds_u2(x_par + par_prev + tt * 64 * 8);
                 const uint4 v = hw ? make_uint4(o.x, o.y, hown[tt].x, hown[tt].y) : make_uint4(hown[tt].x, hown[tt].y, o.x, o.y);
                 hf[tt] = __builtin_bit_cast(bf16x8, v);
             }

@@ -75,7 +75,9 @@ def test_generate_and_plan_chain_equals_separate_calls():
                             {k: v.clone() for k, v in r["result"].items()}))
         torch.cuda.synchronize()
         for (mb0, m0), (g1, sp1, ob1, no1, m1, h1, r1) in zip(want, got):
-            assert torch.equal(mb0.grid, g1) and torch.equal(mb0.segpoint, sp1) and torch.equal(mb0.obstacles, ob1)
+            assert torch.equal(mb0.grid, g1) and torch.equal(mb0.segpoint, sp1) and torch.equal(mb0.n_obstacles, no1)
+            live = torch.arange(ob1.shape[1], device=dev)[None, :] < no1[:, 0:1]      # rows past the count keep whatever the buffer held
+            assert torch.equal(mb0.obstacles[live], ob1[live])
             # SegNet's fused classifier sums its channel tiles with float atomics: the last bit of a logit depends on arrival order
             # (run to run on ONE stream ~1e-5 of the logits differ), so a label may flip where the two classes tie.  The chain's
             # labels equal the separate call's up to that; every later stage is compared on the chain's OWN labels, bit for bit.
