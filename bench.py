@@ -661,7 +661,7 @@ def pick_path_group(warmup, steps):
     return 1
 
 
-DEFAULT_PATH_GROUP_MAX = 1      # measured default, see DESIGN.md section 5
+DEFAULT_PATH_GROUP_MAX = 8      # measured (gpurun_out/r04/group_*.json): 54.2 M instances/s at 1, 54.3 at 4, 54.85 at 8; see DESIGN.md section 5
 
 
 def main():

@@ -519,6 +519,14 @@ class SETRUPHead(nn.Module):
         src = [t for up in self.up_convs for t in (up[0].conv.weight, up[0].conv.bias)] + [cs.weight, cs.bias]
         packs = self._mfma.get(src, lambda: [_mfma_weights(up[0].conv) for up in self.up_convs] +
                                [(cs.weight.detach().float().reshape(cs.out_channels, -1).contiguous(), cs.bias.detach().float().contiguous())])
+        # The convolution kernels address their input with 32-bit byte offsets: the last stage reads [B, channels, H 2^(n-1), W 2^(n-1)]
+        # bfloat16, which passes 4 GiB at batch 256 of 512 x 512 maps.  Larger batches go through the head in slices.
+        B = x.shape[0]
+        last_in = self.up_convs[-1][0].conv.in_channels * x.shape[-2] * x.shape[-1] * 4 ** (len(self.up_convs) - 1) * 2
+        bmax = max(1, (2 ** 32 - 1) // last_in)
+        if B > bmax:
+            step = -(-B // (-(-B // bmax)))                                   # equal slices
+            return torch.cat([self._forward_mfma(x[i:i + step], lowres) for i in range(0, B, step)], dim=0)
         for i, up in enumerate(self.up_convs[:-1]):
             x = up[1](fused.conv3x3_mfma(x, packs[i][0], packs[i][1], stride=1, relu=True))
         w2, b2 = packs[-1]
