@@ -84,6 +84,16 @@ __device__ __forceinline__ float gelu_logistic(float x) {
     const float t = x * (2.3009787f + x2 * (0.10690469f - 1.0350827e-3f * x2));
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-t));
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// two at a time: the multiplies / adds as packed float32 instructions (v_pk_mul_f32, v_pk_fma_f32)
+__device__ __forceinline__ f32x2 gelu_logistic2(f32x2 x) {
+    f32x2 x2 = x * x;
+    x2 = f32x2{fminf(x2.x, 64.0f), fminf(x2.y, 64.0f)};
+    const f32x2 k0 = {2.3009787f, 2.3009787f}, k1 = {0.10690469f, 0.10690469f}, k2 = {-1.0350827e-3f, -1.0350827e-3f}, one = {1.0f, 1.0f};
+    const f32x2 t = x * __builtin_elementwise_fma(x2, __builtin_elementwise_fma(x2, k2, k1), k0);
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(-t.x), __builtin_amdgcn_exp2f(-t.y)} + one;
+    return x * f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
 // LDS reads through the fragment type: hipcc drains the LDS-DMA queue (vmcnt(0)) in front of float4-typed LDS reads
 __device__ __forceinline__ f32x4 lds_f4(const void* ptr) { return __builtin_bit_cast(f32x4, *reinterpret_cast<const bf16x8*>(ptr)); }
 __device__ __forceinline__ uint2 lds_u2(const void* ptr) { return __builtin_bit_cast(uint2, *reinterpret_cast<const bf16x4*>(ptr)); }
@@ -101,7 +111,12 @@ __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 
 
 // HW = the wave's half of its pair, a template parameter so that every register index below is a constant (as a run-time value —
 // even a wave-uniform one — the selects between the two halves of sraw keep both alive and spill into the chunk loop)
-template <int C, int HW>
+// ORD = the order of an iteration's phases.  All eight waves meet at one barrier per chunk, so without it they run in lock step:
+// every wave reads its fragments, then every wave is in the matrix pipe, then every wave in the GELU's vector work — the units
+// take turns (measured: 4300 cycles per chunk for 1024 of matrix work per SIMD).  Waves 0-3 (ORD 0) run stage 1 -> GELU ->
+// stage 2, waves 4-7 (ORD 1: the other wave of every SIMD) stage 2 -> stage 1 -> GELU: one wave's vector phase lies beside the
+// other's matrix phase.  The data flow is the same (stage 2 consumes the PREVIOUS chunk's GELU either way).
+template <int C, int HW, int ORD>
 __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds, const int wave) {
     using G = Geo<C>;
     constexpr int KS = G::KS, OTW = G::OT / 2, CHUNK = G::CHUNK;
@@ -215,37 +230,65 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
                 hf[tt] = __builtin_bit_cast(bf16x8, v);
             }
             const unsigned char* s2 = first ? cur : prev;
-            // ---- all LDS reads of the iteration are issued before its first MFMA (the latency of a fragment read is ~10 MFMAs: a
-            // read-then-use order leaves the matrix pipe idle most of the time; 16 fragments = 64 registers, which the pair design
-            // has): this wave's stage-1 fragments (hidden tile hw of chunk t), its stage-2 fragments (output tiles of chunk t-1),
-            // (colsum, b1') of this lane's four hidden units 32 j + 16 hw + 4 g + r
+            // ---- LDS reads are issued a phase ahead of their use (the latency of a fragment read is ~10 MFMAs): this wave's
+            // stage-1 fragments a1 (hidden tile hw of chunk t), its stage-2 fragments a2 (output tiles of chunk t-1), (colsum, b1')
+            // of this lane's four hidden units 32 j + 16 hw + 4 g + r
             bf16x8 a1[KS], a2[OTW];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a1[ks] = frag(cur, hw * KS + ks, lane);
-#pragma unroll
-            for (int o = 0; o < OTW; ++o) a2[o] = frag(s2, 2 * KS + OTW * hw + o, lane);
-            const float* hbj = hbl + (size_t)(HC * j + 16 * hw + 4 * g) * 2;
-            const f32x4 c0 = lds_f4(hbj), c1 = lds_f4(hbj + 4);
-            const float cs[4] = {c0[0], c0[2], c1[0], c1[2]}, bs[4] = {c0[1], c0[3], c1[1], c1[3]};
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- stage 1: P[tt] = W1'[32 j + 16 hw ..][:] . s^T (this wave's hidden tile)
             f32x4 P[2];
-            P[0] = f32x4{0.f, 0.f, 0.f, 0.f}; P[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                P[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ks], __builtin_bit_cast(bf16x8, sraw[0][ks]), P[0], 0, 0, 0);
-                P[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ks], __builtin_bit_cast(bf16x8, sraw[1][ks]), P[1], 0, 0, 0);
-            }
-            // ---- stage 2 of chunk t-1 (O += W2'[:, chunk] . h) with the GELU of this chunk's P between its MFMAs
             float hv[2][4];
+            const float* hbj = hbl + (size_t)(HC * j + 16 * hw + 4 * g) * 2;
+            auto read_a1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int o = 0; o < OTW; ++o) {
-                acc[o][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[o], hf[0], acc[o][0], 0, 0, 0);
-                acc[o][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[o], hf[1], acc[o][1], 0, 0, 0);
-                {                                                       // value (tt = o >> 2, r = o & 3) of the 8 this lane owns
-                    const int tt = o >> 2, r = o & 3;
-                    hv[tt][r] = gelu_logistic(fmaf(P[tt][r], rstd[tt], fmaf(nmr[tt], cs[r], bs[r])));
+                for (int ks = 0; ks < KS; ++ks) a1[ks] = frag(cur, hw * KS + ks, lane);
+            };
+            auto read_a2 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                for (int o = 0; o < OTW; ++o) a2[o] = frag(s2, 2 * KS + OTW * hw + o, lane);
+            };
+            auto stage1 = [&]() __attribute__((always_inline)) {           // P[tt] = W1'[32 j + 16 hw ..][:] . s^T
+                P[0] = f32x4{0.f, 0.f, 0.f, 0.f}; P[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    P[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ks], __builtin_bit_cast(bf16x8, sraw[0][ks]), P[0], 0, 0, 0);
+                    P[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ks], __builtin_bit_cast(bf16x8, sraw[1][ks]), P[1], 0, 0, 0);
                 }
+            };
+            auto stage2 = [&]() __attribute__((always_inline)) {           // O += W2'[:, chunk t-1] . h
+#pragma unroll
+                for (int o = 0; o < OTW; ++o) {
+                    acc[o][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[o], hf[0], acc[o][0], 0, 0, 0);
+                    acc[o][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[o], hf[1], acc[o][1], 0, 0, 0);
+                }
+            };
+            auto gelu = [&]() __attribute__((always_inline)) {             // the 8 values this lane owns, two per instruction
+                const f32x4 c0 = lds_f4(hbj), c1 = lds_f4(hbj + 4);       // (cs, b1') of hidden units r = 0, 1 | 2, 3
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const f32x2 rs = {rstd[tt], rstd[tt]}, nm = {nmr[tt], nmr[tt]};
+                    const f32x2 v01 = __builtin_elementwise_fma(f32x2{P[tt][0], P[tt][1]}, rs, __builtin_elementwise_fma(nm, f32x2{c0[0], c0[2]}, f32x2{c0[1], c0[3]}));
+                    const f32x2 v23 = __builtin_elementwise_fma(f32x2{P[tt][2], P[tt][3]}, rs, __builtin_elementwise_fma(nm, f32x2{c1[0], c1[2]}, f32x2{c1[1], c1[3]}));
+                    const f32x2 g01 = gelu_logistic2(v01), g23 = gelu_logistic2(v23);
+                    hv[tt][0] = g01.x; hv[tt][1] = g01.y; hv[tt][2] = g23.x; hv[tt][3] = g23.y;
+                }
+            };
+            if constexpr (ORD == 0) {
+                read_a1();
+                __builtin_amdgcn_sched_barrier(0);
+                stage1();
+                read_a2();
+                __builtin_amdgcn_sched_barrier(0);
+                gelu();
+                __builtin_amdgcn_sched_barrier(0);
+                stage2();
+            } else {
+                read_a2();
+                __builtin_amdgcn_sched_barrier(0);
+                stage2();
+                read_a1();
+                __builtin_amdgcn_sched_barrier(0);
+                stage1();
+                __builtin_amdgcn_sched_barrier(0);
+                gelu();
             }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
@@ -320,8 +363,13 @@ __global__ __launch_bounds__(NTHR, 2) void nat_mlp_kernel(Params p) {
     for (int i = threadIdx.x; i < C; i += NTHR) b2l[i] = p.b2[i];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: the branch below is a scalar branch
-    if (wave & 1) nat_mlp_body<C, 1>(p, lds, wave);
-    else nat_mlp_body<C, 0>(p, lds, wave);
+    if (wave & 4) {
+        if (wave & 1) nat_mlp_body<C, 1, 1>(p, lds, wave);
+        else nat_mlp_body<C, 0, 1>(p, lds, wave);
+    } else {
+        if (wave & 1) nat_mlp_body<C, 1, 0>(p, lds, wave);
+        else nat_mlp_body<C, 0, 0>(p, lds, wave);
+    }
 }
 
 }  // namespace nmlp
