@@ -37,6 +37,16 @@
 #include "ppn_kernels.h"
 #pragma clang fp contract(fast)      // network arithmetic checked to a tolerance (see nat_c128.hip)
 
+#ifndef NMLP_TRACE
+#define NMLP_TRACE 0      // diagnostic build: s_memtime stamps of workgroup 0's waves into the stats buffer (tools/mlp_trace.py)
+#endif
+#ifndef NMLP_STAGGER
+#define NMLP_STAGGER 0
+#endif
+#ifndef NMLP_ABL
+#define NMLP_ABL 0        // diagnostic builds (tools/r04_mlp_abl.sh): bit 0 no ring DMA after the prologue, 1 no GELU, 2 no per-chunk
+#endif                    // barrier, 3 no stage-2 MFMAs, 4 no stage-1 MFMAs, 5 no fragment reads.  Never shipped.
+
 namespace ppn {
 namespace nmlp {
 
@@ -116,10 +126,16 @@ __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 
 // take turns (measured: 4300 cycles per chunk for 1024 of matrix work per SIMD).  Waves 0-3 (ORD 0) run stage 1 -> GELU ->
 // stage 2, waves 4-7 (ORD 1: the other wave of every SIMD) stage 2 -> stage 1 -> GELU: one wave's vector phase lies beside the
 // other's matrix phase.  The data flow is the same (stage 2 consumes the PREVIOUS chunk's GELU either way).
+#if NMLP_TRACE
+#define NMLP_T(slot) do { if (blockIdx.x == 0 && lane == 0 && tr_n < 4096) { tr[tr_n * 2] = __builtin_readcyclecounter(); tr[tr_n * 2 + 1] = (slot); ++tr_n; } } while (0)
+#else
+#define NMLP_T(slot) do { } while (0)
+#endif
 template <int C, int HW, int ORD>
 __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds, const int wave) {
     using G = Geo<C>;
     constexpr int KS = G::KS, OTW = G::OT / 2, CHUNK = G::CHUNK;
+    constexpr int EPI_STORES = 2 * (2 * 2 + 1);                        // vector-memory instructions of a row block's epilogue
     constexpr int hw = HW;
     unsigned char* ring = lds;
     unsigned char* xch = lds + NS * CHUNK;
@@ -127,6 +143,10 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
     float* b2l = hbl + 2 * HC * p.NCH;                                 // [C]
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int pair = wave >> 1;                                        // the pair's 32 tokens
+#if NMLP_TRACE
+    unsigned long long* tr = reinterpret_cast<unsigned long long*>(p.stats_out) + (size_t)wave * 8192;
+    int tr_n = 0;
+#endif
 
     const int nblk = p.M / ROWS;
     const int my_blocks = ((int)blockIdx.x < nblk) ? (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
@@ -166,7 +186,12 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
     int t = 0;
     for (int b = 0; b < my_blocks; ++b) {
         const int blk = blockIdx.x + b * gridDim.x;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this block's rows (and whatever DMA was in flight)
+        // this block's rows have landed (and every DMA issued before them); the previous block's stores — issued after the row
+        // prefetch — stay in flight: 4 row stores + 1 statistics store per token tile
+        NMLP_T(1);
+        if (b == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(EPI_STORES) : "memory");
+        NMLP_T(2);
         // ---- LayerNorm statistics of the raw rows (over all C channels: 4 lanes per token)
         float rstd[2], nmr[2];
 #pragma unroll
@@ -202,16 +227,23 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
             }
         }
 
+        NMLP_T(3);
         uint2 hown[2];                                                 // this wave's half of GELU(P) of the previous chunk, per token tile
         hown[0] = make_uint2(0u, 0u); hown[1] = make_uint2(0u, 0u);
 #pragma unroll 1
         for (int j = 0; j < p.NCH; ++j, ++t) {
             // chunk t has landed (this wave's share), everyone is done with iteration t-1 (the slot of chunk t-2 may be refilled, the
             // halves of GELU(P) of chunk t-1 are in the exchange buffer)
-            if (t + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G::DMA_PER_WAVE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (t + 2 < total) { dma(jn, (t + 2) & (NS - 1)); jn = (jn + 1 == p.NCH) ? 0 : jn + 1; }
+            // (the first two chunks of a row block landed before the block's rows did — vector memory retires in order — and behind
+            // them only the previous block's stores may still be in flight, which nobody here waits for)
+            if (j >= 2) {
+                if (t + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G::DMA_PER_WAVE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            NMLP_T(10);
+            if (!(NMLP_ABL & 4)) __builtin_amdgcn_s_barrier();
+            NMLP_T(11);
+            if (!(NMLP_ABL & 1) && t + 2 < total) { dma(jn, (t + 2) & (NS - 1)); jn = (jn + 1 == p.NCH) ? 0 : jn + 1; }
             const unsigned char* cur = ring + (t & (NS - 1)) * CHUNK;
             const unsigned char* prev = ring + ((t - 1) & (NS - 1)) * CHUNK;
             const int par_prev = ((t - 1) & 1) * XPAR, par_cur = (t & 1) * XPAR;
@@ -239,16 +271,23 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
             const float* hbj = hbl + (size_t)(HC * j + 16 * hw + 4 * g) * 2;
             auto read_a1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) a1[ks] = frag(cur, hw * KS + ks, lane);
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (NMLP_ABL & 32) { a1[ks] = __builtin_bit_cast(bf16x8, sraw[0][ks]); asm volatile("" : "+v"(a1[ks])); }
+                    else a1[ks] = frag(cur, hw * KS + ks, lane);
+                }
             };
             auto read_a2 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-                for (int o = 0; o < OTW; ++o) a2[o] = frag(s2, 2 * KS + OTW * hw + o, lane);
+                for (int o = 0; o < OTW; ++o) {
+                    if (NMLP_ABL & 32) { a2[o] = __builtin_bit_cast(bf16x8, sraw[1][o]); asm volatile("" : "+v"(a2[o])); }
+                    else a2[o] = frag(s2, 2 * KS + OTW * hw + o, lane);
+                }
             };
             auto stage1 = [&]() __attribute__((always_inline)) {           // P[tt] = W1'[32 j + 16 hw ..][:] . s^T
                 P[0] = f32x4{0.f, 0.f, 0.f, 0.f}; P[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
+                    if (NMLP_ABL & 16) { asm volatile("" :: "v"(a1[ks])); continue; }
                     P[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ks], __builtin_bit_cast(bf16x8, sraw[0][ks]), P[0], 0, 0, 0);
                     P[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ks], __builtin_bit_cast(bf16x8, sraw[1][ks]), P[1], 0, 0, 0);
                 }
@@ -256,6 +295,7 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
             auto stage2 = [&]() __attribute__((always_inline)) {           // O += W2'[:, chunk t-1] . h
 #pragma unroll
                 for (int o = 0; o < OTW; ++o) {
+                    if (NMLP_ABL & 8) { asm volatile("" :: "v"(a2[o]), "v"(hf[0]), "v"(hf[1])); continue; }
                     acc[o][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[o], hf[0], acc[o][0], 0, 0, 0);
                     acc[o][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[o], hf[1], acc[o][1], 0, 0, 0);
                 }
@@ -267,7 +307,7 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
                     const f32x2 rs = {rstd[tt], rstd[tt]}, nm = {nmr[tt], nmr[tt]};
                     const f32x2 v01 = __builtin_elementwise_fma(f32x2{P[tt][0], P[tt][1]}, rs, __builtin_elementwise_fma(nm, f32x2{c0[0], c0[2]}, f32x2{c0[1], c0[3]}));
                     const f32x2 v23 = __builtin_elementwise_fma(f32x2{P[tt][2], P[tt][3]}, rs, __builtin_elementwise_fma(nm, f32x2{c1[0], c1[2]}, f32x2{c1[1], c1[3]}));
-                    const f32x2 g01 = gelu_logistic2(v01), g23 = gelu_logistic2(v23);
+                    const f32x2 g01 = (NMLP_ABL & 2) ? v01 : gelu_logistic2(v01), g23 = (NMLP_ABL & 2) ? v23 : gelu_logistic2(v23);
                     hv[tt][0] = g01.x; hv[tt][1] = g01.y; hv[tt][2] = g23.x; hv[tt][3] = g23.y;
                 }
             };
@@ -296,6 +336,7 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
                 *reinterpret_cast<uint2*>(x_own + par_cur + tt * 64 * 8) = hown[tt];
             }
         }
+        NMLP_T(4);
         // the rows are dead as an operand: the next block's ride in behind the last stage 2
         if (b + 1 < my_blocks) load_rows(blk + gridDim.x);
         {
@@ -319,6 +360,7 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
                 if (o & 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        NMLP_T(5);
         // ---- epilogue: 32-byte stores (a token's four lanes write 128 contiguous bytes per q), row statistics of this wave's 128 columns
         __bf16* orow = p.s + ((size_t)blk * ROWS + pair * TOK + n) * C + 128 * hw + 16 * g;
 #pragma unroll
@@ -343,14 +385,24 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
                 dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
                 dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
             }
-            if (p.stats_out) {
+            {
+                // (always one store instruction per token tile, so that the counted wait above is exact: without stats_out the
+                // lanes are masked off and the instruction retires at once)
                 sx += __shfl_xor(sx, 16, 64); sq += __shfl_xor(sq, 16, 64);
                 sx += __shfl_xor(sx, 32, 64); sq += __shfl_xor(sq, 32, 64);
-                if (g == 0)
-                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)hw * p.M + (size_t)blk * ROWS + pair * TOK + tt * 16 + n) * 2) = make_float2(sx, sq);
+                float* sp = p.stats_out ? p.stats_out + ((size_t)hw * p.M + (size_t)blk * ROWS + pair * TOK + tt * 16 + n) * 2 : nullptr;
+#if !NMLP_TRACE
+                if (g == 0 && sp) *reinterpret_cast<float2*>(sp) = make_float2(sx, sq);
+#else
+                asm volatile("" :: "v"(sx), "v"(sq), "v"(sp));
+#endif
             }
         }
+        NMLP_T(6);
     }
+#if NMLP_TRACE
+    if (blockIdx.x == 0 && lane == 0) { tr[tr_n * 2] = 0; tr[tr_n * 2 + 1] = 0; }
+#endif
 }
 
 template <int C>
@@ -363,6 +415,11 @@ __global__ __launch_bounds__(NTHR, 2) void nat_mlp_kernel(Params p) {
     for (int i = threadIdx.x; i < C; i += NTHR) b2l[i] = p.b2[i];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: the branch below is a scalar branch
+#if NMLP_STAGGER
+    // Workgroups start together and do identical work, so their row-block boundaries (a burst of row loads and stores, ~50 MB
+    // over the chip, then nothing for 16 chunks) coincide: spread the starts over ~NMLP_STAGGER us so that the bursts interleave
+    for (int k = 0; k < (int)((blockIdx.x >> 3) & 7) * NMLP_STAGGER; ++k) __builtin_amdgcn_s_sleep(32);     // ~32 x 64 cycles ~ 1 us
+#endif
     if (wave & 4) {
         if (wave & 1) nat_mlp_body<C, 1, 1>(p, lds, wave);
         else nat_mlp_body<C, 0, 1>(p, lds, wave);
