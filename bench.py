@@ -717,7 +717,13 @@ def main():
     GROUP = pick_path_group(args.warmup, args.steps)
     if GROUP > 1 and (args.warmup % GROUP or args.steps % GROUP):
         raise SystemExit(f"BENCH_PATH_GROUP={GROUP}: --warmup and --steps must be multiples of it (the timed region must hold whole groups)")
-    TIMED_EVERY = 2 if args.steps < 80 else (4 if args.steps < 800 else 8)   # every 2nd / 4th / 8th launch carries a start marker: >= 10 launches averaged from --steps 20 on
+    # The roofline's kernel duration is sampled over whole GROUPS of launches: a start marker in front of a group's first stage-B
+    # launch, the group's closing event (the path-buffer release, there anyway) as the end, elapsed / GROUP per launch — a marker
+    # around a single launch of a marker-free run would add its own ~5 us to that launch alone.  Every SAMPLE_EVERY-th group: at
+    # least 10 launches from --steps 20 on, 500 at the default window.  (GROUP = 1: an event pair around every 2nd / 4th launch.)
+    n_groups = max(1, args.steps // GROUP)
+    SAMPLE_EVERY = max(1, (n_groups * GROUP) // 500) if GROUP > 1 else (2 if args.steps < 80 else 4)
+    TIMED_EVERY = SAMPLE_EVERY                    # (stage A's sampled launches use the same stride, in groups)
     NPB = DEPTH + 1
     pbs = [edage.PathsBatch(PATHS * GROUP, R, MAP_SIZE, CLEARANCE, dev) for _ in range(NPB)]
     pviews = [[pb.view(k * PATHS, PATHS) for k in range(GROUP)] for pb in pbs]
@@ -790,8 +796,9 @@ def main():
         # every event is a marker packet the queue has to drain before the next kernel starts (~5 us each on this
         # runtime), so the stream carries one per step (it doubles as the buffer hand-off) and a start marker only on
         # every TIMED_EVERY-th step: those launches are the sample the roofline's kernel duration is averaged over
+        sampled = (grp % SAMPLE_EVERY == 0) or args.steps < SAMPLE_EVERY * GROUP
         ev0 = None
-        if it % TIMED_EVERY == 0 or args.steps < TIMED_EVERY:
+        if sampled and sub == 0:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record()
         target = mb
@@ -800,8 +807,8 @@ def main():
             target = mviews[ring.slot][ring.k]
         edage.generate_maps(pviews[b][sub], PLACEMENTS, OBST_SIZE, K, seed=SEED, first_map_id=first_map, out=target)
         ev1 = None
-        if ev0 is not None or sub == GROUP - 1 or os.environ.get("BENCH_TIMED_HANDOFF"):
-            ev1 = torch.cuda.Event(enable_timing=ev0 is not None or bool(os.environ.get("BENCH_TIMED_HANDOFF")))   # a timestamp only on the sampled launches
+        if sub == GROUP - 1:
+            ev1 = torch.cuda.Event(enable_timing=sampled)      # a timestamp only on the sampled groups
             ev1.record()
         if sub == GROUP - 1:
             consumed[b] = ev1                     # the last step of the group releases the path buffer
@@ -851,8 +858,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    timed = [(a, b) for a, b in evs if a is not None]
-    maps_kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / len(timed)
+    starts = [a for a, _ in evs if a is not None]
+    ends = [evs[i + GROUP - 1][1] for i, (a, _) in enumerate(evs) if a is not None]
+    timed = list(zip(starts, ends))
+    maps_kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / (len(timed) * GROUP)
     stage_a_ms = sum(a.elapsed_time(b) for a, b in stage_a_evs) / len(stage_a_evs) if stage_a_evs else None
     k_tot = float(mb.n_obstacles[:, 0].double().mean().item())
     k_pocket = float(pbs[0].n_obstacles.double().mean().item())
@@ -888,7 +897,7 @@ def main():
                        "rng": "philox4x32-10", "parallelism": f"instances sharded over {world} GPU(s), end-of-batch all-gather"},
             "roofline": {"bound": "hbm", "kernel": "edage_maps_kernel_t<3>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(),
-                         "kernel_ms": round(maps_kernel_ms, 4), "timed_launches": len(timed), "units_per_launch": n_local,
+                         "kernel_ms": round(maps_kernel_ms, 4), "timed_launches": len(timed) * GROUP, "units_per_launch": n_local,
                          "algorithmic_bytes_per_map": round(algorithmic_bytes_per_map(k_tot, k_pocket), 1),
                          "survey_bytes_per_map": round(2 * R * R + 16384 + 12.0 * k_tot, 1)},
             # stage A paths/s, stage B maps/s (each kernel's own launch time by events on its stream, while

@@ -42,11 +42,25 @@ def _use_mfma_conv(x, conv, narrow=False):
             and conv.weight.dtype == torch.bfloat16 and not os.environ.get("PPNET_LIBRARY_CONV"))
 
 
+# Per-shape gate between the build's GEMMs and the vendor library behind LayerNorm kernels: stream widths C with
+# C >= LIBRARY_GEMM_FROM_C or C < LIBRARY_GEMM_BELOW_C take the library.  Defaults from the alternating A/B of tools/ppnet_ab.py
+# (DESIGN.md section 4); PPNET_LIBRARY_GEMM_FROM_C / PPNET_LIBRARY_GEMM_BELOW_C override, PPNET_LIBRARY_GEMM=1 = the library everywhere.
+LIBRARY_GEMM_FROM_C = 512
+LIBRARY_GEMM_BELOW_C = 0
+
+
+def _library_width(C):
+    if os.environ.get("PPNET_LIBRARY_GEMM"):
+        return True
+    return (C >= int(os.environ.get("PPNET_LIBRARY_GEMM_FROM_C", LIBRARY_GEMM_FROM_C))
+            or C < int(os.environ.get("PPNET_LIBRARY_GEMM_BELOW_C", LIBRARY_GEMM_BELOW_C)))
+
+
 def _own_gemm_ok(x2, lin):
     """The build's own MFMA GEMM (ppn_gemm_bf16) serves bfloat16 inference with K % 64 == 0, K >= 128, N % 8 == 0."""
     K, N = lin.in_features, lin.out_features
     return (x2.is_cuda and x2.dtype == torch.bfloat16 and lin.weight.dtype == torch.bfloat16 and K % 64 == 0 and K >= 128 and N % 8 == 0
-            and x2.is_contiguous() and not fused.recording(x2, lin.weight) and not os.environ.get("PPNET_LIBRARY_GEMM"))
+            and x2.is_contiguous() and not fused.recording(x2, lin.weight) and not _library_width(min(K, N)))
 
 
 def _bias32(lin):
@@ -326,7 +340,7 @@ class NATBlock(nn.Module):
         C = x.shape[-1]
         return (b0.folded and x.is_cuda and x.dtype == torch.bfloat16 and b0.attn.qkv.weight.dtype == torch.bfloat16 and C % 256 == 0
                 and (x.numel() // C) % 256 == 0 and (x.numel() // C // 256) * (C // 256) >= int(os.environ.get("PPNET_SMALL_GEMM_TILES", "64")) and b0.mlp.fc1.out_features % 256 == 0 and b0.mlp._erf_gelu() and x.is_contiguous()
-                and not torch.is_grad_enabled() and not os.environ.get("PPNET_LIBRARY_GEMM") and not os.environ.get("PPNET_NO_LN_FOLD"))
+                and not torch.is_grad_enabled() and not _library_width(C) and not os.environ.get("PPNET_NO_LN_FOLD"))
 
     def _forward_ln_folded(self, x, out_norm):
         """The level with the dense half of every layer on the build's own persistent GEMMs (reference SegNet/nat.py:140-153): per
