@@ -337,12 +337,15 @@ int ppn_conv3x3_to1_nhwc(const void* x, const float* w, float bias, void* y, int
  * stride-2 convolution of NAT's ConvDownsampler (SegNet/nat.py:48-59). */
 int ppn_conv3x3_mfma_bf16(const void* x, const void* w, const float* bias, void* y, int32_t B, int32_t H, int32_t W, int32_t Cin,
                           int32_t Cout, int32_t stride, int32_t relu, void* stream);
-/* The head's last stage in one kernel (setr_up_head.py:78-80 with the 1x1 classifier commuted in front of the last
- * up-sampling): logits[m][c] += sum_n max(conv(x, w)[m][n] + bias[n], 0) * w2[c][n] for the B*H*W pixels m and c = 0, 1.
- * logits [B*H*W][2] float32 must hold the classifier's bias on entry; w2 [2][Cout] float32.  The 512-channel activation is
- * never written. */
-int ppn_conv3x3_relu_classify2_bf16(const void* x, const void* w, const float* bias, const float* w2, float* logits, int32_t B, int32_t H,
-                                    int32_t W, int32_t Cin, int32_t Cout, void* stream);
+/* The head's last stage (setr_up_head.py:78-80 with the 1x1 classifier commuted in front of the last up-sampling):
+ * logits[m][c] += sum_n max(conv(x, w)[m][n] + bias[n], 0) * w2[c][n] for the B*H*W pixels m and c = 0, 1.
+ * logits [B*H*W][2] float32 must hold the classifier's bias on entry; w2 [2][Cout] float32.  The Cout-channel activation is
+ * never written: the convolution kernel leaves one partial sum per pixel, class and 64-column slot in
+ * partial [ppn_conv3x3_relu_classify2_slots(Cout)][B*H*W][2] float32 (caller-owned workspace, every element written), and a
+ * second launch adds the slots to logits in slot order — no atomics: bit-reproducible. */
+int32_t ppn_conv3x3_relu_classify2_slots(int32_t Cout);
+int ppn_conv3x3_relu_classify2_bf16(const void* x, const void* w, const float* bias, const float* w2, float* logits, float* partial, int32_t B,
+                                    int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
 /* GenNet's 24-channel stride-2 stages on MFMA, NHWC bfloat16, BatchNorm folded by the caller, bias + LeakyReLU fused:
  *   transposed == 0 (ae_vit.py:24-36, Conv2d(24, 24, 3, 2, 1)): x [B][H][W][24] -> y [B][H/2][W/2][24];
  *        w [32][224] bfloat16, row co (24..31 zero), column (ky*3+kx)*24 + ci (216..223 zero);

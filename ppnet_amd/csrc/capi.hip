@@ -453,18 +453,20 @@ int ppn_conv3x3_mfma_bf16(const void* x, const void* w, const float* bias, void*
     // 32-bit byte offsets inside the kernel: the image and the weights must stay below 4 GiB
     if ((long long)B * H * W * Cin * 2 >= (1LL << 32) || (long long)Cout * 9 * Cin * 2 >= (1LL << 32) || (long long)B * H * W >= (1LL << 31))
         return PPN_E_UNSUPPORTED;
-    const int e = ppn::conv3x3_mfma_launch(x, w, bias, y, B, H, W, Cin, Cout, stride, relu, nullptr, nullptr, (hipStream_t)stream);
+    const int e = ppn::conv3x3_mfma_launch(x, w, bias, y, B, H, W, Cin, Cout, stride, relu, nullptr, nullptr, nullptr, (hipStream_t)stream);
     if (e != 0) return hip_fail((hipError_t)e);
     return PPN_OK;
 }
 
-int ppn_conv3x3_relu_classify2_bf16(const void* x, const void* w, const float* bias, const float* w2, float* logits, int32_t B, int32_t H,
-                                    int32_t W, int32_t Cin, int32_t Cout, void* stream) {
-    if (!x || !w || !bias || !w2 || !logits || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 64) != 0 || Cout <= 0 || (Cout % 8) != 0)
+int32_t ppn_conv3x3_relu_classify2_slots(int32_t Cout) { return Cout > 0 ? ((Cout + 255) / 256) * 4 : -1; }
+
+int ppn_conv3x3_relu_classify2_bf16(const void* x, const void* w, const float* bias, const float* w2, float* logits, float* partial, int32_t B,
+                                    int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream) {
+    if (!x || !w || !bias || !w2 || !logits || !partial || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 64) != 0 || Cout <= 0 || (Cout % 8) != 0)
         return PPN_E_INVALID;
     if ((long long)B * H * W * Cin * 2 >= (1LL << 32) || (long long)Cout * 9 * Cin * 2 >= (1LL << 32) || (long long)B * H * W >= (1LL << 31))
         return PPN_E_UNSUPPORTED;
-    const int e = ppn::conv3x3_mfma_launch(x, w, bias, nullptr, B, H, W, Cin, Cout, 1, 1, w2, logits, (hipStream_t)stream);
+    const int e = ppn::conv3x3_mfma_launch(x, w, bias, nullptr, B, H, W, Cin, Cout, 1, 1, w2, logits, partial, (hipStream_t)stream);
     if (e != 0) return hip_fail((hipError_t)e);
     return PPN_OK;
 }

@@ -40,7 +40,8 @@ enum Epi {
     EPI_BIAS_GELU = 1,   // C = gelu(acc + bias[n])              (erf form, torch.nn.GELU default)
     EPI_ACCUM = 2,       // C = C + acc                           (residual stream update, bias carried outside)
     EPI_BIAS_RELU = 3,   // C = max(acc + bias[n], 0)             (conv + folded BatchNorm + ReLU)
-    EPI_RELU_DOT2 = 4    // logits[m][c] += sum_n max(acc + bias[n], 0) * w2[c][n], c = 0, 1  (the 1x1 classifier on top)
+    EPI_RELU_DOT2 = 4    // partial[slot][m][c] = sum_{n in slot} max(acc + bias[n], 0) * w2[c][n], c = 0, 1, slot = a wave's 64 columns
+                         // (the 1x1 classifier on top; the slots are summed in order by classify2_reduce_kernel: no atomics)
 };
 
 struct Params {
@@ -55,7 +56,7 @@ struct Params {
     const __bf16* zero;    // >= 128 bytes of zeros
     // EPI_RELU_DOT2
     const float* w2;       // [2][N]
-    float* logits;         // [M][2], pre-filled with the classifier's bias
+    float* logits;         // EPI_RELU_DOT2: the partial sums [ceil(N / 64)][M][2]
 };
 
 __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_uniform) {
@@ -364,8 +365,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
             finish_quadrant(1, 0, m0, n0, pb);
             ++g;
         } else if (EPI == EPI_RELU_DOT2) {
-            // max(acc + bias, 0) . w2[c] over this wave's 64 columns: reduce over the 4 lane quarters, then one float atomic per
-            // (row, class) per wave (8 per row over the two column blocks' four wave columns): 16 atomic instructions
+            // max(acc + bias, 0) . w2[c] over this wave's 64 columns: reduce over the 4 lane quarters, then ONE plain 8-byte store per
+            // row into this wave's column slot (n0 / 64 + wc): every (slot, row) has exactly one writer, and the slots are added in
+            // a fixed order afterwards — the logits are bit-reproducible (round 3 used float atomics: the last bit of a logit
+            // depended on the arrival order of its eight adders)
             float4 bv[2][2], w0v[2][2], w1v[2][2];
 #pragma unroll
             for (int bp = 0; bp < 2; ++bp)
@@ -397,10 +400,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
                         }
                     s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
                     s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-                    if (fq == 0 && m < p.M) {
-                        atomicAdd(p.logits + (size_t)m * 2, s0);
-                        atomicAdd(p.logits + (size_t)m * 2 + 1, s1);
-                    }
+                    if (fq == 0 && m < p.M)
+                        *reinterpret_cast<float2*>(p.logits + ((size_t)(n0 / 64 + wc) * p.M + m) * 2) = make_float2(s0, s1);
                 }
         } else {
             // persistent form: the whole tile is finished here; exactly EPI_STORES vector-memory instructions stay in the queue

@@ -41,8 +41,20 @@ int launch(const gemm::Params& p, int persistent, hipStream_t stream) {
 
 }  // namespace
 
+// logits[m][c] += sum over the column slots, in slot order (logits holds the classifier's bias on entry)
+__global__ __launch_bounds__(256) void classify2_reduce_kernel(const float* __restrict__ partial, float* __restrict__ logits, int M, int slots) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;           // one float2 = one pixel
+    if (i >= M) return;
+    float2 a = reinterpret_cast<const float2*>(logits)[i];
+    for (int s = 0; s < slots; ++s) {
+        const float2 v = reinterpret_cast<const float2*>(partial)[(size_t)s * M + i];
+        a.x += v.x; a.y += v.y;
+    }
+    reinterpret_cast<float2*>(logits)[i] = a;
+}
+
 int conv3x3_mfma_launch(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int stride,
-                        int relu, const float* w2, float* logits, hipStream_t stream) {
+                        int relu, const float* w2, float* logits, float* partial, hipStream_t stream) {
     gemm::Params p{};
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     p.A = (const __bf16*)x; p.B = (const __bf16*)w; p.C = (__bf16*)y; p.bias = bias;
@@ -50,8 +62,16 @@ int conv3x3_mfma_launch(const void* x, const void* w, const float* bias, void* y
     p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.stride = stride;
     p.zero = (const __bf16*)zero_line();
     if (!p.zero) return (int)hipErrorOutOfMemory;
-    p.w2 = w2; p.logits = logits;
-    if (logits) return launch<gemm::CONV3, gemm::EPI_RELU_DOT2>(p, 0, stream);
+    p.w2 = w2; p.logits = partial;
+    if (logits) {
+        if (!partial) return (int)hipErrorInvalidValue;
+        // columns beyond N inside the last 256-wide block contribute zeros (their w2 is read as 0), so every slot of every row is written
+        const int e = launch<gemm::CONV3, gemm::EPI_RELU_DOT2>(p, 0, stream);
+        if (e != 0) return e;
+        const int slots = ((Cout + 255) / 256) * 4;
+        hipLaunchKernelGGL(classify2_reduce_kernel, dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, stream, partial, logits, p.M, slots);
+        return (int)hipGetLastError();
+    }
     return relu ? launch<gemm::CONV3, gemm::EPI_BIAS_RELU>(p, 0, stream) : launch<gemm::CONV3, gemm::EPI_BIAS>(p, 0, stream);
 }
 

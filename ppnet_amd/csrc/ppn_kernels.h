@@ -120,7 +120,7 @@ int grid_image_launch(const uint8_t* grid, void* img, long long n, const float* 
 int bias_act_launch(void* x, const void* bias, long long n, int C, float slope, int dtype, hipStream_t stream);
 
 int conv3x3_mfma_launch(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int stride,
-                        int relu, const float* w2, float* logits, hipStream_t stream);
+                        int relu, const float* w2, float* logits, float* partial, hipStream_t stream);
 int gennet_enc_conv_launch(const void* x, const void* wk, const float* bias, void* y, int B, int H, int W, float slope, hipStream_t stream);
 int gennet_dec_conv_launch(const void* x, const void* wt, const float* bias, void* y, int B, int H, int W, float slope, hipStream_t stream);
 int assemble_paths_launch(const double* wp, const int32_t* wp_n, const uint8_t* ok, const double* init, const double* end, double rate, int n, int max_wp,

@@ -78,10 +78,9 @@ def test_generate_and_plan_chain_equals_separate_calls():
             assert torch.equal(mb0.grid, g1) and torch.equal(mb0.segpoint, sp1) and torch.equal(mb0.n_obstacles, no1)
             live = torch.arange(ob1.shape[1], device=dev)[None, :] < no1[:, 0:1]      # rows past the count keep whatever the buffer held
             assert torch.equal(mb0.obstacles[live], ob1[live])
-            # SegNet's fused classifier sums its channel tiles with float atomics: the last bit of a logit depends on arrival order
-            # (run to run on ONE stream ~1e-5 of the logits differ), so a label may flip where the two classes tie.  The chain's
-            # labels equal the separate call's up to that; every later stage is compared on the chain's OWN labels, bit for bit.
-            assert float((m0 != m1).float().mean()) < 1e-4
+            # (round 3's fused classifier summed its channel tiles with float atomics and the labels of two runs differed on ~1e-5
+            # of the pixels, wherever the classes tie; the per-slot partial sums of round 4 are added in a fixed order)
+            assert torch.equal(m0, m1)
             heat = model.heatmap(m1)
             assert torch.equal(heat, h1)
             res = model.plan_tail(h1, sp1[:, 0].contiguous(), sp1[:, 10].contiguous(), ob1, no1[:, 0].contiguous())

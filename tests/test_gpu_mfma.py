@@ -53,6 +53,9 @@ def test_conv3x3_relu_classify2_vs_torch():
         got = fused.conv3x3_relu_classify2(x, w.permute(0, 2, 3, 1).contiguous(), b.contiguous(), w2.contiguous(), b2)
         assert got.shape == (B, 2, H, W) and got.dtype == torch.float32
         _close(got, want, rel=2e-3)                                           # float32 out: only the bf16 operands round
+        for _ in range(3):                                                    # per-slot partial sums added in a fixed order: no atomics
+            again = fused.conv3x3_relu_classify2(x, w.permute(0, 2, 3, 1).contiguous(), b.contiguous(), w2.contiguous(), b2)
+            assert torch.equal(again, got)
 
 
 @pytest.mark.parametrize("M,N,K,persistent", [(300, 264, 128, 0), (512, 256, 192, 0), (256 * 40, 768, 192, 256), (256 * 33, 512, 320, 256),
