@@ -452,6 +452,8 @@ def end_to_end_leg(torch, dev, steps, world, rank, cpu_leg):
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
     n_local = PATHS5 * PLACEMENTS5
     bufs = [(edage.PathsBatch(PATHS5, R5, MAP_SIZE, CLEARANCE, dev), edage.MapsBatch(n_local, R5, K, dev)) for _ in range(n_streams)]
+    s_comm = torch.cuda.Stream(dev) if world > 1 else None
+    gathered = torch.empty(world * n_local, shard.PLAN_RECORD_WIDTH, dtype=torch.float64, device=dev) if world > 1 else None
 
     def one(it, timers=None):
         pb, mb = bufs[it % n_streams]
@@ -459,6 +461,14 @@ def end_to_end_leg(torch, dev, steps, world, rank, cpu_leg):
         marks = iter(timers) if timers else None
         r = model.generate_and_plan(pb, mb, PLACEMENTS5, first_path, first_map, seed=SEED + 5, obstacles_size=OBST_SIZE, obstacles_num=K,
                                     mark=(lambda name: next(marks).record()) if timers else None)
+        if world > 1:                                                         # end-of-batch gather of the plan records (RCCL, own stream)
+            res = r["result"]
+            rec = shard.pack_plan_records(res, evaluate.plan_lengths(res["waypoints"], res["counts"]))
+            ev = torch.cuda.Event(); ev.record()
+            with torch.cuda.stream(s_comm):
+                s_comm.wait_event(ev)
+                shard.gather_records(rec, world, out=gathered)
+                rec.record_stream(s_comm)
         return pb, mb, r["heat"], r["result"]
     for i in range(2 * n_streams):                                   # allocator pools, tile descriptors, library workspaces: outside the clock
         with torch.cuda.stream(streams[i % n_streams]):

@@ -53,5 +53,24 @@ def test_rccl_group_of_one_gathers_records():
         torch.cuda.synchronize()
         assert torch.equal(gathered, rec) and float(t) == 1.5
         assert int(rec[:, 0].sum()) >= 1                                      # at least one ridge walk reached its goal
+        # bench.py's record ring as real collectives: stage B writes three steps straight into the ring's slices, one
+        # all_gather_into_tensor per group of two steps on the communication stream, the third step flushed alone
+        ring = shard.RecordRing(1, mb.n, 2, dev, s_comm, collective="always")
+        views = [[mb.with_records(ring.slot_view(sl, k)) for k in range(2)] for sl in range(2)]
+        shipped = []
+        for it in range(3):
+            ring.begin_step()
+            edage.generate_maps(pb, 4, 5, 20, seed=9, first_map_id=it * mb.n, out=views[ring.slot][ring.k])
+            before = ring.n_gathers
+            ring.end_step()
+            if ring.n_gathers != before:
+                shipped.append(ring.last)
+        tail = ring.flush()
+        s_comm.synchronize(); torch.cuda.synchronize()
+        assert len(shipped) == 1 and shipped[0][1] == 2 and ring.last[1] == 1 and ring.n_gathers == 2
+        for it in range(3):
+            want = edage.generate_maps(pb, 4, 5, 20, seed=9, first_map_id=it * mb.n).records
+            got = ring.rank_rows(shipped[0][0], 2, 0, it) if it < 2 else ring.rank_rows(tail, 1, 0, 0)
+            assert torch.equal(got, want)
     finally:
         dist.destroy_process_group()
