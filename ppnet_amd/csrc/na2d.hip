@@ -377,10 +377,11 @@ int na2d_launch(const void* qkv, const void* pad_kv, const float* rpb, void* out
         const int rc = na2d_dense7_launch(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
         if (rc != -2) return rc;
     }
-    const int hq_ = (Hr + dil - 1) / dil, wq_ = (Wr + dil - 1) / dil;
-    auto util = [&](int t) { return (double)(hq_ * wq_) / ((double)((hq_ + t - 1) / t * t) * ((wq_ + t - 1) / t * t)); };
-    const bool region16 = !(util(8) > util(16) + 0.05) && !(util(4) > util(16) + 0.05);
-    if (dtype == 1 && !valu && elems < 0xffffffffLL && (region16 || all_mfma)) return na2d_mfma_launch(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
+    // every other bfloat16 launch runs on the matrix cores, in the region size that covers its dilation groups cheapest
+    // (na_region_size: rounds 2-3 sent groups that fill a 16 x 16 region poorly to this file's v_dot2 kernel — 2.23 ms against
+    // 0.52 ms on the 11 x 11 groups of the dilation-3 layers at 512 x 512, and the 56 x 56 level of a 224 x 224 input likewise)
+    (void)all_mfma;
+    if (dtype == 1 && !valu && elems < 0xffffffffLL) return na2d_mfma_launch(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
     return dtype == 0 ? launch_typed<float>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream)
                       : launch_typed<__hip_bfloat16>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, stream);
 }

@@ -277,11 +277,7 @@ int na2d_mfma_launch(const void* qkv, const void* pad_kv, const float* rpb, void
     const __bf16* zero = (const __bf16*)zero_line();
     if (!zero) return (int)hipErrorOutOfMemory;
     const int hq = (Hr + dil - 1) / dil, wq = (Wr + dil - 1) / dil;
-    // lane utilisation of each region size on the query sub-image (as na2d.hip chooses its tile)
-    auto util = [&](int t) { return (double)(hq * wq) / ((double)((hq + t - 1) / t * t) * ((wq + t - 1) / t * t)); };
-    int best = 16;
-    if (util(8) > util(best) + 0.05) best = 8;
-    if (util(4) > util(best) + 0.05) best = 4;
+    int best = na_region_size(hq, wq);                                      // the cheapest cover of the query sub-image (ppn_kernels.h)
     if (const char* f = getenv("PPNET_NA_RT")) { const int v = atoi(f); if (v == 4 || v == 8 || v == 16) best = v; }   // A/B: force the region size
     if (best == 4) return launch_rt<4>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, zero, stream);
     if (best == 8) return launch_rt<8>(qkv, pad_kv, rpb, out, B, H, W, Hr, Wr, heads, dil, scale, zero, stream);

@@ -31,6 +31,16 @@ inline int dynamic_lds_once(DeviceOnce& o, const void* fn, int bytes) {
     o.done[d].store(1, std::memory_order_release);
     return 0;
 }
+// Region size (16 / 8 / 4 queries a side) of the matrix-core neighbourhood-attention kernels for a dilation group of hq x wq queries:
+// the cheapest cover, priced per covered query cell.  Measured on 11 x 11 groups (DiNAT-B's dilation-3 layers at 32 x 32 tokens,
+// batch 256: tools/na_timing_512.py): 16 x 16 regions 0.52 ms (47 % of the cells used), 8 x 8 0.97 ms, 4 x 4 1.56 ms (84 % used; the
+// v_dot2 kernel 2.23 ms) — per cell 1 : 1.9 : 5.3.  Rounds 2-3 chose by lane utilisation alone and took the 4 x 4 form here.
+inline int na_region_size(int hq, int wq) {
+    auto cells = [&](int t) { return (double)((hq + t - 1) / t * t) * (double)((wq + t - 1) / t * t); };
+    const double c16 = cells(16), c8 = 1.9 * cells(8), c4 = 5.3 * cells(4);
+    return (c16 <= c8 && c16 <= c4) ? 16 : (c8 <= c4 ? 8 : 4);
+}
+
 // compute units of the current device (cached per device; 0 when the query fails)
 inline int device_cu_count() {
     static std::atomic<int> cus[PPN_MAX_DEVICES];
