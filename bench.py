@@ -644,12 +644,25 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None)
     tflops = (seg_fl + gen_fl) * batch / (ms * 1e-3) / 1e12
     ev_tail = evaluate.evaluate_plans(res, target_px)
     net_tail = model.plan_tail(heat, init, end, obs, n_obs)
+    # the same batch CHAINED end to end — the planner tail walks GenNet's own heat map (PPNet.plan) — on the same two streams: with
+    # untrained weights that map is noise and the walk ends early, so this is the lighter batch; reported beside the ridge-map one
+    for st in pp_streams:
+        with torch.cuda.stream(st):
+            model.plan(g, init, end, obs, n_obs)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for i in range(steps):
+        with torch.cuda.stream(pp_streams[i % n_streams]):
+            model.plan(g, init, end, obs, n_obs)
+    torch.cuda.synchronize()
+    ms_chained = (time.perf_counter() - t2) / steps * 1e3
     out = {"metric": "ppnet_plans_per_sec", "value": round(world * batch * steps / el, 1), "unit": "plans/s",
            "batch_per_gpu": batch, "steps": steps, "ms_per_batch": round(ms, 2), "dtype": "bf16 (fp32 accumulate)",
            "workload": "PPNet inference batch=256 over 256x256 maps: DiNAT-B + SETR-UP -> AE-ViT -> extract_path -> collision check"
                        + (" -> all-gather of plan records" if world > 1 else ""),
            "ms_segnet": round(t_seg, 2), "ms_gennet": round(t_gen, 2), "ms_tail": round(t_tail, 2),
            "ms_per_batch_hip_graph": round(ms_graph, 2) if ms_graph is not None else None, "streams": n_streams,
+           "ms_per_batch_chained_network_output": round(ms_chained, 2),
            "weights": "seeded random init, neutral parameters randomised too (no trained weights in the reference)",
            "tail_input": "ridge heat maps along the label paths (GenNet's training target, blurred); the networks' own output is noise",
            "tail": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ev_tail.items()},
