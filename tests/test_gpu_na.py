@@ -37,7 +37,11 @@ def test_kernel_vs_oracle_f32(dev, B, H, W, heads, d):
 
 
 @pytest.mark.parametrize("B,H,W,heads,d", [(2, 20, 17, 2, 2), (1, 64, 64, 4, 1), (2, 56, 56, 2, 8), (3, 7, 7, 1, 1), (1, 21, 21, 3, 3),
-                                           (2, 16, 16, 2, 2), (3, 8, 8, 3, 1), (1, 32, 32, 1, 4)])   # 7 x 7 and 8 x 8 dilation groups: na2d_dense7.hip
+                                           (2, 16, 16, 2, 2), (3, 8, 8, 3, 1), (1, 32, 32, 1, 4),    # 7 x 7 and 8 x 8 dilation groups: na2d_dense7.hip
+                                           # groups that fill a 16 x 16 region poorly and still take it (na_region_size: the cheapest
+                                           # cover, round 4): 11 x 11 / 10 x 11 groups of dilation 3 at 32 x 32 (DiNAT-B level 2 at 512 x 512),
+                                           # the 56 x 56 level of a 224 x 224 input, a 9 x 12 remainder; and one the 8 x 8 regions keep
+                                           (2, 32, 32, 2, 3), (1, 56, 56, 2, 1), (1, 25, 28, 1, 1), (2, 9, 9, 1, 1), (1, 18, 20, 2, 2)])
 def test_kernel_vs_oracle_bf16(dev, B, H, W, heads, d):
     import torch
     from ppnet_amd import na
