@@ -55,4 +55,4 @@ python3 tools/na_bwd_timing.py >> $OUT/train_timing.txt 2>&1 || true
 python3 tools/graph_latency.py > $OUT/graph_latency.txt 2>&1 || true
 bash tools/steps_sweep.sh > $OUT/steps_sweep.txt 2>&1 || true
 fi
-[ -f $OUT/bench.json ] && tail -c 900 $OUT/bench.json
+[ -f $OUT/bench.json ] && tail -c 900 $OUT/bench.json || true
