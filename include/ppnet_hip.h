@@ -302,6 +302,17 @@ int ppn_upsample2x_nhwc(const void* x, void* y, int32_t B, int32_t H, int32_t W,
  * folded) bias and its separate add pass (mmcv ConvModule conv -> bn -> ReLU -> Upsample, setr_up_head.py:56-66). */
 int ppn_upsample2x_nhwc_bias(const void* x, const void* bias, void* y, int32_t B, int32_t H, int32_t W, int32_t C,
                              int32_t relu, int32_t dtype, void* stream);
+/* y = add + (x resized x2): the FPN's top-down step (uper_head.py:103-108: `laterals[i - 1] += resize(laterals[i], size=prev_shape,
+ * mode='bilinear', align_corners=False)`) when the finer level is exactly twice the coarser one.  x [B][H][W][C], add and y
+ * [B][2H][2W][C]; add may be y.  The resized value is rounded to the tensor's type before the sum, as the two separate kernels do. */
+int ppn_upsample2x_add_nhwc(const void* x, const void* add, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+/* UPerHead's FPN output assembly (mmseg/decode_heads/uper_head.py:117-127: `resize(fpn_outs[i], size=fpn_outs[0].shape[2:],
+ * mode='bilinear', align_corners=False)` for i = 1..3, then `torch.cat(fpn_outs, dim=1)`) in one pass over NHWC tensors:
+ * out [B][H0][W0][4 C], channels [l C, (l + 1) C) = level l resized to H0 x W0 (level 0 copied).  x_l is [B][hw[2 l]][hw[2 l + 1]][C]
+ * (host array hw[8], no level larger than level 0); PyTorch's upsample_bilinear2d arithmetic per output.  C % 8 == 0; dtype 0
+ * float32, 1 bfloat16. */
+int ppn_resize_concat4_nhwc(const void* x0, const void* x1, const void* x2, const void* x3, const int32_t* hw, void* out, int32_t B, int32_t C,
+                            int32_t dtype, void* stream);
 /* SegNet's input straight from stage B's occupancy codes: img [n_pixels][3] (NHWC) = (rgb - mean3) / std3 with rgb = (255,255,255)
  * for PPN_GRID_FREE, (255,0,0) for PPN_GRID_MARK, (0,0,0) otherwise (process_map.py:120,128; planning_seg.py:12-41).
  * mean3 / std3 are HOST pointers to three floats; n_pixels a multiple of 8. */

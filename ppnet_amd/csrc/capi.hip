@@ -398,7 +398,27 @@ int ppn_upsample2x_nhwc(const void* x, void* y, int32_t B, int32_t H, int32_t W,
 int ppn_upsample2x_nhwc_bias(const void* x, const void* bias, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t relu,
                              int32_t dtype, void* stream) {
     if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
-    const int e = ppn::upsample2x_launch(x, bias, y, B, H, W, C, relu, dtype, (hipStream_t)stream);
+    const int e = ppn::upsample2x_launch(x, bias, nullptr, y, B, H, W, C, relu, dtype, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
+int ppn_upsample2x_add_nhwc(const void* x, const void* add, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+    if (!x || !add || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
+    const int e = ppn::upsample2x_launch(x, nullptr, add, y, B, H, W, C, 0, dtype, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
+int ppn_resize_concat4_nhwc(const void* x0, const void* x1, const void* x2, const void* x3, const int32_t* hw, void* out, int32_t B, int32_t C,
+                            int32_t dtype, void* stream) {
+    if (!x0 || !x1 || !x2 || !x3 || !hw || !out || B <= 0 || C <= 0 || (C % 8) != 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
+    for (int l = 0; l < 4; ++l)
+        if (hw[2 * l] <= 0 || hw[2 * l + 1] <= 0 || hw[2 * l] > hw[0] || hw[2 * l + 1] > hw[1]) return PPN_E_INVALID;
+    const void* x[4] = {x0, x1, x2, x3};
+    int h[8];
+    for (int k = 0; k < 8; ++k) h[k] = hw[k];
+    const int e = ppn::resize_concat4_launch(x, h, out, B, C, dtype, (hipStream_t)stream);
     if (e != 0) return hip_fail((hipError_t)e);
     return PPN_OK;
 }

@@ -142,8 +142,12 @@ __global__ __launch_bounds__(256) void norm_kernel(const T* __restrict__ x, cons
 // Bilinear x2 up-sampling of an NHWC tensor (F.interpolate(scale_factor=2, mode="bilinear", align_corners=False), the
 // SETR-UP head's Upsample, mmseg/ops/wrappers.py:30-51) with the preceding ReLU folded into the loads: one thread per
 // 8 channels of one output pixel, four 16-byte loads, one 16-byte store.
+template <typename T> __device__ __forceinline__ float through(float v);
+template <> __device__ __forceinline__ float through<float>(float v) { return v; }
+template <> __device__ __forceinline__ float through<__hip_bfloat16>(float v) { return __bfloat162float(__float2bfloat16(v)); }
+
 template <typename T, bool RELU>
-__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ x, const T* __restrict__ bias, T* __restrict__ y, int B, int H, int W,
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ x, const T* __restrict__ bias, const T* add, T* y, int B, int H, int W,
                                                          int C) {
     // One thread per 8 channels of a 2 x 2 OUTPUT block {2i+1, 2i+2} x {2j+1, 2j+2}, i = -1 .. H-1, j = -1 .. W-1: its four pixels
     // interpolate the same 2 x 2 input block (rows i, i+1, columns j, j+1, clamped to the image), so a thread makes four 16-byte
@@ -193,19 +197,79 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ x
             float o[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = hy * (hx * v[0][0][k] + lx * v[0][1][k]) + ly * (hx * v[1][0][k] + lx * v[1][1][k]);
-            Vec8<T>::store(y + (((size_t)b * 2 * H + oy) * 2 * W + ox) * C + c0, o);
+            const size_t at = (((size_t)b * 2 * H + oy) * 2 * W + ox) * C + c0;
+            if (add) {                                                      // y = add + resize(x) (the FPN's top-down step, uper_head.py:103-108;
+                float ad[8];                                                // add may be y): the resized value rounds to T before the sum, as the
+                Vec8<T>::load(add + at, ad);                                // framework's two kernels leave it
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = ad[k] + through<T>(o[k]);
+            }
+            Vec8<T>::store(y + at, o);
         }
     }
 }
 
-int upsample2x_launch(const void* x, const void* bias, void* y, int B, int H, int W, int C, int relu, int dtype, hipStream_t stream) {
+int upsample2x_launch(const void* x, const void* bias, const void* add, void* y, int B, int H, int W, int C, int relu, int dtype, hipStream_t stream) {
     const long long per_row = ((long long)W + 1) * (C / 8), rows = (long long)B * (H + 1);
     if ((per_row + 255) / 256 > 65535 || rows >= (1LL << 31)) return (int)hipErrorInvalidValue;
     const dim3 grid((unsigned)rows, (unsigned)((per_row + 255) / 256));
-#define PPN_UP(T, R) hipLaunchKernelGGL((upsample2x_kernel<T, R>), grid, dim3(256), 0, stream, (const T*)x, (const T*)bias, (T*)y, B, H, W, C)
+#define PPN_UP(T, R) hipLaunchKernelGGL((upsample2x_kernel<T, R>), grid, dim3(256), 0, stream, (const T*)x, (const T*)bias, (const T*)add, (T*)y, B, H, W, C)
     if (dtype == 0) { if (relu) PPN_UP(float, true); else PPN_UP(float, false); }
     else { if (relu) PPN_UP(__hip_bfloat16, true); else PPN_UP(__hip_bfloat16, false); }
 #undef PPN_UP
+    return (int)hipGetLastError();
+}
+
+// UPerHead's FPN output assembly (uper_head.py:117-127: every FPN level resized to the finest one's size, bilinear, align_corners
+// False, then concatenated over channels) as ONE pass over NHWC tensors: out[b][i][j][l * C + c] = resize(x_l)[b][i][j][c], level 0
+// copied.  One thread per 8 channels of one (pixel, level), the level = blockIdx.y (uniform: its geometry stays in scalars, a wave
+// stores eight 16 C-byte runs); each output uses PyTorch's formula for its coordinate (source index
+// scale * (dst + 0.5) - 0.5 clamped at 0 with scale = in / out as a float, the four taps weighted in float32: upsample_bilinear2d).
+// Replaces three interpolate launches, the concatenation and the channels_last copy behind it (5 passes over the 4C-channel tensor).
+struct Concat4Params {
+    const void* x[4];
+    int H[4], W[4];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void resize_concat4_kernel(Concat4Params p, T* __restrict__ out, int B, int C) {
+    const int cg = C >> 3;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int H0 = p.H[0], W0 = p.W[0];
+    if (idx >= (long long)B * H0 * W0 * cg) return;
+    const int g = (int)(idx % cg), l = (int)blockIdx.y;
+    const long long pix = idx / cg;
+    const int j = (int)(pix % W0), i = (int)((pix / W0) % H0), b = (int)(pix / ((long long)W0 * H0));
+    const int Hl = p.H[l], Wl = p.W[l];
+    const T* src = reinterpret_cast<const T*>(p.x[l]) + (size_t)b * Hl * Wl * C + g * 8;
+    T* dst = out + ((size_t)pix * 4 + l) * C + g * 8;
+    float o[8];
+    if (Hl == H0 && Wl == W0) {
+        Vec8<T>::load(src + ((size_t)i * Wl + j) * C, o);
+    } else {
+        const float sh = (float)Hl / (float)H0, sw = (float)Wl / (float)W0;
+        const float sy = fmaxf(sh * ((float)i + 0.5f) - 0.5f, 0.0f), sx = fmaxf(sw * ((float)j + 0.5f) - 0.5f, 0.0f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < Hl - 1 ? 1 : 0), x1 = x0 + (x0 < Wl - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, hy = 1.0f - ly, lx = sx - (float)x0, hx = 1.0f - lx;
+        float a[8], bq[8], c[8], d[8];
+        Vec8<T>::load(src + ((size_t)y0 * Wl + x0) * C, a);
+        Vec8<T>::load(src + ((size_t)y0 * Wl + x1) * C, bq);
+        Vec8<T>::load(src + ((size_t)y1 * Wl + x0) * C, c);
+        Vec8<T>::load(src + ((size_t)y1 * Wl + x1) * C, d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = hy * (hx * a[k] + lx * bq[k]) + ly * (hx * c[k] + lx * d[k]);
+    }
+    Vec8<T>::store(dst, o);
+}
+
+int resize_concat4_launch(const void* const* x, const int* hw, void* out, int B, int C, int dtype, hipStream_t stream) {
+    Concat4Params p;
+    for (int l = 0; l < 4; ++l) { p.x[l] = x[l]; p.H[l] = hw[2 * l]; p.W[l] = hw[2 * l + 1]; }
+    const long long total = (long long)B * p.H[0] * p.W[0] * (C / 8);
+    if ((total + 255) / 256 >= (1LL << 31)) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)((total + 255) / 256), 4);
+    if (dtype == 0) hipLaunchKernelGGL(resize_concat4_kernel<float>, grid, dim3(256), 0, stream, p, (float*)out, B, C);
+    else hipLaunchKernelGGL(resize_concat4_kernel<__hip_bfloat16>, grid, dim3(256), 0, stream, p, (__hip_bfloat16*)out, B, C);
     return (int)hipGetLastError();
 }
 

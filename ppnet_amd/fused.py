@@ -164,6 +164,40 @@ def upsample2x_nhwc(x_nchw_cl, relu=False, bias=None):
     return y.permute(0, 3, 1, 2)
 
 
+def upsample2x_add_(fine, coarse):
+    """fine += bilinear x2 (align_corners=False) of coarse, in place: the FPN's top-down step (uper_head.py:103-108) on channels_last
+    [B,C,2H,2W] / [B,C,H,W] tensors, one kernel (ppn_upsample2x_add_nhwc) instead of interpolate + add."""
+    f, c = fine.permute(0, 2, 3, 1), coarse.permute(0, 2, 3, 1)
+    if not c.is_contiguous():
+        c = c.contiguous()
+    B, H, W, C = c.shape
+    assert f.is_contiguous() and f.is_cuda and f.dtype == c.dtype and f.dtype in _DT and tuple(f.shape) == (B, 2 * H, 2 * W, C)
+    with torch.cuda.device(f.device):
+        rc = L.lib.ppn_upsample2x_add_nhwc(_p(c), _p(f), _p(f), B, H, W, C, _DT[f.dtype], ctypes.c_void_p(torch.cuda.current_stream(f.device).cuda_stream))
+    L.check(rc, "ppn_upsample2x_add_nhwc")
+    return fine
+
+
+def resize_concat4(levels):
+    """UPerHead's FPN output assembly (uper_head.py:117-127) for four channels_last [B,C,H_l,W_l] tensors, finest first: every
+    level bilinearly resized (align_corners=False) to the finest one's size and concatenated over channels, in ONE kernel
+    (ppn_resize_concat4_nhwc).  Returns a channels_last [B,4C,H_0,W_0] tensor."""
+    assert len(levels) == 4
+    xs = []
+    for t in levels:
+        x = t.permute(0, 2, 3, 1)
+        xs.append(x if x.is_contiguous() else x.contiguous())
+    B, H0, W0, C = xs[0].shape
+    assert all(x.is_cuda and x.dtype == xs[0].dtype and x.shape[0] == B and x.shape[3] == C for x in xs) and xs[0].dtype in _DT
+    out = torch.empty(B, H0, W0, 4 * C, dtype=xs[0].dtype, device=xs[0].device)
+    hw = (ctypes.c_int32 * 8)(*[v for x in xs for v in (x.shape[1], x.shape[2])])
+    with torch.cuda.device(out.device):
+        rc = L.lib.ppn_resize_concat4_nhwc(_p(xs[0]), _p(xs[1]), _p(xs[2]), _p(xs[3]), hw, _p(out), B, C, _DT[xs[0].dtype],
+                                           ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream))
+    L.check(rc, "ppn_resize_concat4_nhwc")
+    return out.permute(0, 3, 1, 2)
+
+
 def bias_act_(x_nchw_cl, bias, negative_slope):
     """In place leaky_relu(x + bias[c], negative_slope) on a channels_last [B,C,H,W] tensor (slope 0 = ReLU, 1 = bias
     only).  Returns x."""

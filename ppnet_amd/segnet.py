@@ -627,11 +627,20 @@ class UPerHead(nn.Module):
         x = inputs[-1]
         psp = torch.cat([x] + [self._resize(conv1(m[1], m[0](x)), x.shape[2:]) for m in self.psp_modules], dim=1)
         laterals = [conv1(cm, inputs[i]) for i, cm in enumerate(self.lateral_convs)] + [conv3(self.bottleneck, psp.contiguous(memory_format=torch.channels_last))]
+        own_resize = not self.align_corners and laterals[0].shape[1] % 8 == 0 and not os.environ.get("PPNET_UPER_UNFUSED_RESIZE")
         for i in range(len(laterals) - 1, 0, -1):
-            laterals[i - 1] = laterals[i - 1] + self._resize(laterals[i], laterals[i - 1].shape[2:])
+            fine, coarse = laterals[i - 1], laterals[i]
+            if (own_resize and fine.shape[2] == 2 * coarse.shape[2] and fine.shape[3] == 2 * coarse.shape[3]
+                    and fine.permute(0, 2, 3, 1).is_contiguous()):
+                fused.upsample2x_add_(fine, coarse)                         # the resize and the sum: one kernel, in place
+            else:
+                laterals[i - 1] = fine + self._resize(coarse, fine.shape[2:])
         outs = [conv3(self.fpn_convs[i], laterals[i].contiguous(memory_format=torch.channels_last)) for i in range(len(laterals) - 1)] + [laterals[-1]]
-        outs = [outs[0]] + [self._resize(o, outs[0].shape[2:]) for o in outs[1:]]
-        cat = torch.cat(outs, dim=1).contiguous(memory_format=torch.channels_last)
+        if len(outs) == 4 and own_resize:
+            cat = fused.resize_concat4(outs)                                # the three resizes + the concatenation: one kernel
+        else:
+            outs = [outs[0]] + [self._resize(o, outs[0].shape[2:]) for o in outs[1:]]
+            cat = torch.cat(outs, dim=1).contiguous(memory_format=torch.channels_last)
         fb = self.fpn_bottleneck
         if _use_mfma_conv(cat, fb.conv, narrow=True):
             w, b = pk[fb]

@@ -191,6 +191,37 @@ def test_bias_act_and_biased_upsample_vs_torch(dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_fpn_resize_kernels_vs_the_framework_sequence(dtype):
+    """UPerHead's top-down step and output assembly (uper_head.py:103-108, 117-127) as single kernels against the framework calls they
+    replace, in the tensor's own dtype: interpolate(size=..., bilinear, align_corners=False) then add / cat.  Same arithmetic per
+    output (PyTorch's source index and weights, float32 taps, one rounding per framework kernel); what is left is the compilers'
+    choice of fused multiply-adds inside the four-tap sum: units in the last place of the taps (measured: 4.8e-7 in float32).
+    The levels are the network's x2 / x4 / x8 pyramid and ragged ones (sizes that are no multiples of each other, a 1-wide level)."""
+    from ppnet_amd import fused
+    dt = getattr(torch, dtype)
+    torch.manual_seed(6)
+    F_ = torch.nn.functional
+    tol = 2e-6 if dt == torch.float32 else 2.0 ** -6                       # a few ulp of the taps' magnitude (unit normal draws, |x| < 5)
+
+    def close(got, want):
+        return bool(((got.float() - want.float()).abs() <= tol).all())
+    for B, C, sizes in ((3, 64, ((16, 16), (8, 8), (4, 4), (2, 2))), (2, 24, ((13, 9), (7, 5), (3, 3), (1, 2))), (1, 8, ((5, 5), (5, 5), (1, 1), (2, 4)))):
+        lv = [torch.randn(B, C, h, w, device="cuda", dtype=dt).contiguous(memory_format=torch.channels_last) for (h, w) in sizes]
+        want = torch.cat([lv[0]] + [F_.interpolate(t, size=sizes[0], mode="bilinear", align_corners=False) for t in lv[1:]], dim=1)
+        got = fused.resize_concat4(lv)
+        assert got.shape == want.shape and got.permute(0, 2, 3, 1).is_contiguous()
+        assert close(got, want), (B, C, sizes, (got.float() - want.float()).abs().max().item())
+        assert torch.equal(got[:, :C], lv[0])                              # the finest level is a copy
+    for (h, w) in ((8, 8), (1, 1), (5, 3)):
+        coarse = torch.randn(2, 64, h, w, device="cuda", dtype=dt).contiguous(memory_format=torch.channels_last)
+        fine = torch.randn(2, 64, 2 * h, 2 * w, device="cuda", dtype=dt).contiguous(memory_format=torch.channels_last)
+        want = fine + F_.interpolate(coarse, size=(2 * h, 2 * w), mode="bilinear", align_corners=False)
+        got = fused.upsample2x_add_(fine, coarse)
+        assert got is fine and close(got, want), (h, w, (got.float() - want.float()).abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
 def test_single_channel_convs_vs_torch(dtype):
     from ppnet_amd import fused
     dt = getattr(torch, dtype)
