@@ -11,8 +11,11 @@
 // that the MFMA result layout (lane = token column, 4 consecutive rows per register group) is already the B-operand layout
 // of the next product: the LayerNorm output feeds fc1, and GELU(fc1) feeds fc2, without a shuffle or an LDS round trip.
 // Weights are staged once per workgroup as 16-byte A-operand pieces, XOR-swizzled by row so the 16 rows a fragment read
-// touches fall in 16 different bank groups.  Output channels are assigned to (tile, row) so that a lane ends up with 16
-// CONSECUTIVE channels per four tiles: 32-byte stores, a full 128-byte line per token per four tiles.
+// touches fall in 16 different bank groups.  Memory instructions cover 64 CONTIGUOUS bytes per token: the four lanes of a token
+// (g = 0..3) read / write adjacent 16-byte pieces in one instruction, so a wave-instruction touches 16 half-lines instead of 64
+// separate 16-byte pieces — the k-slot -> channel map of the operands and the (tile, row) -> output channel map are chosen for
+// that (any permutation works as long as the staged weights use the same one): k-slot (ks, g, e) is channel 32 ks + 8 g + e, and
+// of every four output tiles a lane holds channels 8 g .. 8 g + 7 (tiles 0, 1) and 32 + 8 g .. 32 + 8 g + 7 (tiles 2, 3).
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
@@ -42,26 +45,106 @@ __device__ __forceinline__ float gelu_erf128(float x) {
     return 0.5f * x + 0.5f * fabsf(x) * e;
 }
 
+// The same function without a transcendental: Phi(x) - 1/2 as an odd polynomial on [-4.25, 4.25] (x clamped, the end point pinned
+// to 1/2 so that gelu(x) is x or 0 beyond), 8 coefficients in x^2 from a minimax fit of x Phi(x): |error| <= 9.2e-5 absolute in
+// float32 — under one bfloat16 ulp of every value above 0.012 and far under the rounding of the hidden activation to bfloat16.
+// Two values per instruction (v_pk_mul_f32 / v_pk_fma_f32): 10 packed operations + 2 v_med3 per pair = 24 cycles per 64 values
+// against 80 for the erf form above (v_exp and v_rcp issue at a quarter of the rate) — these kernels are VALU-bound and the 256
+// GELUs per token are most of their instructions.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
+    const f32x2 xc = {__builtin_amdgcn_fmed3f(x.x, -4.25f, 4.25f), __builtin_amdgcn_fmed3f(x.y, -4.25f, 4.25f)};
+    const f32x2 u = xc * xc;
+    constexpr float K[8] = {3.984200563e-01f, -6.545352466e-02f, 9.257837137e-03f, -9.404510850e-04f, 6.552754503e-05f, -2.938833893e-06f,
+                            7.570944350e-08f, -8.460567657e-10f};
+    f32x2 q = {K[7], K[7]};
+#pragma unroll
+    for (int i = 6; i >= 0; --i) q = __builtin_elementwise_fma(q, u, f32x2{K[i], K[i]});
+    return x * __builtin_elementwise_fma(xc, q, f32x2{0.5f, 0.5f});
+}
+// Diagnostic builds only (make c128abl; never shipped): nat128_ln_mlp_kernel with one part removed — 1 no row loads, 2 no stores,
+// 4 no GELU, 8 no fc1 products, 16 no fc2 products, 32 no LayerNorm arithmetic.
+#ifndef C128_ABL
+#define C128_ABL 0
+#endif
+#ifndef PPN_GELU128_FORM
+#define PPN_GELU128_FORM 4      // 0: erf form (A&S), 1 / 3: logistic fit (v_exp + v_rcp) packed / scalar, 2 / 4: polynomial packed / scalar — 4 ships
+#endif
+__device__ __forceinline__ f32x2 gelu128_pair(f32x2 x) {
+#if PPN_GELU128_FORM == 0
+    return f32x2{gelu_erf128(x.x), gelu_erf128(x.y)};
+#elif PPN_GELU128_FORM == 1
+    f32x2 x2 = x * x;
+    x2 = f32x2{fminf(x2.x, 64.0f), fminf(x2.y, 64.0f)};
+    const f32x2 t = x * __builtin_elementwise_fma(x2, __builtin_elementwise_fma(x2, f32x2{-1.0350827e-3f, -1.0350827e-3f}, f32x2{0.10690469f, 0.10690469f}),
+                                                  f32x2{2.3009787f, 2.3009787f});
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(-t.x), __builtin_amdgcn_exp2f(-t.y)} + f32x2{1.0f, 1.0f};
+    return x * f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+#elif PPN_GELU128_FORM == 3                      // logistic fit, one value per instruction
+    f32x2 r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float v = x[i], v2 = fminf(v * v, 64.0f);
+        const float t = v * fmaf(v2, fmaf(v2, -1.0350827e-3f, 0.10690469f), 2.3009787f);
+        r[i] = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-t));
+    }
+    return r;
+#elif PPN_GELU128_FORM == 4                      // the polynomial, one value per instruction
+    constexpr float K[8] = {3.984200563e-01f, -6.545352466e-02f, 9.257837137e-03f, -9.404510850e-04f, 6.552754503e-05f, -2.938833893e-06f,
+                            7.570944350e-08f, -8.460567657e-10f};
+    f32x2 r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float v = x[i], vc = __builtin_amdgcn_fmed3f(v, -4.25f, 4.25f), u = vc * vc;
+        float q = K[7];
+#pragma unroll
+        for (int k = 6; k >= 0; --k) q = fmaf(q, u, K[k]);
+        r[i] = v * fmaf(vc, q, 0.5f);
+    }
+    return r;
+#else
+    return gelu_poly2(x);
+#endif
+}
+
 // output channel of (tile t, row i) — see the header: a lane (token j, group g) holds rows 4g..4g+3 of every tile
-__device__ __forceinline__ int out_channel(int t, int i) { return (t >> 2) * 64 + 16 * (i >> 2) + 4 * (t & 3) + (i & 3); }
+__device__ __forceinline__ int out_channel(int t, int i) { return (t >> 2) * 64 + 32 * ((t >> 1) & 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3); }
 
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
-// LayerNorm of 16 tokens in B-operand form.  Lane (j = lane & 15, g = lane >> 4) loads channels [32g, 32g + 32) of token j
-// (64 contiguous bytes); MFMA k-slot (ks, g, e) is channel 32g + 8ks + e, the A operand uses the same map.
+// LayerNorm of 16 tokens in B-operand form.  Lane (j = lane & 15, g = lane >> 4) loads channels [32k + 8g, 32k + 8g + 8), k = 0..3,
+// of token j (load k: 64 contiguous bytes per token over its four lanes); MFMA k-slot (ks, g, e) is channel 32ks + 8g + e, the
+// A operand uses the same map.
 // ln = float32 [3][128] in LDS: weight, bias, offset.
-__device__ __forceinline__ void ln_tokens(const __hip_bfloat16* __restrict__ s, long long tok0, int lane, const float* ln, float eps,
-                                          bf16x8 (&yf)[4]) {
-    const int j = lane & 15, g = lane >> 4;
-    const uint4* src = reinterpret_cast<const uint4*>(s + (tok0 + j) * C128 + 32 * g);
-    uint4 u[4];
+__device__ __forceinline__ void load_rows(const __hip_bfloat16* s, long long tok0, int lane, uint4 (&u)[4]) {
+    const uint4* src = reinterpret_cast<const uint4*>(s + (tok0 + (lane & 15)) * C128 + 8 * (lane >> 4));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) u[k] = src[k];
+    for (int k = 0; k < 4; ++k) u[k] = src[4 * k];
+}
+// The same loads issued from inline assembly: the compiler does not know they are pending, so it puts no wait in front of their
+// first use — the caller does, with a COUNTED s_waitcnt (rows_landed<N>: N = the vector-memory operations the wave issues after
+// these four loads and before the wait, i.e. the stores of the group in between).  hipcc's own wait for loads it can see is
+// vmcnt(0) at the head of the loop — the loop-entry edge carries no stores, and it takes the stricter of the two edges — which
+// makes every group wait for its predecessor's stores to be acknowledged.
+typedef __attribute__((ext_vector_type(4))) unsigned int row16;
+__device__ __forceinline__ void load_rows_async(const __hip_bfloat16* s, long long tok0, int lane, row16 (&u)[4]) {
+    const __hip_bfloat16* src = s + (tok0 + (lane & 15)) * C128 + 8 * (lane >> 4);
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
+                 : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]) : "v"(src) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void rows_landed(row16 (&u)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void ln_rows(const row16 (&v)[4], int lane, const float* ln, float eps, bf16x8 (&yf)[4]);
+__device__ __forceinline__ void ln_rows(const uint4 (&u)[4], int lane, const float* ln, float eps, bf16x8 (&yf)[4]) {
+    const int g = lane >> 4;
     float x[32];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float4 o0 = *reinterpret_cast<const float4*>(ln + 256 + 32 * g + 8 * k), o1 = *reinterpret_cast<const float4*>(ln + 256 + 32 * g + 8 * k + 4);
+        const float4 o0 = *reinterpret_cast<const float4*>(ln + 256 + 32 * k + 8 * g), o1 = *reinterpret_cast<const float4*>(ln + 256 + 32 * k + 8 * g + 4);
         x[8 * k + 0] = bf_lo(u[k].x) + o0.x; x[8 * k + 1] = bf_hi(u[k].x) + o0.y;
         x[8 * k + 2] = bf_lo(u[k].y) + o0.z; x[8 * k + 3] = bf_hi(u[k].y) + o0.w;
         x[8 * k + 4] = bf_lo(u[k].z) + o1.x; x[8 * k + 5] = bf_hi(u[k].z) + o1.y;
@@ -81,8 +164,8 @@ __device__ __forceinline__ void ln_tokens(const __hip_bfloat16* __restrict__ s, 
     const float rstd = rsqrtf(q * (1.0f / C128) + eps);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float4 w0 = *reinterpret_cast<const float4*>(ln + 32 * g + 8 * k), w1 = *reinterpret_cast<const float4*>(ln + 32 * g + 8 * k + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(ln + 128 + 32 * g + 8 * k), b1 = *reinterpret_cast<const float4*>(ln + 128 + 32 * g + 8 * k + 4);
+        const float4 w0 = *reinterpret_cast<const float4*>(ln + 32 * k + 8 * g), w1 = *reinterpret_cast<const float4*>(ln + 32 * k + 8 * g + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(ln + 128 + 32 * k + 8 * g), b1 = *reinterpret_cast<const float4*>(ln + 128 + 32 * k + 8 * g + 4);
         const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
         const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -90,8 +173,15 @@ __device__ __forceinline__ void ln_tokens(const __hip_bfloat16* __restrict__ s, 
     }
 }
 
+__device__ __forceinline__ void ln_rows(const row16 (&v)[4], int lane, const float* ln, float eps, bf16x8 (&yf)[4]) {
+    const uint4 u[4] = {make_uint4(v[0].x, v[0].y, v[0].z, v[0].w), make_uint4(v[1].x, v[1].y, v[1].z, v[1].w),
+                        make_uint4(v[2].x, v[2].y, v[2].z, v[2].w), make_uint4(v[3].x, v[3].y, v[3].z, v[3].w)};
+    ln_rows(u, lane, ln, eps, yf);
+}
+
 // Stage a [rows][128] bf16 weight as A-operand pieces: LDS row r holds source row src_row(r); its 16 chunks of 8 channels are
-// stored at chunk position c ^ (r & 15).  (Fragment read of k-step ks by lane (n, g): chunk 4g + ks of row n.)
+// stored at chunk position c ^ (r & 15).  (Fragment read of k-step ks by lane (n, g): chunk 4ks + g of row n — conflict-free in
+// every 16-lane group ds_read_b128 is served in.)
 template <typename RowMap>
 __device__ __forceinline__ void stage_k128(unsigned char* dst, const __hip_bfloat16* __restrict__ w, int rows, RowMap src_row) {
     for (int i = threadIdx.x; i < rows * 16; i += NAT128_THREADS) {
@@ -136,26 +226,40 @@ __global__ __launch_bounds__(NAT128_THREADS, 1) void nat128_ln_qkv_kernel(const 
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
-    for (long long grp = (long long)blockIdx.x * NAT128_WAVES + wave; grp < groups; grp += (long long)gridDim.x * NAT128_WAVES) {
+    // The rows of the NEXT group are requested as soon as the LayerNorm has consumed the current ones (into the same registers):
+    // they land while the products run, instead of a full memory latency at the head of every group.
+    const long long step = (long long)gridDim.x * NAT128_WAVES;
+    long long grp = (long long)blockIdx.x * NAT128_WAVES + wave;
+    row16 u[4];
+    if (grp < groups) {
+        load_rows_async(s, grp * 16, lane, u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the first group: nothing behind its loads to count
+    }
+    for (; grp < groups; grp += step) {
         const long long tok0 = grp * 16;
         bf16x8 yf[4];
-        ln_tokens(s, tok0, lane, ln, eps, yf);
-        __hip_bfloat16* orow = qkv + (tok0 + n) * QKV_N + 16 * g;
-#pragma unroll 1
-        for (int qd = 0; qd < QKV_TILES / 4; ++qd) {                 // not unrolled: 16 fragment reads in flight are enough
+        rows_landed<2 * (QKV_TILES / 4)>(u);                          // the previous group's 12 stores may still be in flight
+        ln_rows(u, lane, ln, eps, yf);
+        load_rows_async(s, (grp + step < groups ? grp + step : grp) * 16, lane, u);   // (the last group re-reads its own rows)
+        __hip_bfloat16* orow = qkv + (tok0 + n) * QKV_N + 8 * g;
+#pragma unroll
+        for (int qd = 0; qd < QKV_TILES / 4; ++qd) {                 // unrolled so that the compiler can COUNT the stores between the prefetch and
+                                                                     // its use (vmcnt(12) at the head of the next group, not vmcnt(0)); the
+                                                                     // scheduling barriers keep 8 fragment reads in flight, not 96
             f32x4 acc[4];
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const int t = qd * 4 + tt;
                 acc[tt] = *reinterpret_cast<const f32x4*>(bl + t * 16 + 4 * g);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(wl, t * 16 + n, 4 * g + ks, 16), yf[ks], acc[tt], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(wl, t * 16 + n, 4 * ks + g, 16), yf[ks], acc[tt], 0, 0, 0);
                 if (tt & 1) __builtin_amdgcn_sched_barrier(0);
             }
             const uint2 p0 = pack4(acc[0]), p1 = pack4(acc[1]), p2 = pack4(acc[2]), p3 = pack4(acc[3]);
             uint4* dst = reinterpret_cast<uint4*>(orow + qd * 64);
-            dst[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
-            dst[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
+            dst[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);             // channels 64 qd + 8 g .. + 7
+            dst[4] = make_uint4(p2.x, p2.y, p3.x, p3.y);             // channels 64 qd + 32 + 8 g .. + 7
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -190,13 +294,30 @@ __global__ __launch_bounds__(NAT128_THREADS, 1) void nat128_ln_mlp_kernel(__hip_
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
-    for (long long grp = (long long)blockIdx.x * NAT128_WAVES + wave; grp < groups; grp += (long long)gridDim.x * NAT128_WAVES) {
+    // A lane's input channels (32 k + 8 g + e) ARE its output channels (pieces k of the header's map): the accumulators start from
+    // the rows the LayerNorm read — no second read of s in the epilogue — and the rows of the NEXT group are requested into the same
+    // registers as soon as both have consumed them, so they land while the products run.
+    const long long step = (long long)gridDim.x * NAT128_WAVES;
+    long long grp = (long long)blockIdx.x * NAT128_WAVES + wave;
+    uint4 u[4];
+    if (grp < groups) load_rows(s, grp * 16, lane, u);
+    for (; grp < groups; grp += step) {
         const long long tok0 = grp * 16;
         bf16x8 yf[4];
-        ln_tokens(s, tok0, lane, ln, eps, yf);
-        f32x4 acc[8];                                                // starts from `add` (the level's accumulated biases, last layer) or 0
+        if (C128_ABL & 32) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = *reinterpret_cast<const f32x4*>(addl + t * 16 + 4 * g);
+            for (int k = 0; k < 4; ++k) yf[k] = __builtin_bit_cast(bf16x8, u[k]);
+        } else {
+            ln_rows(u, lane, ln, eps, yf);
+        }
+        f32x4 acc[8];                                                // the residual rows + `add` (the level's accumulated biases, last layer) or 0
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(addl + (2 * h) * 16 + 4 * g), c1 = *reinterpret_cast<const f32x4*>(addl + (2 * h + 1) * 16 + 4 * g);
+            acc[2 * h] = f32x4{bf_lo(u[h].x) + c0[0], bf_hi(u[h].x) + c0[1], bf_lo(u[h].y) + c0[2], bf_hi(u[h].y) + c0[3]};
+            acc[2 * h + 1] = f32x4{bf_lo(u[h].z) + c1[0], bf_hi(u[h].z) + c1[1], bf_lo(u[h].w) + c1[2], bf_hi(u[h].w) + c1[3]};
+        }
+        if (!(C128_ABL & 1)) load_rows(s, (grp + step < groups ? grp + step : grp) * 16, lane, u);   // unconditional: see nat128_proj_add_kernel
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             bf16x8 hf[4];
@@ -208,30 +329,35 @@ __global__ __launch_bounds__(NAT128_THREADS, 1) void nat128_ln_mlp_kernel(__hip_
                     const int t = half * 8 + 2 * k + e;
                     h[e] = *reinterpret_cast<const f32x4*>(b1l + t * 16 + 4 * g);
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) h[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(w1l, t * 16 + n, 4 * g + ks, 16), yf[ks], h[e], 0, 0, 0);
+                    for (int ks = 0; ks < 4; ++ks) {
+                        if (C128_ABL & 8) { h[e][ks] += (float)yf[ks][e]; continue; }
+                        h[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(w1l, t * 16 + n, 4 * ks + g, 16), yf[ks], h[e], 0, 0, 0);
+                    }
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) hf[k][e] = (__bf16)gelu_erf128(h[e >> 2][e & 3]);
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 gl = (C128_ABL & 4) ? f32x2{h[e >> 2][e & 3], h[e >> 2][(e & 3) + 1]} : gelu128_pair(f32x2{h[e >> 2][e & 3], h[e >> 2][(e & 3) + 1]});
+                    hf[k][e] = (__bf16)gl.x;
+                    hf[k][e + 1] = (__bf16)gl.y;
+                }
                 __builtin_amdgcn_sched_barrier(0);                   // keep the fragment reads of later steps from being hoisted (spills)
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < 4; ++k) {
+                    if (C128_ABL & 16) { acc[t][k] += (float)hf[k][t]; continue; }
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(w2l, t * 16 + n, (half * 4 + k) * 4 + g, 32), hf[k], acc[t], 0, 0, 0);
+                }
                 if (t & 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __hip_bfloat16* row = s + (tok0 + n) * C128 + 16 * g;
+        uint4* p = reinterpret_cast<uint4*>(s + (tok0 + n) * C128 + 8 * g);
 #pragma unroll
-        for (int qd = 0; qd < 2; ++qd) {
-            uint4* p = reinterpret_cast<uint4*>(row + qd * 64);
-            const uint4 r0 = p[0], r1 = p[1];
-            const f32x4 a0 = acc[qd * 4 + 0], a1 = acc[qd * 4 + 1], a2 = acc[qd * 4 + 2], a3 = acc[qd * 4 + 3];
-            p[0] = make_uint4(pack_bf16x2(bf_lo(r0.x) + a0[0], bf_hi(r0.x) + a0[1]), pack_bf16x2(bf_lo(r0.y) + a0[2], bf_hi(r0.y) + a0[3]),
-                              pack_bf16x2(bf_lo(r0.z) + a1[0], bf_hi(r0.z) + a1[1]), pack_bf16x2(bf_lo(r0.w) + a1[2], bf_hi(r0.w) + a1[3]));
-            p[1] = make_uint4(pack_bf16x2(bf_lo(r1.x) + a2[0], bf_hi(r1.x) + a2[1]), pack_bf16x2(bf_lo(r1.y) + a2[2], bf_hi(r1.y) + a2[3]),
-                              pack_bf16x2(bf_lo(r1.z) + a3[0], bf_hi(r1.z) + a3[1]), pack_bf16x2(bf_lo(r1.w) + a3[2], bf_hi(r1.w) + a3[3]));
+        for (int h = 0; h < 4; ++h) {
+            const uint2 lo = pack4(acc[2 * h]), hi = pack4(acc[2 * h + 1]);
+            if ((C128_ABL & 2) && lo.x != 0x12345678u) continue;      // (keeps the arithmetic alive)
+            p[4 * h] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
     }
 }
@@ -250,33 +376,50 @@ __global__ __launch_bounds__(NAT128_THREADS, 1) void nat128_proj_add_kernel(__hi
     stage_k128(lds, w, C128, [](int r) { return out_channel(r >> 4, r & 15); });
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
-    for (long long grp = (long long)blockIdx.x * NAT128_WAVES + wave; grp < groups; grp += (long long)gridDim.x * NAT128_WAVES) {
-        const long long tok0 = grp * 16;
-        const uint4* src = reinterpret_cast<const uint4*>(a + (tok0 + n) * C128 + 32 * g);
-        __hip_bfloat16* row = s + (tok0 + n) * C128 + 16 * g;
-        uint4 u[4], r[4];
+    // The rows of the NEXT group are requested before the current one is computed: a wave's load -> MFMA -> store chain would
+    // otherwise leave the memory pipe idle for most of a group (16 waves x one group in flight is not enough to cover the latency).
+    const long long step = (long long)gridDim.x * NAT128_WAVES;
+    long long grp = (long long)blockIdx.x * NAT128_WAVES + wave;
+    uint4 u[4], r[4];
+    auto request = [&](long long gq, uint4 (&uu)[4], uint4 (&rr)[4]) {
+        const uint4* src = reinterpret_cast<const uint4*>(a + (gq * 16 + n) * C128 + 8 * g);
+        const uint4* row = reinterpret_cast<const uint4*>(s + (gq * 16 + n) * C128 + 8 * g);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) u[k] = src[k];
+        for (int k = 0; k < 4; ++k) { uu[k] = src[4 * k]; rr[k] = row[4 * k]; }     // rr[k]: channels 32 k + 8 g .. + 7
+    };
+    // Two register sets in turn (no copies: a register move of a loaded value waits for the load it was meant to overlap).
+    auto body = [&](long long gq, uint4 (&uc)[4], uint4 (&rc)[4], uint4 (&un)[4], uint4 (&rn)[4]) {
+        request(gq + step < groups ? gq + step : gq, un, rn);           // unconditional (the last one re-reads its own rows): behind a
+                                                                      // branch the compiler's wait counts fall back to vmcnt(0) at the join
+        asm volatile("" ::: "memory");      // the weight fragments are loop-invariant: hoisted out of the loop they spill (32 x 4 registers)
+        f32x4 acc[8];                                                 // starts from the residual rows (their registers die here)
 #pragma unroll
-        for (int qd = 0; qd < 2; ++qd) { r[2 * qd] = reinterpret_cast<const uint4*>(row + qd * 64)[0]; r[2 * qd + 1] = reinterpret_cast<const uint4*>(row + qd * 64)[1]; }
-        f32x4 acc[8];
+        for (int h = 0; h < 4; ++h) {                                 // 16-byte piece h: channels 32 h + 8 g .. + 7 = tiles 2 h, 2 h + 1
+            acc[2 * h] = f32x4{bf_lo(rc[h].x), bf_hi(rc[h].x), bf_lo(rc[h].y), bf_hi(rc[h].y)};
+            acc[2 * h + 1] = f32x4{bf_lo(rc[h].z), bf_hi(rc[h].z), bf_lo(rc[h].w), bf_hi(rc[h].w)};
+        }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(lds, t * 16 + n, 4 * g + ks, 16), __builtin_bit_cast(bf16x8, u[ks]), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(lds, t * 16 + n, 4 * ks + g, 16), __builtin_bit_cast(bf16x8, uc[ks]), acc[t], 0, 0, 0);
+            if (t & 1) __builtin_amdgcn_sched_barrier(0);            // 8 fragment reads in flight, not 32 (registers)
         }
+        uint4* p = reinterpret_cast<uint4*>(s + (gq * 16 + n) * C128 + 8 * g);
 #pragma unroll
-        for (int qd = 0; qd < 2; ++qd) {
-            uint4* p = reinterpret_cast<uint4*>(row + qd * 64);
-            const uint4 r0 = r[2 * qd], r1 = r[2 * qd + 1];
-            const f32x4 a0 = acc[qd * 4 + 0], a1 = acc[qd * 4 + 1], a2 = acc[qd * 4 + 2], a3 = acc[qd * 4 + 3];
-            p[0] = make_uint4(pack_bf16x2(bf_lo(r0.x) + a0[0], bf_hi(r0.x) + a0[1]), pack_bf16x2(bf_lo(r0.y) + a0[2], bf_hi(r0.y) + a0[3]),
-                              pack_bf16x2(bf_lo(r0.z) + a1[0], bf_hi(r0.z) + a1[1]), pack_bf16x2(bf_lo(r0.w) + a1[2], bf_hi(r0.w) + a1[3]));
-            p[1] = make_uint4(pack_bf16x2(bf_lo(r1.x) + a2[0], bf_hi(r1.x) + a2[1]), pack_bf16x2(bf_lo(r1.y) + a2[2], bf_hi(r1.y) + a2[3]),
-                              pack_bf16x2(bf_lo(r1.z) + a3[0], bf_hi(r1.z) + a3[1]), pack_bf16x2(bf_lo(r1.w) + a3[2], bf_hi(r1.w) + a3[3]));
+        for (int h = 0; h < 4; ++h) {
+            const uint2 lo = pack4(acc[2 * h]), hi = pack4(acc[2 * h + 1]);
+            p[4 * h] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
+    };
+    uint4 u2[4], r2[4];
+    if (grp < groups) request(grp, u, r);
+    while (grp < groups) {
+        body(grp, u, r, u2, r2);
+        grp += step;
+        if (grp >= groups) break;
+        body(grp, u2, r2, u, r);
+        grp += step;
     }
 }
 
