@@ -16,6 +16,11 @@
 // A modes:  DENSE   A is [M][lda] row-major;
 //           CONV3   A is an NHWC image [B][H][W][Cin]; row m = output pixel (stride 1 or 2, padding 1), k = (ky*3 + kx)*Cin + ci;
 //                   out-of-image taps read a zero line.  Cin % 64 == 0.  B is then [N][9*Cin] with the same k order.
+//                   The k-tiles are WALKED channel block by channel block (all 9 taps of 64 channels, then the next 64): the taps of
+//                   a block re-read the same pixels' 128 bytes shifted by a pixel or a row, so the tiles an XCD has in flight touch
+//                   ~1 MB per 9 k-tiles and the re-reads hit its L2; tap-major (the memory order of k) the nine visits of a pixel lie
+//                   Cin / 64 k-tiles apart with 4 MB of other rows in between, and every visit came from HBM (FETCH_SIZE 6.4 GB for
+//                   the 1 GB image of the SETR-UP head's last stage).
 // Epilogues: see Epi.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -144,7 +149,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
         }
     };
     const __bf16* zero_src = (AMODE == CONV3) ? p.zero + (lane & 7) * 8 : nullptr;
-    const int k_per_tap = (AMODE == CONV3) ? p.Cin / BK : 1;
 
     // op: 0 = A, 1 = B.  Issues the two LDS-DMA instructions of unit `u` of k-tile `kt` of tile `t` into buffer `par`.
     const char* baseA = reinterpret_cast<const char*>(p.A);
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
 #pragma unroll
                 for (int j = 0; j < 2; ++j) glds16(baseA + (t.a[u][j] + (uint32_t)(kt * BK * 2)), buf + a_block(u, j) * 1024);
             } else {
-                const int tap = kt / k_per_tap, c0 = (kt - tap * k_per_tap) * BK;
+                const int cblk = kt / 9, tap = kt - cblk * 9, c0 = cblk * BK;
                 const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
                 const int off = ((dy * p.W + dx) * p.Cin + c0) * 2;
 #pragma unroll
@@ -166,8 +170,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
                 }
             }
         } else {
+            int kb = kt * BK;                                          // element offset of the k-tile in a row of B
+            if (AMODE == CONV3) { const int cblk = kt / 9, tap = kt - cblk * 9; kb = tap * p.Cin + cblk * BK; }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(baseB + (t.b[u][j] + (uint32_t)(kt * BK * 2)), buf + TILE_BYTES + b_block(u, j) * 1024);
+            for (int j = 0; j < 2; ++j) glds16(baseB + (t.b[u][j] + (uint32_t)(kb * 2)), buf + TILE_BYTES + b_block(u, j) * 1024);
         }
     };
 

@@ -89,7 +89,7 @@ static int run_dense(int M, int N, int K, int epi, int iters) {
 }
 
 static int run_conv(int Bn, int H, int W, int Cin, int Cout, int epi, int iters) {
-    const int M = Bn * H * W, K = 9 * Cin, N = Cout;
+    const int M = Bn * H * W, K = 9 * Cin, N = Cout, slots = (N + 63) / 64;
     std::vector<uint16_t> hA((size_t)M * Cin), hB((size_t)N * K);
     std::vector<float> hbias(N), hw2(2 * N);
     for (auto& v : hA) v = f2bf(urand());
@@ -98,8 +98,8 @@ static int run_conv(int Bn, int H, int W, int Cin, int Cout, int epi, int iters)
     for (auto& v : hw2) v = urand() * 0.1f;
     __bf16 *dA, *dB, *dC, *dz; float *dbias, *dw2, *dlog;
     CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dB, hB.size() * 2)); CK(hipMalloc(&dC, (size_t)M * N * 2)); CK(hipMalloc(&dz, 256));
-    CK(hipMalloc(&dbias, N * 4)); CK(hipMalloc(&dw2, 2 * N * 4)); CK(hipMalloc(&dlog, (size_t)M * 2 * 4));
-    CK(hipMemset(dz, 0, 256)); CK(hipMemset(dlog, 0, (size_t)M * 8));
+    CK(hipMalloc(&dbias, N * 4)); CK(hipMalloc(&dw2, 2 * N * 4)); CK(hipMalloc(&dlog, (size_t)slots * M * 2 * 4));       // EPI_RELU_DOT2 writes one partial sum per 64 columns: [N / 64][M][2]
+    CK(hipMemset(dz, 0, 256)); CK(hipMemset(dlog, 0, (size_t)slots * M * 8));
     CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dbias, hbias.data(), N * 4, hipMemcpyHostToDevice));
@@ -111,7 +111,7 @@ static int run_conv(int Bn, int H, int W, int Cin, int Cout, int epi, int iters)
     go();
     CK(hipDeviceSynchronize());
     std::vector<uint16_t> out((size_t)M * N);
-    std::vector<float> logit((size_t)M * 2);
+    std::vector<float> logit((size_t)slots * M * 2);
     CK(hipMemcpy(out.data(), dC, out.size() * 2, hipMemcpyDeviceToHost));
     CK(hipMemcpy(logit.data(), dlog, logit.size() * 4, hipMemcpyDeviceToHost));
     double max_err = 0, max_ref = 0;
@@ -139,7 +139,9 @@ static int run_conv(int Bn, int H, int W, int Cin, int Cout, int epi, int iters)
         }
         if (epi == EPI_RELU_DOT2) {
             for (int c = 0; c < 2; ++c) {
-                const double ref = c ? l1 : l0, got = logit[(size_t)m * 2 + c], err = fabs(got - ref);
+                double got = 0;
+                for (int sl = 0; sl < slots; ++sl) got += logit[((size_t)sl * M + m) * 2 + c];
+                const double ref = c ? l1 : l0, err = fabs(got - ref);
                 max_err = fmax(max_err, err); max_ref = fmax(max_ref, fabs(ref));
                 if (err > 2e-3 * fmax(1.0, fabs(ref))) { if (bad < 5) printf("   mismatch m=%d c=%d got %f ref %f\n", m, c, got, ref); ++bad; }
             }
@@ -162,6 +164,11 @@ int main(int argc, char** argv) {
     { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); g_cus = pr.multiProcessorCount; printf("CUs: %d\n", g_cus); }
     int bad = 0;
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+    if (argc > 1 && !strcmp(argv[1], "conv64")) {          // the SETR-UP head's last stage alone (for counter passes)
+        bad += run_conv(256, 64, 64, 512, 512, EPI_RELU_DOT2, 5);
+        bad += run_dense(16384, 4096, 4096, EPI_BIAS, 5);
+        return bad != 0;
+    }
     // small, ragged: correctness of clamping / partial tiles
     bad += run_dense(300, 264, 128, EPI_BIAS, 2);
     bad += run_dense(512, 256, 64, EPI_ACCUM, 2);
