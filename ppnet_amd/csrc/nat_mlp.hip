@@ -94,6 +94,24 @@ __device__ __forceinline__ float gelu_logistic(float x) {
     const float t = x * (2.3009787f + x2 * (0.10690469f - 1.0350827e-3f * x2));
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-t));
 }
+// the polynomial form of nat_c128.hip (no transcendental; |error| <= 9.2e-5)
+__device__ __forceinline__ float gelu_poly(float v) {
+    constexpr float K[8] = {3.984200563e-01f, -6.545352466e-02f, 9.257837137e-03f, -9.404510850e-04f, 6.552754503e-05f, -2.938833893e-06f,
+                            7.570944350e-08f, -8.460567657e-10f};
+    const float vc = __builtin_amdgcn_fmed3f(v, -4.25f, 4.25f), u = vc * vc;
+    float q = K[7];
+#pragma unroll
+    for (int k = 6; k >= 0; --k) q = fmaf(q, u, K[k]);
+    return v * fmaf(vc, q, 0.5f);
+}
+#ifndef NMLP_GELU_SCALAR
+#define NMLP_GELU_SCALAR 2      // 0 = logistic fit, two values per instruction (A/B builds), 1 = the same one value per instruction, 2 = polynomial one value per instruction (ships)
+#endif
+#if NMLP_GELU_SCALAR == 2
+#define NMLP_GELU_FN gelu_poly
+#else
+#define NMLP_GELU_FN gelu_logistic
+#endif
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 // two at a time: the multiplies / adds as packed float32 instructions (v_pk_mul_f32, v_pk_fma_f32)
 __device__ __forceinline__ f32x2 gelu_logistic2(f32x2 x) {
@@ -300,8 +318,22 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
                     acc[o][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[o], hf[1], acc[o][1], 0, 0, 0);
                 }
             };
-            auto gelu = [&]() __attribute__((always_inline)) {             // the 8 values this lane owns, two per instruction
+            auto gelu = [&]() __attribute__((always_inline)) {             // the 8 values this lane owns
                 const f32x4 c0 = lds_f4(hbj), c1 = lds_f4(hbj + 4);       // (cs, b1') of hidden units r = 0, 1 | 2, 3
+#if NMLP_GELU_SCALAR
+                // one value per instruction: beside MFMAs a packed float32 operation costs more issue time than the two plain ones it
+                // replaces (MI355X_MICROARCH.md, cycle constants)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const float cs[4] = {c0[0], c0[2], c1[0], c1[2]}, bb[4] = {c0[1], c0[3], c1[1], c1[3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = fmaf(P[tt][r], rstd[tt], fmaf(nmr[tt], cs[r], bb[r]));
+                        hv[tt][r] = (NMLP_ABL & 2) ? v : NMLP_GELU_FN(v);
+                    }
+                }
+                return;
+#endif
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     const f32x2 rs = {rstd[tt], rstd[tt]}, nm = {nmr[tt], nmr[tt]};
