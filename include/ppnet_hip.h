@@ -313,6 +313,17 @@ int ppn_upsample2x_add_nhwc(const void* x, const void* add, void* y, int32_t B, 
  * float32, 1 bfloat16. */
 int ppn_resize_concat4_nhwc(const void* x0, const void* x1, const void* x2, const void* x3, const int32_t* hw, void* out, int32_t B, int32_t C,
                             int32_t dtype, void* stream);
+/* The general form: n <= 8 NHWC tensors x[l] [B][hw[2 l]][hw[2 l + 1]][channels[l]] (HOST arrays of pointers / sizes; channels % 8 == 0),
+ * each resized (bilinear, align_corners False; a tensor of level 0's size is copied) to level 0's size and written to its channel
+ * range of out [B][H0][W0][sum channels].  Also the pyramid pooling module's output, psp_head.py:48-60 + uper_head.py:76-84:
+ * `torch.cat([x] + [resize(ppm(x), size=x.shape[2:], mode='bilinear')...], dim=1)` with the pooled maps smaller than x. */
+int ppn_resize_concat_nhwc(const void* const* x, const int32_t* hw, const int32_t* channels, int32_t n, void* out, int32_t B, int32_t dtype,
+                           void* stream);
+/* The pyramid pooling module's pools (psp_head.py:33-38: `nn.AdaptiveAvgPool2d(s)` for each pool scale) of one NHWC tensor
+ * x [B][H][W][C] in one launch: y[k] [B][scales[k]][scales[k]][C], k < n <= 4 (HOST arrays), PyTorch's bins
+ * (rows floor(i H / s) .. ceil((i + 1) H / s) - 1), summed in float32.  C % 8 == 0. */
+int ppn_adaptive_pools_nhwc(const void* x, void* const* y, const int32_t* scales, int32_t n, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                            void* stream);
 /* SegNet's input straight from stage B's occupancy codes: img [n_pixels][3] (NHWC) = (rgb - mean3) / std3 with rgb = (255,255,255)
  * for PPN_GRID_FREE, (255,0,0) for PPN_GRID_MARK, (0,0,0) otherwise (process_map.py:120,128; planning_seg.py:12-41).
  * mean3 / std3 are HOST pointers to three floats; n_pixels a multiple of 8. */

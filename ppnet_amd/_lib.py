@@ -50,7 +50,7 @@ EXPORTS = ("ppn_version", "ppn_error_string", "ppn_last_hip_error", "ppn_polyfit
            "ppn_edage_paths_ex", "ppn_edage_paths_ex2", "ppn_edage_maps", "ppn_edage_maps_place", "ppn_edage_maps_raster",
            "ppn_label_masks", "ppn_boundary_check", "ppn_boundary_check_ex",
            "ppn_obstacle_filter", "ppn_paint_markers", "ppn_disc_raster", "ppn_collision_segments", "ppn_collision_segments_bound",
-           "ppn_extract_paths", "ppn_resize_bilinear_u8", "ppn_philox_doubles", "ppn_na2d_fwd", "ppn_na2d_fwd_padded", "ppn_na2d_fwd_vpad", "ppn_na2d_bwd", "ppn_na2d_bwd_workspace", "ppn_residual_layernorm", "ppn_residual_layernorm_padded", "ppn_layernorm_offset", "ppn_upsample2x_nhwc", "ppn_resize_concat4_nhwc", "ppn_upsample2x_add_nhwc", "ppn_upsample2x_nhwc_bias", "ppn_bias_act_nhwc", "ppn_seg_labels_2class", "ppn_grid_to_image", "ppn_conv3x3_c1_nhwc", "ppn_conv3x3_to1_nhwc",
+           "ppn_extract_paths", "ppn_resize_bilinear_u8", "ppn_philox_doubles", "ppn_na2d_fwd", "ppn_na2d_fwd_padded", "ppn_na2d_fwd_vpad", "ppn_na2d_bwd", "ppn_na2d_bwd_workspace", "ppn_residual_layernorm", "ppn_residual_layernorm_padded", "ppn_layernorm_offset", "ppn_upsample2x_nhwc", "ppn_resize_concat4_nhwc", "ppn_resize_concat_nhwc", "ppn_adaptive_pools_nhwc", "ppn_upsample2x_add_nhwc", "ppn_upsample2x_nhwc_bias", "ppn_bias_act_nhwc", "ppn_seg_labels_2class", "ppn_grid_to_image", "ppn_conv3x3_c1_nhwc", "ppn_conv3x3_to1_nhwc",
            "ppn_conv3x3_mfma_bf16", "ppn_conv3x3_relu_classify2_bf16", "ppn_conv3x3_relu_classify2_slots", "ppn_gemm_bf16", "ppn_nat_gemm_bf16", "ppn_nat_gemm_partials", "ppn_row_stats_bf16", "ppn_nat_mlp_supported", "ppn_nat_mlp_pack_bf16", "ppn_nat_mlp_bf16", "ppn_gennet_conv_s2_bf16", "ppn_gennet_trunk_bf16",
            "ppn_assemble_paths", "ppn_plan_collision", "ppn_gennet_first_enc_bf16", "ppn_gennet_dec_final_bf16", "ppn_heatmap_u8", "ppn_tokenizer_conv1_codes_bf16", "ppn_tokenizer_codes_bf16", "ppn_nat128_ln_qkv_bf16", "ppn_nat128_ln_mlp_bf16", "ppn_nat128_ln_mlp_add_bf16", "ppn_nat128_proj_add_bf16")
 
@@ -103,6 +103,8 @@ def _load():
                                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p]
     lib.ppn_layernorm_offset.argtypes = [_p, _p, _p, _p, _p, C.c_int64, C.c_int32, C.c_float, C.c_int32, _p]
     lib.ppn_upsample2x_add_nhwc.argtypes = [_p, _p, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p]
+    lib.ppn_resize_concat_nhwc.argtypes = [C.POINTER(_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, _p, C.c_int32, C.c_int32, _p]
+    lib.ppn_adaptive_pools_nhwc.argtypes = [_p, C.POINTER(_p), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p]
     lib.ppn_resize_concat4_nhwc.argtypes = [_p, _p, _p, _p, C.POINTER(C.c_int32), _p, C.c_int32, C.c_int32, C.c_int32, _p]
     lib.ppn_upsample2x_nhwc.argtypes = [_p, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p]
     lib.ppn_upsample2x_nhwc_bias.argtypes = [_p, _p, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p]

@@ -413,12 +413,29 @@ int ppn_upsample2x_add_nhwc(const void* x, const void* add, void* y, int32_t B, 
 int ppn_resize_concat4_nhwc(const void* x0, const void* x1, const void* x2, const void* x3, const int32_t* hw, void* out, int32_t B, int32_t C,
                             int32_t dtype, void* stream) {
     if (!x0 || !x1 || !x2 || !x3 || !hw || !out || B <= 0 || C <= 0 || (C % 8) != 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
-    for (int l = 0; l < 4; ++l)
-        if (hw[2 * l] <= 0 || hw[2 * l + 1] <= 0 || hw[2 * l] > hw[0] || hw[2 * l + 1] > hw[1]) return PPN_E_INVALID;
     const void* x[4] = {x0, x1, x2, x3};
-    int h[8];
-    for (int k = 0; k < 8; ++k) h[k] = hw[k];
-    const int e = ppn::resize_concat4_launch(x, h, out, B, C, dtype, (hipStream_t)stream);
+    const int32_t ch[4] = {C, C, C, C};
+    return ppn_resize_concat_nhwc(x, hw, ch, 4, out, B, dtype, stream);
+}
+
+int ppn_resize_concat_nhwc(const void* const* x, const int32_t* hw, const int32_t* channels, int32_t n, void* out, int32_t B, int32_t dtype, void* stream) {
+    if (!x || !hw || !channels || !out || n <= 0 || n > 8 || B <= 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
+    int h[16], ch[8];
+    for (int l = 0; l < n; ++l) {
+        if (!x[l] || hw[2 * l] <= 0 || hw[2 * l + 1] <= 0 || channels[l] <= 0 || (channels[l] % 8) != 0) return PPN_E_INVALID;
+        h[2 * l] = hw[2 * l]; h[2 * l + 1] = hw[2 * l + 1]; ch[l] = channels[l];
+    }
+    const int e = ppn::resize_concat_launch(x, h, ch, n, out, B, dtype, (hipStream_t)stream);
+    if (e != 0) return hip_fail((hipError_t)e);
+    return PPN_OK;
+}
+
+int ppn_adaptive_pools_nhwc(const void* x, void* const* y, const int32_t* scales, int32_t n, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                            void* stream) {
+    if (!x || !y || !scales || n <= 0 || n > 4 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0 || (dtype != 0 && dtype != 1)) return PPN_E_INVALID;
+    int sc[4];
+    for (int k = 0; k < n; ++k) { if (!y[k] || scales[k] <= 0) return PPN_E_INVALID; sc[k] = scales[k]; }
+    const int e = ppn::adaptive_pools_launch(x, y, sc, n, B, H, W, C, dtype, (hipStream_t)stream);
     if (e != 0) return hip_fail((hipError_t)e);
     return PPN_OK;
 }

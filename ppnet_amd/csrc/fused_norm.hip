@@ -220,28 +220,32 @@ int upsample2x_launch(const void* x, const void* bias, const void* add, void* y,
     return (int)hipGetLastError();
 }
 
-// UPerHead's FPN output assembly (uper_head.py:117-127: every FPN level resized to the finest one's size, bilinear, align_corners
-// False, then concatenated over channels) as ONE pass over NHWC tensors: out[b][i][j][l * C + c] = resize(x_l)[b][i][j][c], level 0
-// copied.  One thread per 8 channels of one (pixel, level), the level = blockIdx.y (uniform: its geometry stays in scalars, a wave
-// stores eight 16 C-byte runs); each output uses PyTorch's formula for its coordinate (source index
-// scale * (dst + 0.5) - 0.5 clamped at 0 with scale = in / out as a float, the four taps weighted in float32: upsample_bilinear2d).
-// Replaces three interpolate launches, the concatenation and the channels_last copy behind it (5 passes over the 4C-channel tensor).
-struct Concat4Params {
-    const void* x[4];
-    int H[4], W[4];
+// Resize + channel concatenation of up to 8 NHWC tensors in ONE pass: out[b][i][j][off_l + c] = resize(x_l)[b][i][j][c], level 0 (and any
+// level of its size) copied.  Two places of UPerHead use it: the FPN output assembly (uper_head.py:117-127: every FPN level resized
+// to the finest one's size, then concatenated: 4 levels of `channels`) and the pyramid pooling module's output (psp_head.py:48-60 +
+// uper_head.py:76-84: the input and its 1 / 2 / 3 / 6-bin pooled, projected copies resized back: 1024 + 4 x `channels`).  One thread
+// per 8 channels of one (pixel, level), the level = blockIdx.y (uniform: its geometry stays in scalars, a wave stores runs of whole
+// 16-byte pieces); each output uses PyTorch's formula for its coordinate (source index scale * (dst + 0.5) - 0.5 clamped at 0 with
+// scale = in / out as a float, the four taps weighted in float32: upsample_bilinear2d, align_corners False).  Replaces, for the FPN,
+// three interpolate launches, the concatenation and the channels_last copy behind it.
+struct ConcatParams {
+    const void* x[8];
+    int H[8], W[8], C[8], off[8];
+    int Ctot;
 };
 template <typename T>
-__global__ __launch_bounds__(256) void resize_concat4_kernel(Concat4Params p, T* __restrict__ out, int B, int C) {
-    const int cg = C >> 3;
+__global__ __launch_bounds__(256) void resize_concat_kernel(ConcatParams p, T* __restrict__ out, int B) {
+    const int l = (int)blockIdx.y;
+    const int cg = p.C[l] >> 3;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int H0 = p.H[0], W0 = p.W[0];
     if (idx >= (long long)B * H0 * W0 * cg) return;
-    const int g = (int)(idx % cg), l = (int)blockIdx.y;
+    const int g = (int)(idx % cg);
     const long long pix = idx / cg;
     const int j = (int)(pix % W0), i = (int)((pix / W0) % H0), b = (int)(pix / ((long long)W0 * H0));
-    const int Hl = p.H[l], Wl = p.W[l];
+    const int Hl = p.H[l], Wl = p.W[l], C = p.C[l];
     const T* src = reinterpret_cast<const T*>(p.x[l]) + (size_t)b * Hl * Wl * C + g * 8;
-    T* dst = out + ((size_t)pix * 4 + l) * C + g * 8;
+    T* dst = out + (size_t)pix * p.Ctot + p.off[l] + g * 8;
     float o[8];
     if (Hl == H0 && Wl == W0) {
         Vec8<T>::load(src + ((size_t)i * Wl + j) * C, o);
@@ -262,14 +266,63 @@ __global__ __launch_bounds__(256) void resize_concat4_kernel(Concat4Params p, T*
     Vec8<T>::store(dst, o);
 }
 
-int resize_concat4_launch(const void* const* x, const int* hw, void* out, int B, int C, int dtype, hipStream_t stream) {
-    Concat4Params p;
-    for (int l = 0; l < 4; ++l) { p.x[l] = x[l]; p.H[l] = hw[2 * l]; p.W[l] = hw[2 * l + 1]; }
-    const long long total = (long long)B * p.H[0] * p.W[0] * (C / 8);
+int resize_concat_launch(const void* const* x, const int* hw, const int* ch, int n, void* out, int B, int dtype, hipStream_t stream) {
+    ConcatParams p;
+    int off = 0, cmax = 0;
+    for (int l = 0; l < 8; ++l) {
+        const int k = l < n ? l : 0;
+        p.x[l] = x[k]; p.H[l] = hw[2 * k]; p.W[l] = hw[2 * k + 1]; p.C[l] = ch[k]; p.off[l] = off;
+        if (l < n) { off += ch[l]; cmax = ch[l] > cmax ? ch[l] : cmax; }
+    }
+    p.Ctot = off;
+    const long long total = (long long)B * p.H[0] * p.W[0] * (cmax / 8);
     if ((total + 255) / 256 >= (1LL << 31)) return (int)hipErrorInvalidValue;
-    const dim3 grid((unsigned)((total + 255) / 256), 4);
-    if (dtype == 0) hipLaunchKernelGGL(resize_concat4_kernel<float>, grid, dim3(256), 0, stream, p, (float*)out, B, C);
-    else hipLaunchKernelGGL(resize_concat4_kernel<__hip_bfloat16>, grid, dim3(256), 0, stream, p, (__hip_bfloat16*)out, B, C);
+    const dim3 grid((unsigned)((total + 255) / 256), (unsigned)n);
+    if (dtype == 0) hipLaunchKernelGGL(resize_concat_kernel<float>, grid, dim3(256), 0, stream, p, (float*)out, B);
+    else hipLaunchKernelGGL(resize_concat_kernel<__hip_bfloat16>, grid, dim3(256), 0, stream, p, (__hip_bfloat16*)out, B);
+    return (int)hipGetLastError();
+}
+
+// The pyramid pooling module's adaptive average pools (psp_head.py:33-38: nn.AdaptiveAvgPool2d(s) for s in pool_scales) of one NHWC
+// tensor in ONE launch: y_k [B][s_k][s_k][C], bin (i, j) = the mean over rows floor(i H / s) .. ceil((i + 1) H / s) - 1 and the
+// columns alike (PyTorch's bins), summed in float32.  One thread per 8 channels of one bin; blockIdx.y = the scale.
+struct PoolParams {
+    void* y[4];
+    int s[4];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void adaptive_pools_kernel(const T* __restrict__ x, PoolParams p, int B, int H, int W, int C) {
+    const int k = (int)blockIdx.y, s = p.s[k], cg = C >> 3;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * s * s * cg) return;
+    const int g = (int)(idx % cg);
+    const long long bin = idx / cg;
+    const int j = (int)(bin % s), i = (int)((bin / s) % s), b = (int)(bin / ((long long)s * s));
+    const int r0 = (i * H) / s, r1 = ((i + 1) * H + s - 1) / s, c0 = (j * W) / s, c1 = ((j + 1) * W + s - 1) / s;
+    const T* src = x + (size_t)b * H * W * C + g * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r1; ++r)
+        for (int c = c0; c < c1; ++c) {
+            float v[8];
+            Vec8<T>::load(src + ((size_t)r * W + c) * C, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+    const float inv = (float)((r1 - r0) * (c1 - c0));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = acc[e] / inv;
+    Vec8<T>::store(reinterpret_cast<T*>(p.y[k]) + (size_t)bin * C + g * 8, acc);
+}
+
+int adaptive_pools_launch(const void* x, void* const* y, const int* scales, int n, int B, int H, int W, int C, int dtype, hipStream_t stream) {
+    PoolParams p;
+    int smax = 0;
+    for (int k = 0; k < 4; ++k) { p.y[k] = y[k < n ? k : 0]; p.s[k] = scales[k < n ? k : 0]; if (k < n && scales[k] > smax) smax = scales[k]; }
+    const long long total = (long long)B * smax * smax * (C / 8);
+    if ((total + 255) / 256 >= (1LL << 31)) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)((total + 255) / 256), (unsigned)n);
+    if (dtype == 0) hipLaunchKernelGGL(adaptive_pools_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, p, B, H, W, C);
+    else hipLaunchKernelGGL(adaptive_pools_kernel<__hip_bfloat16>, grid, dim3(256), 0, stream, (const __hip_bfloat16*)x, p, B, H, W, C);
     return (int)hipGetLastError();
 }
 

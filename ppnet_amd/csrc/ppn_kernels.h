@@ -121,7 +121,8 @@ int na2d_bwd_launch(const void* qkv, const float* rpb, const void* dout, void* d
 int norm_launch(const void* x, const void* a, const void* gamma, const void* w, const void* b, void* x_out, void* y_out,
                 long long rows, int C, float eps, int dtype, int Hr, int Wr, int Hp, int Wp, const void* xoff, hipStream_t stream);
 
-int resize_concat4_launch(const void* const* x, const int* hw, void* out, int B, int C, int dtype, hipStream_t stream);
+int resize_concat_launch(const void* const* x, const int* hw, const int* ch, int n, void* out, int B, int dtype, hipStream_t stream);
+int adaptive_pools_launch(const void* x, void* const* y, const int* scales, int n, int B, int H, int W, int C, int dtype, hipStream_t stream);
 int upsample2x_launch(const void* x, const void* bias, const void* add, void* y, int B, int H, int W, int C, int relu, int dtype, hipStream_t stream);
 int conv3x3_c1_launch(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cout, float slope, int dtype,
                       hipStream_t stream);

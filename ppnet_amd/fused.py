@@ -178,24 +178,50 @@ def upsample2x_add_(fine, coarse):
     return fine
 
 
-def resize_concat4(levels):
-    """UPerHead's FPN output assembly (uper_head.py:117-127) for four channels_last [B,C,H_l,W_l] tensors, finest first: every
-    level bilinearly resized (align_corners=False) to the finest one's size and concatenated over channels, in ONE kernel
-    (ppn_resize_concat4_nhwc).  Returns a channels_last [B,4C,H_0,W_0] tensor."""
-    assert len(levels) == 4
+def resize_concat(levels):
+    """Up to eight channels_last [B,C_l,H_l,W_l] tensors, each bilinearly resized (align_corners=False) to the FIRST one's size and
+    concatenated over channels in ONE kernel (ppn_resize_concat_nhwc): UPerHead's FPN output assembly (uper_head.py:117-127) and
+    its pyramid pooling module's output (psp_head.py:48-60).  Returns a channels_last [B, sum C_l, H_0, W_0] tensor."""
+    assert 1 <= len(levels) <= 8
     xs = []
     for t in levels:
         x = t.permute(0, 2, 3, 1)
         xs.append(x if x.is_contiguous() else x.contiguous())
-    B, H0, W0, C = xs[0].shape
-    assert all(x.is_cuda and x.dtype == xs[0].dtype and x.shape[0] == B and x.shape[3] == C for x in xs) and xs[0].dtype in _DT
-    out = torch.empty(B, H0, W0, 4 * C, dtype=xs[0].dtype, device=xs[0].device)
-    hw = (ctypes.c_int32 * 8)(*[v for x in xs for v in (x.shape[1], x.shape[2])])
+    B, H0, W0, _ = xs[0].shape
+    assert all(x.is_cuda and x.dtype == xs[0].dtype and x.shape[0] == B and x.shape[3] % 8 == 0 for x in xs) and xs[0].dtype in _DT
+    n = len(xs)
+    out = torch.empty(B, H0, W0, sum(x.shape[3] for x in xs), dtype=xs[0].dtype, device=xs[0].device)
+    ptrs = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
+    hw = (ctypes.c_int32 * (2 * n))(*[v for x in xs for v in (x.shape[1], x.shape[2])])
+    ch = (ctypes.c_int32 * n)(*[x.shape[3] for x in xs])
     with torch.cuda.device(out.device):
-        rc = L.lib.ppn_resize_concat4_nhwc(_p(xs[0]), _p(xs[1]), _p(xs[2]), _p(xs[3]), hw, _p(out), B, C, _DT[xs[0].dtype],
-                                           ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream))
-    L.check(rc, "ppn_resize_concat4_nhwc")
+        rc = L.lib.ppn_resize_concat_nhwc(ptrs, hw, ch, n, _p(out), B, _DT[xs[0].dtype], ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream))
+    L.check(rc, "ppn_resize_concat_nhwc")
     return out.permute(0, 3, 1, 2)
+
+
+def resize_concat4(levels):
+    """The four-level form (UPerHead's FPN output assembly)."""
+    assert len(levels) == 4
+    return resize_concat(levels)
+
+
+def adaptive_pools(x_nchw_cl, scales):
+    """nn.AdaptiveAvgPool2d(s) for every s in `scales` (<= 4) of one channels_last [B,C,H,W] tensor in ONE kernel
+    (ppn_adaptive_pools_nhwc; psp_head.py:33-38).  Returns channels_last [B,C,s,s] tensors."""
+    x = x_nchw_cl.permute(0, 2, 3, 1)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, H, W, C = x.shape
+    n = len(scales)
+    assert x.is_cuda and x.dtype in _DT and 1 <= n <= 4 and C % 8 == 0
+    ys = [torch.empty(B, s, s, C, dtype=x.dtype, device=x.device) for s in scales]
+    ptrs = (ctypes.c_void_p * n)(*[y.data_ptr() for y in ys])
+    sc = (ctypes.c_int32 * n)(*[int(s) for s in scales])
+    with torch.cuda.device(x.device):
+        rc = L.lib.ppn_adaptive_pools_nhwc(_p(x), ptrs, sc, n, B, H, W, C, _DT[x.dtype], ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    L.check(rc, "ppn_adaptive_pools_nhwc")
+    return [y.permute(0, 3, 1, 2) for y in ys]
 
 
 def bias_act_(x_nchw_cl, bias, negative_slope):

@@ -586,9 +586,10 @@ class UPerHead(nn.Module):
         """uper_head.py:76-127 with every convolution on the hand-written kernels: 1x1 ConvModules (laterals, pyramid pooling) are
         ppn_gemm_bf16 over the NHWC tokens with bias + ReLU in the epilogue, 3x3 ConvModules the implicit-GEMM kernel
         (ppn_conv3x3_mfma_bf16), the last one fused with the 1x1 classifier (ppn_conv3x3_relu_classify2_bf16: the 64-channel
-        activation at the highest resolution is never written); x2 resizes on the NHWC up-sampling kernel.  What stays on the
-        framework: the adaptive average pools of the pyramid (4 tiny reductions of the 8 x 8 level), the x4 / x8 resizes of the
-        coarse FPN outputs and the channel concatenations."""
+        activation at the highest resolution is never written); the FPN's top-down step, the resize + concatenation of its outputs
+        and the pyramid pooling module's pools and output assembly on NHWC kernels (ppn_upsample2x_add_nhwc, ppn_resize_concat_nhwc,
+        ppn_adaptive_pools_nhwc).  Nothing of the head runs on framework kernels but the 1x1 ConvModule of a pool scale with fewer
+        than 256 pooled positions in the batch."""
         if self._packs is None:
             self._packs = fused.WeightCache()
         cms = [m[1] for m in self.psp_modules] + [self.bottleneck] + list(self.lateral_convs) + list(self.fpn_convs) + [self.fpn_bottleneck]
@@ -625,9 +626,16 @@ class UPerHead(nn.Module):
             return F.relu(y) if relu else y
         inputs = [inputs[i] for i in self.in_index]
         x = inputs[-1]
-        psp = torch.cat([x] + [self._resize(conv1(m[1], m[0](x)), x.shape[2:]) for m in self.psp_modules], dim=1)
-        laterals = [conv1(cm, inputs[i]) for i, cm in enumerate(self.lateral_convs)] + [conv3(self.bottleneck, psp.contiguous(memory_format=torch.channels_last))]
-        own_resize = not self.align_corners and laterals[0].shape[1] % 8 == 0 and not os.environ.get("PPNET_UPER_UNFUSED_RESIZE")
+        own_resize = not self.align_corners and self.conv_seg.in_channels % 8 == 0 and not os.environ.get("PPNET_UPER_UNFUSED_RESIZE")
+        scales = [m[0].output_size if isinstance(m[0].output_size, int) else m[0].output_size[0] for m in self.psp_modules]
+        if own_resize and len(scales) <= 4 and x.shape[1] % 8 == 0:
+            # the pyramid pooling module (psp_head.py:48-60) as 6 launches: every pool in one kernel, a 1x1 ConvModule each on the
+            # GEMM kernel (B s^2 rows), the resizes back + the concatenation with x in one kernel
+            pooled = fused.adaptive_pools(x, scales)
+            psp = fused.resize_concat([x] + [conv1(m[1], t) for m, t in zip(self.psp_modules, pooled)])
+        else:
+            psp = torch.cat([x] + [self._resize(conv1(m[1], m[0](x)), x.shape[2:]) for m in self.psp_modules], dim=1).contiguous(memory_format=torch.channels_last)
+        laterals = [conv1(cm, inputs[i]) for i, cm in enumerate(self.lateral_convs)] + [conv3(self.bottleneck, psp)]
         for i in range(len(laterals) - 1, 0, -1):
             fine, coarse = laterals[i - 1], laterals[i]
             if (own_resize and fine.shape[2] == 2 * coarse.shape[2] and fine.shape[3] == 2 * coarse.shape[3]
@@ -637,7 +645,7 @@ class UPerHead(nn.Module):
                 laterals[i - 1] = fine + self._resize(coarse, fine.shape[2:])
         outs = [conv3(self.fpn_convs[i], laterals[i].contiguous(memory_format=torch.channels_last)) for i in range(len(laterals) - 1)] + [laterals[-1]]
         if len(outs) == 4 and own_resize:
-            cat = fused.resize_concat4(outs)                                # the three resizes + the concatenation: one kernel
+            cat = fused.resize_concat(outs)                                 # the three resizes + the concatenation: one kernel
         else:
             outs = [outs[0]] + [self._resize(o, outs[0].shape[2:]) for o in outs[1:]]
             cat = torch.cat(outs, dim=1).contiguous(memory_format=torch.channels_last)

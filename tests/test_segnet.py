@@ -212,6 +212,17 @@ def test_fpn_resize_kernels_vs_the_framework_sequence(dtype):
         assert got.shape == want.shape and got.permute(0, 2, 3, 1).is_contiguous()
         assert close(got, want), (B, C, sizes, (got.float() - want.float()).abs().max().item())
         assert torch.equal(got[:, :C], lv[0])                              # the finest level is a copy
+    # the pyramid pooling module's two kernels: every pool scale in one launch, the input + the pooled maps resized back in one
+    x = torch.randn(3, 64, 8, 8, device="cuda", dtype=dt).contiguous(memory_format=torch.channels_last)
+    for xx, scales in ((x, (1, 2, 3, 6)), (x[:, :, :7, :5].contiguous(memory_format=torch.channels_last), (2, 4, 7))):
+        got = fused.adaptive_pools(xx, scales)
+        for s_, gt in zip(scales, got):
+            want = F_.adaptive_avg_pool2d(xx, s_)
+            assert gt.shape == want.shape and close(gt, want), (s_, (gt.float() - want.float()).abs().max().item())
+        small = [torch.randn(3, 24, s_, s_, device="cuda", dtype=dt).contiguous(memory_format=torch.channels_last) for s_ in scales]
+        want = torch.cat([xx] + [F_.interpolate(t, size=xx.shape[2:], mode="bilinear", align_corners=False) for t in small], dim=1)
+        got = fused.resize_concat([xx] + small)
+        assert got.shape == want.shape and close(got, want), (scales, (got.float() - want.float()).abs().max().item())
     for (h, w) in ((8, 8), (1, 1), (5, 3)):
         coarse = torch.randn(2, 64, h, w, device="cuda", dtype=dt).contiguous(memory_format=torch.channels_last)
         fine = torch.randn(2, 64, 2 * h, 2 * w, device="cuda", dtype=dt).contiguous(memory_format=torch.channels_last)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""NAT-Base + UPerHead batch time with the FPN's resizes on the build's kernels (ppn_upsample2x_add_nhwc, ppn_resize_concat4_nhwc:
-the default) against PPNET_UPER_UNFUSED_RESIZE=1 (interpolate + add, interpolate x3 + cat + channels_last copy on the framework),
-alternating in ONE process on one box; the labels of the two forms are compared."""
+"""NAT-Base + UPerHead batch time with the head's pooling / resize / concatenation steps on the build's kernels (ppn_adaptive_pools_nhwc,
+ppn_upsample2x_add_nhwc, ppn_resize_concat_nhwc: the default) against PPNET_UPER_UNFUSED_RESIZE=1 (adaptive pools, interpolate + add,
+interpolate + cat + channels_last copy on the framework), alternating in ONE process on one box; the labels of the two forms are
+compared (the pooled 1x1 ConvModules move from F.linear to the GEMM kernel with them: bfloat16 roundings differ, labels at ties flip)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
