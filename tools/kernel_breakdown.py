@@ -6,7 +6,9 @@ d, marker, per_iter = sys.argv[1], sys.argv[2], int(sys.argv[3])
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
-sel = rows[max(idx[-per_iter] - 12, 0):]
+# per_iter > 0: the tail of the trace from 12 dispatches before the iteration's first marker call (the marker closes a PPNet batch);
+# per_iter == 0: everything between the last two marker calls (one whole step of a loop that ends with the marker)
+sel = rows[max(idx[-per_iter] - 12, 0):] if per_iter > 0 else rows[idx[-2] + 1:idx[-1] + 1]
 agg = collections.defaultdict(lambda: [0, 0])
 for r in sel:
     k = r["Kernel_Name"][:100]
