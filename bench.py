@@ -495,9 +495,7 @@ def end_to_end_leg(torch, dev, steps, world, rank, cpu_leg):
     torch.cuda.synchronize()
     el = time.perf_counter() - t1
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        el = shard.max_over_ranks(el, dev)
     if rank != 0:
         return None
     ms = el / steps * 1e3
@@ -634,9 +632,7 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None)
     torch.cuda.synchronize()
     el = time.perf_counter() - t1
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        el = shard.max_over_ranks(el, dev)
     if rank != 0:
         return None
     ms = el / steps * 1e3
@@ -728,11 +724,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with WORLD_SIZE={args.gpus}")
+    # BENCH_REHEARSE_SHARED_GPU: every rank on GPU 0 with a gloo group — a one-GPU box runs the N > 1 control flow (sharding by rank,
+    # the record ring and its events, barriers, the max over ranks) before an 8-GPU node sees it; the rows of the gathers travel
+    # through the host (shard.all_gather_rows), so the VALUE of such a run is not a measurement and the line says so
+    shared_gpu = bool(os.environ.get("BENCH_REHEARSE_SHARED_GPU"))
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # buffers are allocated once and reused every step (resident in HBM).  Stage A is a latency chain (one workgroup
     # per path, ~0.19 ms for 100 paths) that leaves most of the chip idle, so it runs DEPTH batches ahead of stage B on
@@ -882,9 +887,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = shard.max_over_ranks(elapsed, dev)
 
     starts = [a for a, _ in evs if a is not None]
     ends = [evs[i + GROUP - 1][1] for i, (a, _) in enumerate(evs) if a is not None]
@@ -938,12 +941,15 @@ def main():
                         "maps_per_s": round(n_local / (maps_kernel_ms * 1e-3), 1)},
             "exchange": ({"gather_every_steps": ring.G, "gathers_in_timed_region": ring.n_gathers - gathers_before,
                           "bytes_per_rank_per_gather": ring.G * n_local * shard.RECORD_WIDTH * 8,
-                          "collective": "all_gather_into_tensor (RCCL)" if world > 1 else "copy (BENCH_FORCE_EXCHANGE rehearsal on one GPU)"}
+                          "collective": ("all_gather_into_tensor (gloo, rows through the host: rehearsal)" if shared_gpu else "all_gather_into_tensor (RCCL)") if world > 1 else "copy (BENCH_FORCE_EXCHANGE rehearsal on one GPU)"}
                          if exchange else None),
             "path_group": GROUP,
             "placement_success": round(placed, 4),
             "mean_obstacles_per_map": round(k_tot, 2),
         }
+        if shared_gpu:
+            out["rehearsal"] = ("BENCH_REHEARSE_SHARED_GPU: every rank on one GPU, gloo group, gathered rows through the host - the N > 1 control "
+                                "flow run for its own sake, not a measurement")
         if ppnet is not None:
             out["ppnet"] = ppnet
             if world == 1 and args.segnet in ("nat_uper", "both"):

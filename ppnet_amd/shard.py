@@ -59,6 +59,26 @@ def pack_plan_records(result, lengths, out=None):
     return rec
 
 
+def all_gather_rows(out, src, group=None):
+    """dist.all_gather_into_tensor, RCCL for CUDA tensors.  Under a gloo group CUDA rows travel through the host: that is the
+    REHEARSAL transport of `bench.py` with BENCH_REHEARSE_SHARED_GPU (several ranks on one GPU cannot form an RCCL communicator);
+    the control flow around the call — streams, events, slots, barriers — is the production one."""
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        torch.cuda.current_stream(src.device).synchronize()
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, src.cpu().contiguous(), group=group)
+        out.copy_(host)
+        return
+    dist.all_gather_into_tensor(out, src, group=group)
+
+
+def max_over_ranks(value, device, group=None):
+    """The slowest rank's clock (bench.py's contract: MAX over ranks of the timed region)."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if dist.get_backend(group) == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
 def gather_records(rec, world, sizes=None, group=None, out=None, always_collective=False):
     """All-gather of per-instance records; `sizes` = rows per rank when shards are uneven; `out` = a preallocated
     [world * rows, width] buffer for the even case (a steady-state loop should not allocate on a side stream).
@@ -68,13 +88,13 @@ def gather_records(rec, world, sizes=None, group=None, out=None, always_collecti
     if sizes is None or len(set(sizes)) == 1:
         if out is None:
             out = torch.empty(world * rec.shape[0], rec.shape[1], dtype=rec.dtype, device=rec.device)
-        dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
+        all_gather_rows(out, rec.contiguous(), group)
         return out
     m = max(sizes)
     pad = torch.zeros(m, rec.shape[1], dtype=rec.dtype, device=rec.device)
     pad[:rec.shape[0]] = rec
     out = torch.empty(world * m, rec.shape[1], dtype=rec.dtype, device=rec.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    all_gather_rows(out, pad, group)
     return torch.cat([out[r * m:r * m + sizes[r]] for r in range(world)])
 
 
@@ -136,7 +156,7 @@ class RecordRing:
 
         def ship():
             if self.collective:
-                dist.all_gather_into_tensor(out, src, group=self.group)
+                all_gather_rows(out, src, self.group)
             else:
                 out.copy_(src)
         if self.device.type == "cuda":

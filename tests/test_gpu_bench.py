@@ -39,6 +39,33 @@ def test_exchange_branch_runs_in_a_child_process():
         assert d["roofline"]["bound"] == "hbm" and 0.2 < d["roofline"]["frac"] < 1.0 and d["placement_success"] > 0.99
 
 
+def test_two_ranks_rehearsal_on_one_gpu():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), both ranks on this box's one GPU
+    (BENCH_REHEARSE_SHARED_GPU: gloo group, gathered rows through the host): rc 0, ONE JSON line from rank 0, the whole-job
+    aggregate of both ranks' units, the record ring's gathers of both ranks' rows inside the clock, the PPNet and config-5 legs'
+    gathers, barriers and max-over-ranks clocks.  Not a measurement — the line says so — but every branch an 8-GPU run takes."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.update({"BENCH_REHEARSE_SHARED_GPU": "1", "BENCH_GATHER_STEPS": "8", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--ppnet-steps", "2",
+           "--end-to-end-steps", "1"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and "rehearsal" in d
+    assert d["value"] > 0 and d["placement_success"] > 0.99
+    ex = d["exchange"]
+    assert ex["gather_every_steps"] == 8 and ex["gathers_in_timed_region"] == 3 and "gloo" in ex["collective"]
+    assert d["ppnet"]["value"] > 0
+    assert d["end_to_end_r512"]["value"] > 0 and d["end_to_end_r512"]["problems_per_step_per_gpu"] == 256
+
+
 def test_generate_and_plan_chain_equals_separate_calls():
     """Config 5's chain at 512 x 512 on two alternating streams (what bench.py's end_to_end_r512 leg times) against the same
     stages called one by one on the default stream with a synchronise after each: identical grids, labels, heat maps, plans."""
