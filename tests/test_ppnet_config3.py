@@ -295,6 +295,8 @@ def test_two_captures_of_different_batch_sizes_in_one_process(dev, stage_b, segn
     is declined (na2d_halo16_launch returns -1, the per-tile kernel runs — same arithmetic).  Here: a warm capture at batch 4
     (PPNet.capture), then a COLD capture at batch 6 — a batch size this process has never run, recorded without a warm-up pass,
     so its geometries are first met inside the capture —, both graphs replayed alternately, compared with eager runs bit for bit."""
+    if any(os.environ.get(k) for k in ("PPNET_LIBRARY_TOKENIZER", "PPNET_TOKENIZER_TWO_KERNELS", "PPNET_LIBRARY_CONV")):
+        pytest.skip("A/B knob: a COLD capture cannot hold a library convolution (MIOpen searches for a solution at a shape's first call)")
     _, _, p16 = segnet_models
     pb, mb = stage_b
     init, end = mb.segpoint[:, 0].contiguous(), mb.segpoint[:, 10].contiguous()

@@ -27,4 +27,8 @@ run PPNET_LIBRARY_GEMM=1 $S
 run PPNET_NAT_GEMM128=0 $S tests/test_gpu_natgemm.py
 run PPNET_NAT_GEMM128=all $S tests/test_gpu_natgemm.py
 run PPNET_NO_SMALL_GEMM=1 $S tests/test_gpu_mfma.py
+run PPNET_NO_FUSED_MLP=1 $S tests/test_gpu_natgemm.py
+run PPNET_LIBRARY_GEMM_FROM_C=1073741824 $S
+run PPNET_LIBRARY_GEMM_FROM_C=1024 $S
+run PPNET_UPER_UNFUSED_RESIZE=1 tests/test_segnet.py
 exit $rc
