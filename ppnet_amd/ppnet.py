@@ -15,11 +15,12 @@ _TUNED = os.environ.get("PPNET_TUNED_TABLE") or os.path.join(os.path.dirname(os.
 
 
 def _use_tuned_gemms():
-    """hipBLASLt solution picks for the vendor GEMMs that remain OFF the default bf16 path: since round 3 the prepared bfloat16
-    batch runs every projection on the build's own kernels (ppn_nat_gemm_bf16 / nat128 kernels / the GenNet trunk kernel), so this
-    table (PyTorch TunableOp, recorded on MI355X, ROCm 7.2) serves the A/B knobs that restore the library (PPNET_LIBRARY_GEMM,
-    PPNET_NO_LN_FOLD's fallbacks) and the float32 leg.  Read-only: no tuning at run time; shapes not in the table, or a table whose
-    validators do not match the installed libraries, fall back to the default heuristics."""
+    """hipBLASLt solution picks (PyTorch TunableOp, recorded on MI355X, ROCm 7.2) for the vendor GEMMs of the prepared bfloat16
+    batch — since round 4 the projections of the NAT levels at C >= 512 (segnet.LIBRARY_GEMM_FROM_C: addmm_ with beta = 1,
+    _addmm_activation with the GELU epilogue) at batch 256 of 256 x 256 and of 512 x 512 maps —, for the A/B knobs that send more
+    of the network to the library (PPNET_LIBRARY_GEMM, PPNET_NO_LN_FOLD's fallbacks) and for the float32 leg.  Read-only: no tuning
+    at run time; shapes not in the table, or a table whose validators do not match the installed libraries, fall back to the
+    default heuristics."""
     try:
         import torch.cuda.tunable as tn
         if os.path.exists(_TUNED) and torch.cuda.is_available():

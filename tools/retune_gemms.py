@@ -2,7 +2,7 @@
 """Time a batch of both networks with the TunableOp table in use (PPNET_TUNED_TABLE overrides the shipped one), or — with
 `fresh OUT.csv` — record a table from scratch on the CURRENT call pattern (addmm_ with beta = 1, _addmm_activation with the
 GELU epilogue, virtual padding's token counts) and time a batch with it.
-    python tools/retune_gemms.py                 python tools/retune_gemms.py fresh OUT.csv"""
+    python tools/retune_gemms.py [R]             python tools/retune_gemms.py fresh OUT.csv [R]        (R = 256 or 512, batch 256)"""
 import os
 import sys
 import time
@@ -15,8 +15,9 @@ from ppnet_amd import edage
 import ppnet_amd.ppnet as PP
 
 fresh = len(sys.argv) > 2 and sys.argv[1] == "fresh"
+R = int(sys.argv[3]) if fresh and len(sys.argv) > 3 else (int(sys.argv[1]) if not fresh and len(sys.argv) > 1 else 256)
 dev = torch.device("cuda:0")
-pb = edage.generate_paths(16, 256, 50, 3, seed=0, device=dev)
+pb = edage.generate_paths(16, R, 50, 3, seed=0, device=dev)
 mb = edage.generate_maps(pb, 16, 5, 20, seed=0)
 g = mb.grid[:256].contiguous()
 
@@ -41,7 +42,7 @@ if fresh:
         tn.set_filename(sys.argv[2] + ".tunableop")
     PP._use_tuned_gemms = tune_from_scratch
 torch.manual_seed(0)
-m = PP.PPNet(256).to(dev).eval()
+m = PP.PPNet(R).to(dev).eval()
 if fresh:
     t0 = time.perf_counter()
     m.heatmap(m.segment_u8(g))
