@@ -2,7 +2,8 @@
 """Time a batch of both networks with the TunableOp table in use (PPNET_TUNED_TABLE overrides the shipped one), or — with
 `fresh OUT.csv` — record a table from scratch on the CURRENT call pattern (addmm_ with beta = 1, _addmm_activation with the
 GELU epilogue, virtual padding's token counts) and time a batch with it.
-    python tools/retune_gemms.py [R]             python tools/retune_gemms.py fresh OUT.csv [R]        (R = 256 or 512, batch 256)"""
+    python tools/retune_gemms.py [R]             python tools/retune_gemms.py fresh OUT.csv [R] [fp32]  (R = 256 or 512, batch 256;
+fp32: the float32 model of the reference-precision leg)"""
 import os
 import sys
 import time
@@ -42,7 +43,8 @@ if fresh:
         tn.set_filename(sys.argv[2] + ".tunableop")
     PP._use_tuned_gemms = tune_from_scratch
 torch.manual_seed(0)
-m = PP.PPNet(R).to(dev).eval()
+FP32 = "fp32" in sys.argv
+m = (PP.PPNet(R, weights_dtype=None) if FP32 else PP.PPNet(R)).to(dev).eval()
 if fresh:
     t0 = time.perf_counter()
     m.heatmap(m.segment_u8(g))
