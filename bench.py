@@ -460,13 +460,13 @@ def end_to_end_leg(torch, dev, steps, world, rank, cpu_leg):
     s_comm = torch.cuda.Stream(dev) if world > 1 else None
     gathered = torch.empty(world * n_local, shard.PLAN_RECORD_WIDTH, dtype=torch.float64, device=dev) if world > 1 else None
 
-    def one(it, timers=None):
+    def one(it, timers=None, gather=True):
         pb, mb = bufs[it % n_streams]
         first_path, _, first_map = shard.local_ids(PATHS5 * world, PLACEMENTS5, rank, world, batch_index=it)
         marks = iter(timers) if timers else None
         r = model.generate_and_plan(pb, mb, PLACEMENTS5, first_path, first_map, seed=SEED + 5, obstacles_size=OBST_SIZE, obstacles_num=K,
                                     mark=(lambda name: next(marks).record()) if timers else None)
-        if world > 1:                                                         # end-of-batch gather of the plan records (RCCL, own stream)
+        if world > 1 and gather:                                              # end-of-batch gather of the plan records (RCCL, own stream)
             res = r["result"]
             rec = shard.pack_plan_records(res, evaluate.plan_lengths(res["waypoints"], res["counts"]))
             ev = torch.cuda.Event(); ev.record()
@@ -529,7 +529,8 @@ def end_to_end_leg(torch, dev, steps, world, rank, cpu_leg):
                         "frac": round(tflops / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": None,
                         "gflop_per_plan": round((seg_fl + gen_fl) / 1e9, 2), "counting": "as executed (ppnet_flops_per_plan)"}}
     try:
-        own, lib, own_ms, lib_ms = _kernel_split(torch, lambda: one(999), top=6)
+        # rank 0 alone is here: the profiled step must not enter a collective the other ranks have left (with RCCL it would never return)
+        own, lib, own_ms, lib_ms = _kernel_split(torch, lambda: one(999, gather=False), top=6)
         out["roofline"]["dominant_kernels"] = own
         out["own_kernels_ms"], out["other_kernels_ms"] = round(own_ms, 2), round(lib_ms, 2)
     except Exception as e:
