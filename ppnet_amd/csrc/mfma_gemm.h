@@ -19,7 +19,7 @@
 //                   The k-tiles are WALKED channel block by channel block (all 9 taps of 64 channels, then the next 64): the taps of
 //                   a block re-read the same pixels' 128 bytes shifted by a pixel or a row, so the tiles an XCD has in flight touch
 //                   ~1 MB per 9 k-tiles and the re-reads hit its L2; tap-major (the memory order of k) the nine visits of a pixel lie
-//                   Cin / 64 k-tiles apart with 4 MB of other rows in between, and every visit came from HBM (FETCH_SIZE 6.4 GB for
+//                   Cin / 64 k-tiles apart with 4 MB of other rows in between, and every visit missed the L2 (a third of all requests: ≈12.8 GB fetched for
 //                   the 1 GB image of the SETR-UP head's last stage).
 // Epilogues: see Epi.
 #pragma once
