@@ -55,6 +55,27 @@ def test_invalid_arguments_return_codes_without_gpu():
     assert L.ppn_extract_paths(None, 1, 8, 8, None, None, 16, None, None, None, None) == -1
 
 
+def test_network_entry_points_reject_bad_arguments_without_gpu():
+    """The round-4 entries of the SegNet heads / NAT levels: argument checks come before any HIP call."""
+    from ppnet_amd import _lib
+    L = _lib.lib
+    one = C.c_void_p(0x1000)                                  # a non-null pointer that is never dereferenced on these paths
+    hw8 = (C.c_int32 * 8)(16, 16, 8, 8, 4, 4, 2, 2)
+    assert L.ppn_resize_concat4_nhwc(None, one, one, one, hw8, one, 1, 64, 1, None) == -1
+    assert L.ppn_resize_concat4_nhwc(one, one, one, one, hw8, one, 1, 60, 1, None) == -1          # C % 8
+    assert L.ppn_resize_concat4_nhwc(one, one, one, one, hw8, one, 1, 64, 2, None) == -1          # dtype
+    ptrs = (C.c_void_p * 2)(0x1000, 0x1000)
+    assert L.ppn_resize_concat_nhwc(ptrs, (C.c_int32 * 4)(8, 8, 0, 2), (C.c_int32 * 2)(64, 64), 2, one, 1, 1, None) == -1     # empty level
+    assert L.ppn_resize_concat_nhwc(ptrs, (C.c_int32 * 4)(8, 8, 2, 2), (C.c_int32 * 2)(64, 12), 2, one, 1, 1, None) == -1     # channels % 8
+    assert L.ppn_resize_concat_nhwc(ptrs, (C.c_int32 * 4)(8, 8, 2, 2), (C.c_int32 * 2)(64, 64), 9, one, 1, 1, None) == -1     # > 8 levels
+    assert L.ppn_adaptive_pools_nhwc(one, ptrs, (C.c_int32 * 2)(1, 0), 2, 1, 8, 8, 64, 1, None) == -1                        # scale 0
+    assert L.ppn_adaptive_pools_nhwc(one, ptrs, (C.c_int32 * 2)(1, 2), 5, 1, 8, 8, 64, 1, None) == -1                        # > 4 scales
+    assert L.ppn_upsample2x_add_nhwc(one, None, one, 1, 8, 8, 64, 1, None) == -1
+    assert L.ppn_upsample2x_add_nhwc(one, one, one, 1, 8, 8, 60, 1, None) == -1
+    assert L.ppn_nat_mlp_bf16(None, one, one, one, None, 256, 256, 512, C.c_float(1e-5), None) == -1
+    assert L.ppn_nat_mlp_supported(256, 512, 1024) == 0 and L.ppn_nat_mlp_supported(256, 256, 512) == 1
+
+
 def test_polyfit_operator_matches_numpy():
     from ppnet_amd import _lib
     W = np.zeros((4, 1000))
