@@ -97,7 +97,12 @@ __global__ __launch_bounds__(TOKF_THREADS, 1) void tokenizer_fused_kernel(const 
                                                                           __hip_bfloat16* __restrict__ out, int B, int H, int W, long long groups, float eps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tl[];
     float* vl = reinterpret_cast<float*>(tl + TOKF_W2_BYTES);
-    for (int i = threadIdx.x; i < TOKF_W2_BYTES / 16; i += TOKF_THREADS) reinterpret_cast<uint4*>(tl)[i] = reinterpret_cast<const uint4*>(w2p)[i];
+    // A fragment (16 rows x 64 bytes) is laid out [lane quarter g][row p] in LDS, not [p][g] as in memory: lane (p, g) reads its 16
+    // bytes at g * 256 + p * 16, and the 16-lane groups a ds_read_b128 is served in — rows {0-3, 12-15} of one quarter with rows 4-11
+    // of the next — then fall on 16 different bank groups (row-major they met two by two: SQ_LDS_BANK_CONFLICT was 45 % of the
+    // kernel's LDS cycles, and it reads 144 fragments per 16 tokens)
+    for (int i = threadIdx.x; i < TOKF_W2_BYTES / 16; i += TOKF_THREADS)
+        reinterpret_cast<uint4*>(tl)[(i & ~63) + (i & 3) * 16 + ((i >> 2) & 15)] = reinterpret_cast<const uint4*>(w2p)[i];
     for (int i = threadIdx.x; i < 3 * 128; i += TOKF_THREADS) vl[i] = vec[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(TOKF_THREADS, 1) void tokenizer_fused_kernel(const 
         ah[t] = *reinterpret_cast<const bf16x8*>(lut + (size_t)(t * 16 + p) * 32 + 8 * g);
         al[t] = *reinterpret_cast<const bf16x8*>(lut + (size_t)(64 + t * 16 + p) * 32 + 8 * g);
     }
-    const unsigned char* wrow = tl + p * 64 + g * 16;                       // this lane's 16 bytes of every weight fragment
+    const unsigned char* wrow = tl + g * 256 + p * 16;                      // this lane's 16 bytes of every weight fragment
     const long long wave0 = (long long)blockIdx.x * (TOKF_THREADS / 64) + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * (TOKF_THREADS / 64);
     for (long long grp = wave0; grp < groups; grp += nwaves) {
         const uint32_t g32 = (uint32_t)grp, bimg = g32 / (uint32_t)(gpr * Ht), rem = g32 - bimg * (uint32_t)(gpr * Ht);
