@@ -227,8 +227,11 @@ def bench_ppnet(torch, dev, resolution, weights_dtype="bf16", calibrate=None):
 
 
 PARITY_TOLERANCE = {      # what tests/test_ppnet_config3.py asserts for the same objects (bf16 prepared vs float32)
-    "rms_logit_rel_max": 0.08, "labels_agree_where_margin_exceeds_rms_x": 6.0,      # x the rms error of the class margin l1 - l0
-    "heat_u8_max_code_diff_max": 16, "heat_u8_rms_code_diff_max": round(0.03 * 255, 2),
+    # <= 4 x what is measured (rms logit error 0.0021-0.0025 of the logit rms, heat map 2 codes / rms 0.56 codes; VERDICT r04 item 6:
+    # the round-4 bounds 0.08 / 16 / 7.65 would have survived a 30 x regression).  The dominant terms: one bf16 rounding per stored
+    # activation (2^-9 relative) and the fused MLP's polynomial GELU (|error| <= 9.2e-5 absolute, include/ppnet_hip.h)
+    "rms_logit_rel_max": 0.01, "labels_agree_where_margin_exceeds_rms_x": 6.0,      # x the rms error of the class margin l1 - l0
+    "heat_u8_max_code_diff_max": 6, "heat_u8_rms_code_diff_max": 2.0,
     "label_agreement_min_unbalanced_classifier": 0.97,
     "label_agreement_note": "overall agreement is reported, not a criterion here: the bench balances the untrained classifier's bias, so the "
                             "class margin is a small difference of two near-equal logits and a pixel inside 6 x the rms margin error of a tie "

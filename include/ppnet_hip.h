@@ -61,6 +61,12 @@ extern "C" {
                                             obstacles are not the reference's — call again with a larger buffer
                                             (3 * PPN_POCKET_TRY_CAP * PPN_MAX_ISLES floats always suffice) */
 
+/* ABI version of this header.  ppn_version() returns the PPN_ABI_VERSION the LIBRARY was built with; a caller compares the two
+ * before its first real call (ppnet_amd/_lib.py does, INTEGRATION.md shows the check) — argument lists are plain pointers and
+ * sizes, so a caller built against another header would link and pass, say, a batch size where a workspace pointer is expected.
+ * Bumped whenever an entry point's argument list changes or an entry point is removed: 100 = rounds 1-3; 101 = round 4
+ * (ppn_conv3x3_relu_classify2_bf16 gained `partial`); 105 = round 5. */
+#define PPN_ABI_VERSION 105
 int         ppn_version(void);
 const char* ppn_error_string(int code);
 int         ppn_last_hip_error(void);   /* hipError_t of the most recent PPN_E_HIP on this thread */
@@ -362,9 +368,11 @@ int ppn_conv3x3_mfma_bf16(const void* x, const void* w, const float* bias, void*
 /* The head's last stage (setr_up_head.py:78-80 with the 1x1 classifier commuted in front of the last up-sampling):
  * logits[m][c] += sum_n max(conv(x, w)[m][n] + bias[n], 0) * w2[c][n] for the B*H*W pixels m and c = 0, 1.
  * logits [B*H*W][2] float32 must hold the classifier's bias on entry; w2 [2][Cout] float32.  The Cout-channel activation is
- * never written: the convolution kernel leaves one partial sum per pixel, class and 64-column slot in
- * partial [ppn_conv3x3_relu_classify2_slots(Cout)][B*H*W][2] float32 (caller-owned workspace, every element written), and a
- * second launch adds the slots to logits in slot order — no atomics: bit-reproducible. */
+ * never written: a workgroup adds the sums of its 256-column block in a fixed order (through LDS) and, when Cout <= 256, onto the
+ * logits directly — ppn_conv3x3_relu_classify2_slots(Cout) is then 0 and `partial` may be NULL.  Wider convolutions leave one partial
+ * sum per pixel, class and 256-column block in partial [ppn_conv3x3_relu_classify2_slots(Cout)][B*H*W][2] float32 (caller-owned
+ * workspace, every element written; 16 bytes per pixel at Cout = 512 — round 4: 32) and a second launch adds the slots to logits in
+ * slot order.  No atomics anywhere: bit-reproducible. */
 int32_t ppn_conv3x3_relu_classify2_slots(int32_t Cout);
 int ppn_conv3x3_relu_classify2_bf16(const void* x, const void* w, const float* bias, const float* w2, float* logits, float* partial, int32_t B,
                                     int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
@@ -482,14 +490,16 @@ int ppn_nat_gemm_bf16(const void* a, const void* w, const float* bias, const flo
 /* The MLP half of a NAT layer as ONE kernel (SegNet/nat.py:62-85 `Mlp.forward`, :147-153 of `NATLayer.forward`; csrc/nat_mlp.hip):
  *     s += gelu(LN(s) W1^T + b1) W2^T + b2        in place on the residual stream s [M][C] (bfloat16),
  * the hidden activation [M][HID] never written: it is produced and consumed chunk by chunk inside the compute unit.
- * ppn_nat_mlp_supported: 1 when (M, C, HID) is served (C = 256, M % 256 == 0, HID % 32 == 0), else 0 — callers fall back to two
+ * ppn_nat_mlp_supported: 1 when (M, C, HID) is served (C = 256, M % 128 == 0 — a workgroup pass is 4 wave pairs x 32 rows —, 64 <= HID <= 2048, HID % 32 == 0), else 0 — callers fall back to two
  *   ppn_nat_gemm_bf16 calls (modes 1 and 2).
  * ppn_nat_mlp_pack_bf16: wpk [2 * C * HID] bfloat16 <- the two weights in the kernel's streaming order; w1 [HID][C] with the
  *   LayerNorm folded in (w1 = W1 diag(gamma)), w2 [C][HID] with LayerScale folded in (torch Linear layouts).  Once per weight change.
  * ppn_nat_mlp_bf16: hb [HID][2] float32 = (colsum_k w1[h][k] of the bfloat16 values, b1[h] + W1[h] . beta); b2 [C] float32;
  *   stats_out [C / 128][M][2] (or null) receives (sum, sum of squares) of every row of the NEW s per 128 columns, of the bfloat16
  *   values stored — the stats_in of the next ppn_nat_gemm_bf16 mode-0 call.  LayerNorm over the C features with `eps`; erf-GELU
- *   through the logistic fit of ppn_nat_gemm_bf16 mode 1.  Bit-reproducible (no atomics). */
+ *   as x (1/2 + x~ q(x~^2)) with x~ = clamp(x, -4.25, 4.25) and q an odd-polynomial fit of (Phi(x) - 1/2) / x of degree 15 in x
+ *   (no transcendental instruction; |gelu error| <= 9.2e-5 absolute, three times the 3e-5 of ppn_nat_gemm_bf16 mode 1's logistic
+ *   fit — the bound bench.py's PARITY_TOLERANCE is sized against).  Bit-reproducible (no atomics). */
 int32_t ppn_nat_mlp_supported(int64_t M, int32_t C, int32_t HID);
 int ppn_nat_mlp_pack_bf16(const void* w1, const void* w2, void* wpk, int32_t C, int32_t HID, void* stream);
 int ppn_nat_mlp_bf16(void* s, const void* wpk, const float* hb, const float* b2, float* stats_out, int64_t M, int32_t C, int32_t HID,

@@ -473,9 +473,12 @@ def _gather(img, ii, jj, out_h, out_w):
 
 def rotate_nearest(img, angle_deg):
     """torchvision.transforms.functional.rotate(img, angle_deg, NEAREST) on a tensor (what T.RandomRotation(degrees=
-    (a, a)) applies, Path.py:160-161, MapGenerate.py:103-104): counter-clockwise about the image centre, zero fill."""
+    (a, a)) applies, Path.py:160-161, MapGenerate.py:103-104): counter-clockwise about the image centre, zero fill.
+    RandomRotation.get_params returns float(torch.empty(1).uniform_(a, a).item()) — the angle ROUNDED TO FLOAT32 — and that
+    is what F.rotate builds its matrix from; the points of the label rotate with the float64 angle (MapGenerate.py:70-89)."""
     h, w = img.shape
-    ii, jj = affine_source_index(h, w, inverse_affine_matrix(-angle_deg, [0.0, 0.0]))
+    angle32 = float(np.float32(angle_deg))
+    ii, jj = affine_source_index(h, w, inverse_affine_matrix(-angle32, [0.0, 0.0]))
     return _gather(img, ii, jj, h, w)
 
 

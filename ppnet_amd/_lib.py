@@ -46,6 +46,8 @@ class MapsStruct(C.Structure):
         "n_obstacles", "flags", "records")]
 
 
+ABI_VERSION = 105          # include/ppnet_hip.h: PPN_ABI_VERSION (tests/test_capi_exports.py keeps the two equal)
+
 EXPORTS = ("ppn_version", "ppn_error_string", "ppn_last_hip_error", "ppn_polyfit_table", "ppn_edage_paths",
            "ppn_edage_paths_ex", "ppn_edage_paths_ex2", "ppn_edage_maps", "ppn_edage_maps_place", "ppn_edage_maps_raster",
            "ppn_label_masks", "ppn_boundary_check", "ppn_boundary_check_ex",
@@ -63,6 +65,10 @@ def _load():
             f"or `make -C ppnet_amd/csrc`.")
     lib = C.CDLL(LIB_PATH)
     lib.ppn_version.restype = C.c_int
+    if lib.ppn_version() != ABI_VERSION:
+        raise ImportError(
+            f"{LIB_PATH} reports ABI version {lib.ppn_version()}, these bindings are written against {ABI_VERSION} "
+            f"(include/ppnet_hip.h: PPN_ABI_VERSION): argument lists differ, rebuild with `make -C ppnet_amd/csrc`.")
     lib.ppn_error_string.restype = C.c_char_p
     lib.ppn_error_string.argtypes = [C.c_int]
     lib.ppn_last_hip_error.restype = C.c_int

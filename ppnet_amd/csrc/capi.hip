@@ -85,7 +85,7 @@ int polyfit_table_device(const double** out) {
 
 extern "C" {
 
-int ppn_version(void) { return 100; }
+int ppn_version(void) { return PPN_ABI_VERSION; }
 
 const char* ppn_error_string(int code) {
     switch (code) {
@@ -495,11 +495,12 @@ int ppn_conv3x3_mfma_bf16(const void* x, const void* w, const float* bias, void*
     return PPN_OK;
 }
 
-int32_t ppn_conv3x3_relu_classify2_slots(int32_t Cout) { return Cout > 0 ? ((Cout + 255) / 256) * 4 : -1; }
+// workspace slots: one per 256-column block, none when there is a single block (the kernel then adds straight onto the logits)
+int32_t ppn_conv3x3_relu_classify2_slots(int32_t Cout) { return Cout > 0 ? (Cout > 256 ? (Cout + 255) / 256 : 0) : -1; }
 
 int ppn_conv3x3_relu_classify2_bf16(const void* x, const void* w, const float* bias, const float* w2, float* logits, float* partial, int32_t B,
                                     int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream) {
-    if (!x || !w || !bias || !w2 || !logits || !partial || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 64) != 0 || Cout <= 0 || (Cout % 8) != 0)
+    if (!x || !w || !bias || !w2 || !logits || (!partial && Cout > 256) || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 64) != 0 || Cout <= 0 || (Cout % 8) != 0)
         return PPN_E_INVALID;
     if ((long long)B * H * W * Cin * 2 >= (1LL << 32) || (long long)Cout * 9 * Cin * 2 >= (1LL << 32) || (long long)B * H * W >= (1LL << 31))
         return PPN_E_UNSUPPORTED;

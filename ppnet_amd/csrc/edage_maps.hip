@@ -246,7 +246,7 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
                 bc[0] = angle; bc[6] = ca; bc[7] = sa;
                 if constexpr (PHASE & 2) {
                     double s3, c3;                                            // rotate_nearest(space, -angle): F.rotate's inverse
-                    sincos_small(angle * PPN_DEG2RAD, s3, c3);                // matrix [c, s, 0; -s, c, 0] of radians(angle)
+                    sincos_small((double)(float)angle * PPN_DEG2RAD, s3, c3);  // matrix [c, s, 0; -s, c, 0] of radians(float32(angle)): RandomRotation's draw, MapGenerate.py:103-104
                     bc[8] = c3; bc[9] = s3;
                 }
                 bci[0] = t0; bci[1] = t1; bci[2] = attempts; bci[3] = (int)flags;
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(PPN_MAPS_THREADS, PPN_MAPS_WAVES_PER_EU) void edage
             bc[2] = O.segpoint[(size_t)m * 22];      bc[3] = O.segpoint[(size_t)m * 22 + 1];        // init = segpoint[0]
             bc[4] = O.segpoint[(size_t)m * 22 + 20]; bc[5] = O.segpoint[(size_t)m * 22 + 21];       // end  = segpoint[10]
             double s3v, c3v;
-            sincos_small(O.angle[m] * PPN_DEG2RAD, s3v, c3v);             // rotate_nearest(space, -angle), as in the placement half
+            sincos_small((double)(float)O.angle[m] * PPN_DEG2RAD, s3v, c3v);             // rotate_nearest(space, -angle), as in the placement half
             bc[8] = c3v; bc[9] = s3v;
         }
     }
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(NT) void label_masks_kernel(ppn_paths_t P, ppn_maps
         const double angle = M.angle[m];
         const int t0 = M.translation[(size_t)m * 2], t1 = M.translation[(size_t)m * 2 + 1];
         double c3, s3;
-        sincos_small(angle * PPN_DEG2RAD, s3, c3);
+        sincos_small((double)(float)angle * PPN_DEG2RAD, s3, c3);             // float32: see the placement half
         const TvAxis rcol = tv_axis(c3, s3, 0.0, R), rrow = tv_axis(-s3, c3, 0.0, R);
         const float ctr = 0.5f - 0.5f * (float)R;
         uint8_t* g = mask_space + (size_t)m * R * R;

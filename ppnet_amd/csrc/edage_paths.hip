@@ -449,7 +449,9 @@ __global__ __launch_bounds__(NT, PPN_PATHS_WAVES_PER_EU) void edage_paths_kernel
         const double t0 = Rd / 2.0 - mx, t1 = Rd / 2.0 - my;      // (t_row, t_col)
         for (int i = 0; i < hn; ++i) { hull[i][0] = hull[i][0] + t0; hull[i][1] = hull[i][1] + t1; }
         bc[0] = rotation; bc[1] = c; bc[2] = s; bc[3] = t0; bc[4] = t1;
-        const double b = rotation * PPN_DEG2RAD;                 // rotate_nearest(canvas, -rotation): F.rotate's matrix is
+        // T.RandomRotation(degrees=(a, a)).get_params returns float(torch.empty(1).uniform_(a, a).item()): the angle reaches
+        // F.rotate ROUNDED TO FLOAT32 (Path.py:160-161).  Only the raster rotation: the points rotate with the double angle.
+        const double b = (double)(float)rotation * PPN_DEG2RAD;  // rotate_nearest(canvas, -rotation): F.rotate's matrix is
         bc[5] = cos(b); bc[6] = sin(b);                          // [cos b, sin b, 0; -sin b, cos b, 0], b = radians(rotation)
         O.rotation[p] = rotation;
         O.trans_rc[(size_t)p * 2] = t0; O.trans_rc[(size_t)p * 2 + 1] = t1;

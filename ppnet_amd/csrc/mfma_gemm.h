@@ -45,8 +45,9 @@ enum Epi {
     EPI_BIAS_GELU = 1,   // C = gelu(acc + bias[n])              (erf form, torch.nn.GELU default)
     EPI_ACCUM = 2,       // C = C + acc                           (residual stream update, bias carried outside)
     EPI_BIAS_RELU = 3,   // C = max(acc + bias[n], 0)             (conv + folded BatchNorm + ReLU)
-    EPI_RELU_DOT2 = 4    // partial[slot][m][c] = sum_{n in slot} max(acc + bias[n], 0) * w2[c][n], c = 0, 1, slot = a wave's 64 columns
-                         // (the 1x1 classifier on top; the slots are summed in order by classify2_reduce_kernel: no atomics)
+    EPI_RELU_DOT2 = 4    // partial[slot][m][c] = sum_{n in slot} max(acc + bias[n], 0) * w2[c][n], c = 0, 1, slot = a 256-column block
+                         // (the 1x1 classifier on top; a block's four wave columns are added in order inside the workgroup, the slots in
+                         // order by classify2_reduce_kernel: no atomics.  N <= 256: one slot, added straight onto the logits)
 };
 
 struct Params {
@@ -61,7 +62,7 @@ struct Params {
     const __bf16* zero;    // >= 128 bytes of zeros
     // EPI_RELU_DOT2
     const float* w2;       // [2][N]
-    float* logits;         // EPI_RELU_DOT2: the partial sums [ceil(N / 64)][M][2]
+    float* logits;         // EPI_RELU_DOT2: N > 256: the partial sums [ceil(N / 256)][M][2]; else the logits [M][2] themselves (+=)
 };
 
 __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_uniform) {
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
     // exchanged, stored — in the phase after its final MFMAs, in the segment where this wave group only reads and the other group
     // owns the matrix pipe; three quarters of the store tail then overlap the remaining quadrants' MFMAs.
     const bool overlap = (my_tiles == 1) && (EPI != EPI_RELU_DOT2);
-    int g = 0;
+    int g = 0, cur_m0 = 0, cur_n0 = 0;
     for (int it = 0; it < my_tiles; ++it) {
         const int nk_loop = overlap ? nk - 1 : nk;
         for (int kt = 0; kt < nk_loop; ++kt, ++g) {
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
         }
 
         const int m0 = cur.m0, n0 = cur.n0;
+        cur_m0 = m0; cur_n0 = n0;
         if (overlap) {
             const unsigned char* buf = lds + (g & 1) * BUF_BYTES;           // the last k-tile; everything has landed (vmcnt(0) above)
             uint4 pa[4] = {}, pb[4] = {};
@@ -391,7 +393,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
             for (int ap = 0; ap < 2; ++ap)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const int m = m0 + wr * 128 + ap * 64 + mt * 16 + frow;
                     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                     for (int bp = 0; bp < 2; ++bp)
@@ -406,8 +407,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
                         }
                     s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
                     s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-                    if (fq == 0 && m < p.M)
-                        *reinterpret_cast<float2*>(p.logits + ((size_t)(n0 / 64 + wc) * p.M + m) * 2) = make_float2(s0, s1);
+                    // into the LDS buffer that held k-tile g - 2 (nobody reads it any more: the other wave group is at most one
+                    // barrier behind, inside k-tile g - 1): red[wc][row of the tile] — the four wave columns of a row are added in
+                    // order by ONE thread after the closing barrier, so a 256-column block leaves one partial per row, not four
+                    if (fq == 0) reinterpret_cast<float2*>(lds + (g & 1) * BUF_BYTES)[wc * BM + wr * 128 + ap * 64 + mt * 16 + frow] = make_float2(s0, s1);
                 }
         } else {
             // persistent form: the whole tile is finished here; exactly EPI_STORES vector-memory instructions stay in the queue
@@ -431,6 +434,25 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
 #undef PPN_GEMM_WAIT
 #undef PPN_GEMM_MMA
     if (wr == 0) __builtin_amdgcn_s_barrier();           // rebalance the barrier count of the two groups
+    if (EPI == EPI_RELU_DOT2) {
+        // one tile per workgroup (the launcher guarantees it): g == nk, the partial sums of the tile's 256 rows x 4 wave columns sit
+        // in buffer g & 1.  Thread r adds row r's four in wave-column order — a fixed order: bit-reproducible — and is the only
+        // writer of (column block, row): with one column block (N <= 256) straight onto the logits, which hold the classifier's bias.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < BM) {
+            const float2* red = reinterpret_cast<const float2*>(lds + (g & 1) * BUF_BYTES);
+            float2 a = red[tid];
+#pragma unroll
+            for (int c = 1; c < 4; ++c) { const float2 v = red[c * BM + tid]; a.x += v.x; a.y += v.y; }
+            const int m = cur_m0 + tid;
+            if (m < p.M) {
+                float2* dst = reinterpret_cast<float2*>(p.logits) + ((size_t)(tiles_n > 1 ? cur_n0 / BN : 0) * p.M + m);
+                if (tiles_n == 1) { const float2 b = *dst; a.x += b.x; a.y += b.y; }
+                *dst = a;
+            }
+        }
+    }
 }
 
 }  // namespace gemm

@@ -62,13 +62,16 @@ int conv3x3_mfma_launch(const void* x, const void* w, const float* bias, void* y
     p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.stride = stride;
     p.zero = (const __bf16*)zero_line();
     if (!p.zero) return (int)hipErrorOutOfMemory;
-    p.w2 = w2; p.logits = partial;
+    p.w2 = w2;
     if (logits) {
-        if (!partial) return (int)hipErrorInvalidValue;
+        // one slot per 256-column block (its four wave columns are added in order inside the workgroup); a single block adds straight
+        // onto the logits and needs no workspace
+        const int slots = (Cout + 255) / 256;
+        if (slots > 1 && !partial) return (int)hipErrorInvalidValue;
+        p.logits = slots > 1 ? partial : logits;
         // columns beyond N inside the last 256-wide block contribute zeros (their w2 is read as 0), so every slot of every row is written
         const int e = launch<gemm::CONV3, gemm::EPI_RELU_DOT2>(p, 0, stream);
-        if (e != 0) return e;
-        const int slots = ((Cout + 255) / 256) * 4;
+        if (e != 0 || slots == 1) return e;
         hipLaunchKernelGGL(classify2_reduce_kernel, dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, stream, partial, logits, p.M, slots);
         return (int)hipGetLastError();
     }

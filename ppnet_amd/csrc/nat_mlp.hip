@@ -259,7 +259,9 @@ __device__ __forceinline__ void nat_mlp_body(const Params& p, unsigned char* lds
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             NMLP_T(10);
-            if (!(NMLP_ABL & 4)) __builtin_amdgcn_s_barrier();
+            // the ds_write of this wave's GELU(P) half (foot of the previous iteration) must have LANDED before the barrier
+            // releases the partner's read: gfx950's back-off barrier does not imply the wait and hipcc does not add it
+            if (!(NMLP_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             NMLP_T(11);
             if (!(NMLP_ABL & 1) && t + 2 < total) { dma(jn, (t + 2) & (NS - 1)); jn = (jn + 1 == p.NCH) ? 0 : jn + 1; }
             const unsigned char* cur = ring + (t & (NS - 1)) * CHUNK;

@@ -420,7 +420,8 @@ def conv3x3_relu_classify2(x_nchw_cl, w_k, bias32, w2_32, b2_32):
     B, H, W, Cin = x.shape
     Cout = w_k.shape[0]
     logits = b2_32.to(torch.float32).repeat(B * H * W).view(B, H, W, 2).contiguous()
-    partial = torch.empty(L.lib.ppn_conv3x3_relu_classify2_slots(Cout), B * H * W, 2, dtype=torch.float32, device=x.device)
+    slots = L.lib.ppn_conv3x3_relu_classify2_slots(Cout)            # 0 for Cout <= 256: the kernel adds straight onto the logits
+    partial = torch.empty(slots, B * H * W, 2, dtype=torch.float32, device=x.device) if slots > 0 else None
     with torch.cuda.device(x.device):
         rc = L.lib.ppn_conv3x3_relu_classify2_bf16(_p(x), _p(w_k), _p(bias32), _p(w2_32), _p(logits), _p(partial), B, H, W, Cin, Cout,
                                                    ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))

@@ -37,7 +37,9 @@ def test_header_functions_are_exported():
 def test_binding_matches_header():
     from ppnet_amd import _lib
     assert sorted(_lib.EXPORTS) == _declared()
-    assert _lib.lib.ppn_version() >= 100
+    header = open(os.path.join(ROOT, "include", "ppnet_hip.h")).read()
+    abi = int(re.search(r"#define\s+PPN_ABI_VERSION\s+(\d+)", header).group(1))
+    assert _lib.lib.ppn_version() == abi == _lib.ABI_VERSION          # library, header and bindings agree
     assert _lib.lib.ppn_error_string(-1) == b"invalid argument"
     assert C.sizeof(_lib.PathsStruct) == 28 * C.sizeof(C.c_void_p)
     assert C.sizeof(_lib.MapsStruct) == 11 * C.sizeof(C.c_void_p)

@@ -43,7 +43,8 @@ def test_conv3x3_mfma_vs_torch(B, H, W, Cin, Cout, stride, relu):
 def test_conv3x3_relu_classify2_vs_torch():
     from ppnet_amd import fused
     torch.manual_seed(3)
-    for (B, H, W, Cin, Cout) in [(3, 8, 8, 128, 512), (40, 16, 16, 64, 512), (2, 10, 6, 64, 264)]:
+    for (B, H, W, Cin, Cout) in [(3, 8, 8, 128, 512), (40, 16, 16, 64, 512), (2, 10, 6, 64, 264),
+                                 (5, 12, 12, 64, 256), (2, 9, 7, 128, 64)]:       # Cout <= 256: one column block, no workspace, straight onto the logits
         x = torch.randn(B, Cin, H, W, device="cuda").to(BF).contiguous(memory_format=torch.channels_last)
         w = (torch.randn(Cout, Cin, 3, 3, device="cuda") * (2.0 / (9 * Cin)) ** 0.5).to(BF)
         b = torch.randn(Cout, device="cuda") * 0.3

@@ -61,3 +61,50 @@ def test_nat128_kernels_use_no_scratch_and_qkv_wait_count_matches(tmp_path):
     pre = body[:head]
     first = max(i for i, l in enumerate(pre) if l.startswith("global_load_dwordx4"))
     assert any(l.startswith("s_waitcnt vmcnt(0)") for l in pre[first:]), pre[first:]
+
+
+def test_nat_mlp_no_lds_write_reaches_a_barrier_unwaited(tmp_path):
+    """nat_mlp_kernel (csrc/nat_mlp.hip) publishes a pair's GELU(P) halves with a ds_write that the partner reads right behind the
+    next s_barrier.  gfx950's barrier does not wait for the LDS queue and hipcc adds no wait of its own, so on every straight-line
+    run of emitted code that ends in an s_barrier, a ds_write must be followed by `s_waitcnt lgkmcnt(0)` before the barrier
+    (the per-chunk barrier had only a vmcnt wait in front)."""
+    asm = _device_asm(tmp_path, "nat_mlp.hip")
+    m = re.search(r"^(_ZN3ppn4nmlp\d+nat_mlp_kernel\w*):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M)
+    assert m, "nat_mlp_kernel"
+    body = [l.split(";")[0].strip() for l in m.group(2).splitlines()]
+    body = [l for l in body if l]
+    barriers = [i for i, l in enumerate(body) if l.startswith("s_barrier")]
+    assert len(barriers) >= 8, len(barriers)                       # four bodies x (chunk barrier + block-end barrier), + the prologue
+    def waits_lgkm0(l):
+        # `s_waitcnt lgkmcnt(0)` alone or combined with a vmcnt field
+        return l.startswith("s_waitcnt") and re.search(r"lgkmcnt\(0\)", l) is not None
+    labels = {l[:-1]: i for i, l in enumerate(body) if l.endswith(":")}
+    jumps = {}
+    for i, l in enumerate(body):
+        m2 = re.match(r"s_c?branch\w*\s+(\S+)", l)
+        if m2:
+            jumps.setdefault(m2.group(1), []).append(i)
+
+    def unwaited_write_reaches(end, seen):
+        """True if some path into body[end] carries a ds_write with no lgkmcnt(0) wait behind it (paths followed backwards through
+        fall-through and through every branch that targets a label on the way; an earlier barrier's own check covers what is in front of it)."""
+        for i in range(end - 1, -1, -1):
+            l = body[i]
+            if waits_lgkm0(l) or l.startswith("s_barrier"):
+                return False
+            if l.startswith("ds_write") or l.startswith("ds_store"):
+                return True
+            if l.startswith("s_branch"):                        # unconditional: nothing falls through from above
+                return False
+            if l.endswith(":"):
+                for j in jumps.get(l[:-1], []):
+                    if j not in seen:
+                        seen.add(j)
+                        if unwaited_write_reaches(j, seen):
+                            return True
+        return False
+
+    for b in barriers:
+        assert not unwaited_write_reaches(b, set()), f"a ds_write reaches the s_barrier at instruction {b} without s_waitcnt lgkmcnt(0)"
+    heads = [i for i in barriers if i > 0 and waits_lgkm0(body[i - 1])]
+    assert len(heads) >= 8, (len(heads), len(barriers))

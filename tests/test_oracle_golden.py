@@ -10,6 +10,7 @@ import math
 import os
 
 import numpy as np
+import torch
 import pytest
 
 from oracle import edage_np as E
@@ -269,6 +270,17 @@ def _tv_rotate(img, angle):            # functional.rotate: matrix for -angle ab
     return _tv_grid_sample(img, E.inverse_affine_matrix(-angle, [0.0, 0.0]))
 
 
+def _tv_random_rotation(img, a):
+    """T.RandomRotation(degrees=(a, a))(img) of torchvision 0.12 (transforms.py: get_params returns
+    float(torch.empty(1).uniform_(float(degrees[0]), float(degrees[1])).item()), forward calls F.rotate with it) — the
+    call the reference makes at Path.py:160-161 and MapGenerate.py:103-104.  The draw is made by torch itself here, so the
+    angle is whatever float32 value torch produces for a degenerate range (the global generator is saved and restored)."""
+    state = torch.get_rng_state()
+    angle = float(torch.empty(1).uniform_(float(a), float(a)).item())
+    torch.set_rng_state(state)
+    return _tv_rotate(img, angle)
+
+
 def _tv_translate(img, tx, ty):        # functional.affine(angle=0, translate=[tx, ty], scale=1, shear=0)
     return _tv_grid_sample(img, E.inverse_affine_matrix(0.0, [tx, ty]))
 
@@ -290,7 +302,7 @@ def test_resample_rule_is_torchvisions_tensor_path_on_goldens(golden_dir):
         canvas[nz[:, 0], nz[:, 1]] = True
         rot = float(np.asarray(g[case + "/rotation"]).reshape(-1)[0])
         tx, ty = (float(v) for v in g[case + "/translation"])          # Path.Translation = [t_col, t_row]
-        want_rot = _tv_rotate(canvas, -rot) > 0.5
+        want_rot = _tv_random_rotation(canvas, -rot) > 0.5
         got_rot = E.rotate_nearest(canvas, -rot)
         assert np.array_equal(got_rot, want_rot), case
         want = _tv_translate(want_rot, tx, ty)[:R, :R] > 0.5
@@ -307,9 +319,26 @@ def test_resample_rule_is_torchvisions_tensor_path_on_placements(R):
         img = rng.random([R, R]) < 0.5
         angle = rng.uniform(-180.0, 180.0)                                  # MapGenerate.py:63
         t = [int(rng.random() ** 2 * R - R / 2), int(rng.random() ** 2 * R - R / 2)]
-        want = _tv_translate(_tv_rotate(img, -angle), t[0], t[1]) > 0.5
+        want = _tv_translate(_tv_random_rotation(img, -angle), t[0], t[1]) > 0.5
         got = E.translate_nearest(E.rotate_nearest(img, -angle), float(t[0]), float(t[1]), R, R)
         assert np.array_equal(got, want)
+
+
+def test_rotation_angle_passes_through_float32():
+    """RandomRotation hands F.rotate the angle as a float32 value; rounds 1-4 built the matrix from the float64
+    angle (oracle and kernels alike, so no HIP-vs-oracle test could see it).  The draw is float32(a) exactly, the oracle's
+    rotate_nearest follows it, and on dense images the two angles give different rasters often enough to tell them apart."""
+    rng = np.random.default_rng(11)
+    differ = 0
+    for _ in range(40):
+        a = rng.uniform(-180.0, 180.0)
+        drawn = float(torch.empty(1).uniform_(a, a).item())
+        assert drawn == float(np.float32(a))
+        img = rng.random([512, 512]) < 0.5
+        want = _tv_random_rotation(img, a) > 0.5
+        assert np.array_equal(E.rotate_nearest(img, a), want)
+        differ += int(not np.array_equal(_tv_rotate(img, a) > 0.5, want))
+    assert differ > 0          # the float64-angle form is a different raster on some of them: the test has teeth
 
 
 def test_affine_source_index_equals_grid_sample():
