@@ -46,3 +46,30 @@ def oracle_paths(seed, n, R, map_size, clearance, first_path_id=0):
 def oracle_maps(seed, precs, R, map_size, obstacles_size, K, clearance, placements, first_map_id=0):
     return E.generate_maps(E.PhiloxSource(seed), precs, R, map_size, obstacles_size, K, clearance, placements,
                            first_map_id=first_map_id)
+
+
+def wiring_weights(keys, shapes, seed):
+    """The weights of the NAT-wiring golden (tests/golden/g16_nat_wiring.npz): one deterministic array per state-dict key, from the
+    key's own legacy MT19937 stream (np.random.RandomState: frozen across NumPy versions), scaled by kind so that every branch of
+    the network carries signal — LayerScale 0.2..1.2 (the default 1e-5 would hide the residual branches), norms' weights around 1,
+    biases +-0.2, relative-position biases N(0, 0.5), matrices N(0, fan_in^-1/2).  The fixture stores the key list, the shapes and
+    a (sum, sum of squares) checksum per key instead of ~5 MB of random numbers; tests/golden/make_fixtures.py loads exactly these
+    arrays into the REFERENCE's own module."""
+    import zlib
+    out = {}
+    for k, shp in zip(keys, shapes):
+        rs = np.random.RandomState((zlib.crc32(k.encode()) + 7919 * seed) & 0x7FFFFFFF)
+        shp = tuple(int(v) for v in shp)
+        if k.endswith("gamma1") or k.endswith("gamma2"):
+            a = rs.uniform(0.2, 1.2, shp)
+        elif k.endswith("rpb"):
+            a = rs.normal(0.0, 0.5, shp)
+        elif len(shp) == 1 and k.endswith("weight"):
+            a = rs.uniform(0.7, 1.3, shp)
+        elif len(shp) == 1:
+            a = rs.uniform(-0.2, 0.2, shp)
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            a = rs.normal(0.0, fan_in ** -0.5, shp)
+        out[k] = np.ascontiguousarray(a, dtype=np.float64)
+    return out

@@ -520,8 +520,132 @@ def fixture_aevit():
     sys.path.remove(gen)
 
 
+
+# ----------------------------------------------------------------------------- G16 NAT / DiNAT wiring (B1, B2, B5's resize)
+def _install_segnet_stubs():
+    """SegNet/nat.py imports four third-party names (nat.py:10-14); none of them does arithmetic on the recorded path except the
+    attention op:
+      timm.models.layers.DropPath          -> identity module (eval mode / drop_path 0: what inference runs)
+      mmcv.runner.load_checkpoint          -> no-op (pretrained=None)
+      mmseg.utils.get_root_logger          -> no-op
+      mmseg.models.builder.BACKBONES       -> a registry whose register_module() returns the class unchanged
+      natten.NeighborhoodAttention2D       -> a torch module with NATTEN's parameters (qkv, rpb, proj) whose forward is the build's
+                                              statement of the op (oracle/segnet_ref.py na_fp64 = oracle/na_np.py as a gather).
+    So everything AROUND the attention — tokenizer, downsampler, Mlp, NATLayer with LayerScale, NATBlock, NAT.forward_tokens, the
+    output norms and permutes — is the reference's own code, and the attention op itself stays "parity unpinned" (NATTEN's source is
+    not in /root/reference)."""
+    import torch.nn as nn
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))          # repo root: oracle/
+    from oracle import segnet_ref as SR
+
+    class DropPath(nn.Module):
+        def __init__(self, drop_prob=0.0):
+            super().__init__()
+            assert not drop_prob or True
+
+        def forward(self, x):
+            assert not self.training
+            return x
+
+    class NeighborhoodAttention2D(nn.Module):
+        def __init__(self, dim, kernel_size, dilation=None, num_heads=1, qkv_bias=True, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
+            super().__init__()
+            assert qk_scale is None and attn_drop == 0.0 and proj_drop == 0.0
+            self.num_heads, self.kernel_size, self.dilation = num_heads, kernel_size, dilation or 1
+            self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+            self.rpb = nn.Parameter(torch.zeros(num_heads, 2 * kernel_size - 1, 2 * kernel_size - 1))
+            self.proj = nn.Linear(dim, dim)
+
+        def forward(self, x):
+            return SR.na_fp64(x, self.qkv.weight, self.qkv.bias, self.rpb, self.proj.weight, self.proj.bias, self.num_heads,
+                              self.kernel_size, self.dilation)
+
+    class _Registry:
+        def register_module(self, *a, **k):
+            return lambda cls: cls
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+    mod("timm"); mod("timm.models"); mod("timm.models.layers", DropPath=DropPath)
+    mod("mmcv"); mod("mmcv.runner", load_checkpoint=lambda *a, **k: None)
+    mod("mmseg"); mod("mmseg.utils", get_root_logger=lambda *a, **k: None)
+    mod("mmseg.models"); mod("mmseg.models.builder", BACKBONES=_Registry())
+    mod("natten", NeighborhoodAttention2D=NeighborhoodAttention2D)
+
+
+def fixture_nat_wiring():
+    """SegNet/nat.py (NAT, :212-332) and SegNet/dinat.py (DiNAT) imported UNMODIFIED with the stubs above, in float64, eval mode:
+    two small networks with dilated and padded levels — "dinat": embed 32, depths [2,2,2,1], heads [1,2,4,8] (head dim 32 as on
+    every DiNAT-B level), dilations [[1,3],[1,2],[1,2],[1]], LayerScale on, on a 96 x 128 input (levels 24x32, 12x16 — its d = 2
+    layer is padded to 14 rows —, 6x8 and 3x4: padded to 7 / 14); "nat": no dilations, no LayerScale (the `if not self.layer_scale`
+    branch of NATLayer.forward), 3 levels, out_indices (0, 2), 64 x 64 input.  Recorded: constructor arguments, state-dict key
+    order / shapes / checksums (the weights come from tests/_oracle_util.py wiring_weights), the input, every output level.
+    Also SegNet/mmseg/ops/wrappers.py (torch only, loaded by path): `resize` and `Upsample` as the heads and the segmentor call
+    them (setr_up_head.py:62-66: Upsample(scale_factor=2, mode='bilinear', align_corners=False); encoder_decoder.py:74-78: resize(size=
+    img.shape[2:], mode='bilinear', align_corners=False))."""
+    import importlib.util
+    _install_segnet_stubs()
+    seg = "/root/reference/SegNet"
+    sys.path.insert(0, seg)
+    sys.path.insert(0, os.path.dirname(OUT))                              # tests/: _oracle_util
+    import nat as NATMOD
+    import dinat as DINATMOD
+    from _oracle_util import wiring_weights
+    cases = {
+        "dinat": (DINATMOD.DiNAT, dict(embed_dim=32, mlp_ratio=2.0, depths=[2, 2, 2, 1], num_heads=[1, 2, 4, 8], drop_path_rate=0.2,
+                                       kernel_size=7, dilations=[[1, 3], [1, 2], [1, 2], [1]], out_indices=(0, 1, 2, 3), layer_scale=1e-5),
+                  (2, 3, 96, 128), 1),
+        "nat": (NATMOD.NAT, dict(embed_dim=32, mlp_ratio=3.0, depths=[1, 2, 1], num_heads=[1, 2, 4], drop_path_rate=0.0, kernel_size=7,
+                                 dilations=None, out_indices=(0, 2), layer_scale=None), (1, 3, 64, 64), 2),
+    }
+    out = {"cases": np.array(sorted(cases))}
+    for name, (cls, cfg, xshape, seed) in cases.items():
+        m = cls(**cfg).double()
+        m.eval()                                                          # (NAT.train returns None, nat.py:291-293: no chaining)
+        assert not m.training
+        sd = m.state_dict()
+        keys = list(sd.keys())
+        shapes = [tuple(v.shape) for v in sd.values()]
+        w = wiring_weights(keys, shapes, seed)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+        x = torch.from_numpy(np.random.RandomState(1000 + seed).normal(0.0, 1.0, xshape))
+        with torch.no_grad():
+            ys = m(x)
+        out[f"{name}/cfg"] = np.array(json.dumps(cfg))
+        out[f"{name}/seed"] = np.array([seed])
+        out[f"{name}/keys"] = np.array(keys)
+        out[f"{name}/shapes"] = np.array([json.dumps(s) for s in shapes])
+        out[f"{name}/checksum"] = np.array([[w[k].sum(), (w[k] ** 2).sum()] for k in keys])
+        out[f"{name}/x"] = x.numpy().astype(np.float32)                  # float32-representable input: the GPU test feeds the same values
+        x32 = torch.from_numpy(out[f"{name}/x"]).double()
+        with torch.no_grad():
+            ys = m(x32)
+        for i, y in zip(cfg["out_indices"], ys):
+            out[f"{name}/y{i}"] = y.numpy()
+    spec = importlib.util.spec_from_file_location("_ref_wrappers", os.path.join(seg, "mmseg", "ops", "wrappers.py"))
+    W = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(W)
+    rs = np.random.RandomState(16)
+    a = torch.from_numpy(rs.normal(0, 1, (2, 5, 6, 9)).astype(np.float32)).double()
+    out["resize/in"] = a.numpy()
+    with torch.no_grad():
+        out["resize/upsample2x"] = W.Upsample(scale_factor=2, mode="bilinear", align_corners=False)(a).numpy()
+        out["resize/to_24x36"] = W.resize(a, size=(24, 36), mode="bilinear", align_corners=False).numpy()
+        out["resize/to_13x7"] = W.resize(a, size=(13, 7), mode="bilinear", align_corners=False).numpy()
+        out["resize/to_11x17_ac"] = W.resize(a, size=(11, 17), mode="bilinear", align_corners=True, warning=False).numpy()
+    np.savez_compressed(os.path.join(OUT, "g16_nat_wiring.npz"), **out)
+    sys.path.remove(seg)
+
+
 def main():
     _install_stubs()
+    if len(sys.argv) > 1 and sys.argv[1] == "nat_wiring":
+        fixture_nat_wiring()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "aevit":
         fixture_aevit()
         return
@@ -555,6 +679,7 @@ def main():
     for mod in ("utils",):
         sys.modules.pop(mod, None)
     fixture_aevit()
+    fixture_nat_wiring()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
