@@ -221,9 +221,17 @@ def bench_ppnet(torch, dev, resolution, weights_dtype="bf16", calibrate=None):
     if calibrate is not None:
         seg.to(dev)
         balance_classifier_bias(seg, normalize_images(edage.grid_to_rgb(calibrate) * 255.0))
-    gen = randomize_neutral_parameters(AEViT(1, 1, resolution, 24).eval(), seed=2)
+    # GenNet: the checkpoint this build trained itself (tools/train_gennet.py -> ppnet_amd/weights/gennet_r{R}.pth, the reference's
+    # {'model': state_dict} layout), loaded as predict.py:51-52 loads one; seeded random weights where there is none
+    from ppnet_amd.gennet import load_trained
+    gen = AEViT(1, 1, resolution, 24).eval()
+    trained = load_trained(gen, resolution) and not os.environ.get("BENCH_UNTRAINED_GENNET")
+    if not trained:
+        gen = randomize_neutral_parameters(AEViT(1, 1, resolution, 24).eval(), seed=2)
     kw = {} if weights_dtype == "bf16" else {"weights_dtype": None}
-    return PPNet(resolution=resolution, segnet=seg, gennet=gen, **kw).to(dev).eval()
+    model = PPNet(resolution=resolution, segnet=seg, gennet=gen, **kw).to(dev).eval()
+    model.gennet_trained = bool(trained)
+    return model
 
 
 PARITY_TOLERANCE = {      # what tests/test_ppnet_config3.py asserts for the same objects (bf16 prepared vs float32)
@@ -448,10 +456,13 @@ def end_to_end_leg(torch, dev, steps, world, rank, cpu_leg):
     those grids (segment_u8), GenNet on SegNet's labels (heatmap) and the planner tail (extract_path + collision check) on
     GenNet's own heat map.  Instances shard by id over the ranks as in config 2; consecutive steps alternate over two HIP
     streams, each with its own buffers.  instances/s == plans/s here: every generated instance is planned.
-    No trained weights ship with the reference, so the chained tail finds (almost) no plan — `tail_network_output` says so;
-    the success / length criterion of the OMPL harness (reach (1 + eps) x the target length,
-    experiments/ompl_experiments/updated_geometric_planner.py:260-277,349-354) is evaluated on the last batch with ridge heat
-    maps along the label paths (`tail_ridge`, untimed).  OMPL itself is absent: problems are emitted in the harness's JSON
+    No trained weights ship with the reference: GenNet runs the checkpoint this build trained itself at 512 x 512
+    (tools/train_gennet.py), SegNet a seeded random initialisation whose labels are noise — so inside the chain GenNet reads the
+    generator's own mask_space of the same maps (PPNet.generate_and_plan(gennet_input="labels"): what SegNet is trained to emit; SegNet
+    still segments every grid inside the clock, its mask goes nowhere).  `tail_network_output` is the success / length criterion of
+    the OMPL harness (reach (1 + eps) x the target length, experiments/ompl_experiments/updated_geometric_planner.py:260-277,349-354)
+    on the last timed batch, i.e. on what the trained GenNet predicted; `tail_ridge` the same on ridge heat maps along the label
+    paths (untimed).  OMPL itself is absent: problems are emitted in the harness's JSON
     schema (dataset.problem_records / solution_records) for an external run."""
     import torch.distributed as dist
     from ppnet_amd import dataset, edage, evaluate, shard
@@ -468,7 +479,8 @@ def end_to_end_leg(torch, dev, steps, world, rank, cpu_leg):
         first_path, _, first_map = shard.local_ids(PATHS5 * world, PLACEMENTS5, rank, world, batch_index=it)
         marks = iter(timers) if timers else None
         r = model.generate_and_plan(pb, mb, PLACEMENTS5, first_path, first_map, seed=SEED + 5, obstacles_size=OBST_SIZE, obstacles_num=K,
-                                    mark=(lambda name: next(marks).record()) if timers else None)
+                                    mark=(lambda name: next(marks).record()) if timers else None,
+                                    gennet_input="labels" if model.gennet_trained else "segnet")
         if world > 1 and gather:                                              # end-of-batch gather of the plan records (RCCL, own stream)
             res = r["result"]
             rec = shard.pack_plan_records(res, evaluate.plan_lengths(res["waypoints"], res["counts"]))
@@ -523,7 +535,11 @@ def end_to_end_leg(torch, dev, steps, world, rank, cpu_leg):
                                   "-> AE-ViT (down_time 4) -> extract_path -> collision check, chained", "resolution": R5, "obstacles_num": K,
                       "clearance": CLEARANCE, "map_size": MAP_SIZE},
            "ms_generate": round(split[0], 3), "ms_segnet": round(split[1], 2), "ms_gennet": round(split[2], 2), "ms_tail": round(split[3], 3),
-           "tail_network_output": dict(rnd(ev_net), note="the timed chain: GenNet's own heat map (seeded random weights: noise, few plans)"),
+           "tail_network_output": dict(rnd(ev_net), note=("the timed chain's last batch: the TRAINED GenNet's heat map of the generator's label masks "
+                                                          "(SegNet untrained: its labels are computed and not used)") if model.gennet_trained
+                                       else "the timed chain: GenNet's own heat map (seeded random weights: noise, few plans)"),
+           "weights": {"gennet": f"trained by this build (ppnet_amd/weights/gennet_r{R5}.pth)" if model.gennet_trained else "seeded random init",
+                       "segnet": "seeded random init"},
            "tail_ridge": dict(rnd(ev_ridge), note="untimed, last batch: ridge heat maps along the label paths (GenNet's training target, blurred)"),
            "ompl": "unavailable (no OMPL python bindings in this image): PPNet column only",
            "harness_records": {"problems": len(problems), "with_solution": sum(1 for q in solved if q["Solution"][-1]["Waypoint"] is not None),
@@ -551,12 +567,14 @@ def end_to_end_leg(torch, dev, steps, world, rank, cpu_leg):
 def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None):
     """BASELINE config 3: PPNet inference (SegNet DiNAT-B + SETR-UP -> GenNet AE-ViT -> waypoint extraction ->
     collision check), batch of 256 problems over the 256x256 maps stage B just produced, per GPU.  Weights are
-    seeded random initialisations of the reference architectures (no trained weights ship with the reference), so the
-    heat map the networks emit is noise and a walk over it ends after a few steps.  The timed batch therefore runs both
-    networks on the grids and the planner tail on RIDGE heat maps along the label paths (evaluate.label_heatmaps: GenNet's
-    training target blurred — what a trained GenNet is fitted to emit), built once outside the timed region; the tail's
-    success rate and path-length ratio (config 5's criterion) are reported with it.  Ends with the end-of-batch gather of
-    the fixed-size plan records (RCCL, own stream) when N > 1."""
+    No trained weights ship with the reference.  GenNet holds the weights this build trained itself (tools/train_gennet.py, the
+    build's own training step on its own generator's pairs; ppnet_amd/weights/); SegNet (90 M parameters: no checkpoint fits a
+    repo) is a seeded random initialisation, so the labels it emits are noise.  The timed batch runs both networks on the grids —
+    every kernel of the chain, SegNet's labels into GenNet — and the planner tail on the heat maps the TRAINED GenNet predicts
+    from the generator's label masks of the same problems (mask_space, process_map.py:165-191: SegNet's training target), built
+    once outside the timed region: `tail_network_output` is the harness's success / length criterion (config 5's) on that
+    PREDICTION.  `tail_ridge` is the same on ridge maps along the label paths (GenNet's training target, blurred; untimed).
+    Ends with the end-of-batch gather of the fixed-size plan records (RCCL, own stream) when N > 1."""
     import torch.distributed as dist
     from ppnet_amd import evaluate, na, shard
     model = bench_ppnet(torch, dev, R, calibrate=mb.grid[:CALIBRATION_PROBLEMS])
@@ -565,7 +583,10 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None)
     g = mb.grid[:batch]
     init, end = mb.segpoint[:batch, 0].contiguous(), mb.segpoint[:batch, 10].contiguous()
     obs, n_obs = mb.obstacles[:batch], mb.n_obstacles[:batch, 0].contiguous()
+    from ppnet_amd import edage
     ridge = evaluate.label_heatmaps(pb, mb, PLACEMENTS)[:batch].contiguous()
+    _, space = edage.label_masks(pb, mb, PLACEMENTS, want_path=False, want_space=True)
+    tail_heat = model.heatmap(space[:batch].contiguous()) if model.gennet_trained else ridge     # the trained network's own prediction
     target_px = (pb.length.repeat_interleave(PLACEMENTS) * R / MAP_SIZE)[:batch]
     s_comm = torch.cuda.Stream(dev) if world > 1 else None
     gathered = torch.empty(world * batch, shard.PLAN_RECORD_WIDTH, dtype=torch.float64, device=dev) if world > 1 else None
@@ -576,7 +597,7 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None)
         if timers: timers[1].record()
         heat = model.heatmap(mask)
         if timers: timers[2].record()
-        res = model.plan_tail(ridge, init, end, obs, n_obs)
+        res = model.plan_tail(tail_heat, init, end, obs, n_obs)
         if timers: timers[3].record()
         if world > 1:                                                         # end-of-batch gather of the plan records
             rec = shard.pack_plan_records(res, evaluate.plan_lengths(res["waypoints"], res["counts"]))
@@ -605,7 +626,7 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None)
     # the timed region below stays eager; the graph is what pays at small batches, where the launches are the time.
     ms_graph = None
     if world == 1 and not os.environ.get("PPNET_NO_GRAPH"):
-        cp = model.capture(g, init, end, obs, n_obs, tail_heat=ridge)
+        cp = model.capture(g, init, end, obs, n_obs, tail_heat=tail_heat)
         cp.replay()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -643,6 +664,7 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None)
     seg_fl, gen_fl = ppnet_flops_per_plan(R)
     tflops = (seg_fl + gen_fl) * batch / (ms * 1e-3) / 1e12
     ev_tail = evaluate.evaluate_plans(res, target_px)
+    ev_ridge = evaluate.evaluate_plans(model.plan_tail(ridge, init, end, obs, n_obs), target_px)
     net_tail = model.plan_tail(heat, init, end, obs, n_obs)
     # the same batch CHAINED end to end — the planner tail walks GenNet's own heat map (PPNet.plan) — on the same two streams: with
     # untrained weights that map is noise and the walk ends early, so this is the lighter batch; reported beside the ridge-map one
@@ -663,10 +685,16 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None)
            "ms_segnet": round(t_seg, 2), "ms_gennet": round(t_gen, 2), "ms_tail": round(t_tail, 2),
            "ms_per_batch_hip_graph": round(ms_graph, 2) if ms_graph is not None else None, "streams": n_streams,
            "ms_per_batch_chained_network_output": round(ms_chained, 2),
-           "weights": "seeded random init, neutral parameters randomised too (no trained weights in the reference)",
-           "tail_input": "ridge heat maps along the label paths (GenNet's training target, blurred); the networks' own output is noise",
-           "tail": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ev_tail.items()},
-           "extract_ok_rate_network_output": round(float(net_tail["ok"].float().mean().item()), 4),
+           "weights": {"gennet": ("trained by this build (tools/train_gennet.py; ppnet_amd/weights/gennet_r%d.pth, reference checkpoint layout)" % R)
+                                 if model.gennet_trained else "seeded random init",
+                       "segnet": "seeded random init, neutral parameters randomised too (no trained weights in the reference; 90 M parameters)"},
+           "tail_input": ("the TRAINED GenNet's heat maps of the generator's label masks (mask_space) of the same problems" if model.gennet_trained
+                          else "ridge heat maps along the label paths (GenNet's training target, blurred)"),
+           "tail_network_output": dict({k: (round(v, 4) if isinstance(v, float) else v) for k, v in ev_tail.items()},
+                                       note="timed tail: success / length criterion of the OMPL harness on what the trained GenNet PREDICTS from label masks"
+                                       if model.gennet_trained else "no trained GenNet checkpoint found: ridge maps"),
+           "tail_ridge": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ev_ridge.items()},
+           "extract_ok_rate_untrained_segnet_chain": round(float(net_tail["ok"].float().mean().item()), 4),
            "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tflops / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": None,
                         "gflop_per_plan": round((seg_fl + gen_fl) / 1e9, 2), "gflop_segnet": round(seg_fl / 1e9, 2),
@@ -675,7 +703,7 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None)
                                       "algorithmic_bytes": na_bytes, "achieved": round(na_bytes / (na_ms * 1e-3) / 1e9, 1),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(na_bytes / (na_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}}
     if cpu_leg:
-        out["cpu_baseline"] = ppnet_cpu_baseline(torch, g, ridge, init, end, obs, n_obs, R)
+        out["cpu_baseline"] = ppnet_cpu_baseline(torch, g, tail_heat, init, end, obs, n_obs, R)
     return out
 
 

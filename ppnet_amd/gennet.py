@@ -11,6 +11,8 @@ own module by tests/golden/g13_aevit.npz.
 import math
 from functools import partial
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -294,3 +296,23 @@ def normalize_heatmap_u8(y):
     hi = f.max(dim=1, keepdim=True).values
     n = (f - lo) / (hi - lo)
     return (n * 255).to(torch.uint8).reshape(B, y.shape[-2], y.shape[-1])    # ToPILImage: mul(255).byte()
+
+
+WEIGHTS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "weights")
+
+
+def trained_checkpoint(resolution):
+    """Path of the GenNet checkpoint this build trained itself at `resolution` (tools/train_gennet.py: the build's own training step
+    on pairs from the build's own generator; the reference ships no weights), or None.  The file has the reference's layout —
+    {'model': state_dict}, float32 (GenNet/train.py:133-141; predict.py:51-52 reads that key)."""
+    path = os.path.join(WEIGHTS_DIR, f"gennet_r{int(resolution)}.pth")
+    return path if os.path.exists(path) else None
+
+
+def load_trained(model, resolution):
+    """Load trained_checkpoint(resolution) into an (unprepared) AEViT the way predict.py:51-52 does; returns True if there was one."""
+    path = trained_checkpoint(resolution)
+    if path is None:
+        return False
+    model.load_state_dict(torch.load(path, map_location="cpu", weights_only=True)["model"], strict=True)
+    return True

@@ -114,12 +114,16 @@ class PPNet(torch.nn.Module):
 
     @torch.no_grad()
     def generate_and_plan(self, paths, maps, placements, first_path_id=0, first_map_id=0, seed=0, obstacles_size=5, obstacles_num=20,
-                          clearance=None, down_sample_rate=2, mark=None):
+                          clearance=None, down_sample_rate=2, mark=None, gennet_input="segnet"):
         """BASELINE config 5's chain on the current stream, nothing read back in between: stage A into `paths` (a PathsBatch) ->
         stage B into `maps` (paths.n x placements maps) -> SegNet labels of those grids -> GenNet heat map of those labels ->
         extract_path + collision check on that heat map, start / goal / obstacles straight from `maps`
         (EDaGe-PP/MapGenerate.py:40-124 -> SegNet/test.py -> GenNet/predict.py -> process_map.py:452-506).
         mark: optional callable(stage name) called between the stages (bench.py records timing events with it).
+        gennet_input: "segnet" — GenNet reads SegNet's labels, the reference's chain — or "labels": GenNet reads the generator's own
+        mask_space of the same maps (ppn_label_masks, process_map.py:165-191: what SegNet is TRAINED to emit and GenNet was trained
+        on).  SegNet still segments every grid — same kernels, same time — its mask is returned, and nothing downstream reads it: for
+        a chain whose SegNet holds no trained weights (none ship with the reference, and a DiNAT-B checkpoint does not fit a repo).
         Returns dict(mask, heat, result)."""
         mark = mark or (lambda name: None)
         mark("start")
@@ -129,7 +133,11 @@ class PPNet(torch.nn.Module):
         mark("generated")
         mask = self.segment_u8(maps.grid)
         mark("segmented")
-        heat = self.heatmap(mask)
+        if gennet_input == "labels":
+            _, space = edage.label_masks(paths, maps, placements, want_path=False, want_space=True)
+            heat = self.heatmap(space)
+        else:
+            heat = self.heatmap(mask)
         mark("heatmap")
         init, end = maps.segpoint[:, 0].contiguous(), maps.segpoint[:, 10].contiguous()
         result = self.plan_tail(heat, init, end, maps.obstacles, maps.n_obstacles[:, 0].contiguous(), clearance, down_sample_rate)
