@@ -7,6 +7,7 @@
 #include <string.h>
 #include <vector>
 
+#include <cstdlib>
 #include "ppn_kernels.h"
 
 namespace {
@@ -637,6 +638,24 @@ int ppn_nat_gemm_bf16(const void* a, const void* w, const float* bias, const flo
     if (mode != 2 && (!colsum || !stats_in || partials_in < 1 || partials_in > 4 || K / 64 < 3)) return PPN_E_INVALID;
     if (mode == 2 && !stats_out) return PPN_E_INVALID;
     if ((long long)N * 2 * 8 >= (1LL << 31) || (long long)K * 2 * 8 >= (1LL << 31)) return PPN_E_UNSUPPORTED;     // per-lane 32-bit offsets
+    // mode 2 (round 5): the 256 x 256 core of mfma_gemm.h with the old c read in its epilogue — faster than both round-4 forms on all six
+    // shapes (profiles/r05_natgemm_timing.txt); PPNET_NAT_ACC=old selects those (A/B)
+    static const bool acc_old = [] { const char* v = getenv("PPNET_NAT_ACC"); return v && v[0] == 'o'; }();
+    if (mode == 2 && !acc_old && K >= 128) {
+        const int n_cu = ppn::device_cu_count();
+        if (!n_cu) return hip_fail(hipErrorInvalidDevice);
+        const int e2 = ppn::gemm_acc_stats_launch(a, w, bias, stats_out, c, M, N, K, ppn::nat_gemm128_partials(N) ? 1 : 0, n_cu, (hipStream_t)stream);
+        if (e2 != 0) return hip_fail((hipError_t)e2);
+        return PPN_OK;
+    }
+    static const bool ln_old = [] { const char* v = getenv("PPNET_NAT_LN"); return v && v[0] == 'o'; }();
+    if (mode != 2 && !ln_old && K >= 128) {
+        const int n_cu = ppn::device_cu_count();
+        if (!n_cu) return hip_fail(hipErrorInvalidDevice);
+        const int e2 = ppn::gemm_ln_launch(a, w, bias, colsum, stats_in, partials_in, c, M, N, K, mode == 1, eps, n_cu, (hipStream_t)stream);
+        if (e2 != 0) return hip_fail((hipError_t)e2);
+        return PPN_OK;
+    }
     // the HBM-bound levels (stream width <= 512) run on the small-tile kernel of nat_gemm128.hip, the rest on nat_gemm.hip's persistent one
     const int e = ppn::nat_gemm128_wanted(N, K, mode)
                       ? ppn::nat_gemm128_launch(a, w, bias, colsum, stats_in, partials_in, stats_out, c, M, N, K, mode, eps, (hipStream_t)stream)

@@ -45,10 +45,20 @@ enum Epi {
     EPI_BIAS_GELU = 1,   // C = gelu(acc + bias[n])              (erf form, torch.nn.GELU default)
     EPI_ACCUM = 2,       // C = C + acc                           (residual stream update, bias carried outside)
     EPI_BIAS_RELU = 3,   // C = max(acc + bias[n], 0)             (conv + folded BatchNorm + ReLU)
-    EPI_RELU_DOT2 = 4    // partial[slot][m][c] = sum_{n in slot} max(acc + bias[n], 0) * w2[c][n], c = 0, 1, slot = a 256-column block
+    EPI_RELU_DOT2 = 4,   // partial[slot][m][c] = sum_{n in slot} max(acc + bias[n], 0) * w2[c][n], c = 0, 1, slot = a 256-column block
                          // (the 1x1 classifier on top; a block's four wave columns are added in order inside the workgroup, the slots in
                          // order by classify2_reduce_kernel: no atomics.  N <= 256: one slot, added straight onto the logits)
+    EPI_ACCUM_STATS = 5, // C = C + acc + bias[n] in place, and (sum, sum of squares) of every row of the NEW C (of the bf16 values stored)
+                         // per 128 or 256 columns -> stats[partial][m][2]: the accumulating projections of a NAT layer (proj, fc2:
+                         // SegNet/nat.py:145-153), whose row statistics the next LayerNorm-folded projection reads (nat_gemm.hip).
+                         // Persistent launches only.  Round 5: the old C is READ IN THE EPILOGUE — round 3-4's nat_gemm.hip fed it
+                         // through the matrix pipe as four identity k-tiles (+25 ... +100 % MFMA and LDS work at K = 1024 ... 256)
+    EPI_LN_BIAS = 6,     // C = LN(A) W^T + b WITHOUT a LayerNorm pass (nat_gemm.hip's algebra): with B = W diag(gamma), bias = b + W beta,
+    EPI_LN_BIAS_GELU = 7 // colsum[n] = sum_k B[n][k]:  C = rstd_m (acc - mean_m colsum[n]) + bias[n]  [then erf-GELU, logistic fit, |err| < 3e-5];
+                         // mean / rstd of row m of A from the partial (sum, sum of squares) in stats[P][M][2] (EPI_ACCUM_STATS of the
+                         // projection in front, the fused MLP kernel, or ppn_row_stats_bf16).  Persistent launches only.
 };
+__host__ __device__ constexpr int lds_bytes(int epi) { return LDS_BYTES + (epi == EPI_ACCUM_STATS ? 4 * BM * 8 : 0); }   // + float2 red[4 wave columns][256 rows]
 
 struct Params {
     const __bf16* A;
@@ -63,6 +73,13 @@ struct Params {
     // EPI_RELU_DOT2
     const float* w2;       // [2][N]
     float* logits;         // EPI_RELU_DOT2: N > 256: the partial sums [ceil(N / 256)][M][2]; else the logits [M][2] themselves (+=)
+    // EPI_ACCUM_STATS
+    float* stats;          // [N / 128 or N / 256][M][2]
+    int stats_p128;        // 1: one partial per 128 columns (streams of width 256: what the fused MLP kernel emits too), 0: per 256
+    // EPI_LN_BIAS / EPI_LN_BIAS_GELU: `stats` is the INPUT [stats_parts][M][2]
+    const float* colsum;   // [N]
+    int stats_parts;       // 1..4
+    float inv_k, eps;
 };
 
 __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_uniform) {
@@ -72,12 +89,24 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_uniform
 
 // erf-form GELU (torch.nn.GELU default).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of
 // the result): one v_exp, one v_rcp and six FMAs instead of libm's ~40-instruction erff — the epilogue holds 128 values per lane.
+// 8-byte LDS accesses through the fragment element type: hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of float2 / float4-
+// typed LDS accesses while an LDS-DMA is in flight (it cannot tell which bytes the DMA writes) and leaves these alone (nat_gemm.hip)
+__device__ __forceinline__ float2 lds_f2(const void* ptr) { return __builtin_bit_cast(float2, *reinterpret_cast<const bf16x4*>(ptr)); }
+__device__ __forceinline__ void lds_st_f2(void* ptr, float2 v) { *reinterpret_cast<bf16x4*>(ptr) = __builtin_bit_cast(bf16x4, v); }
+
 __device__ __forceinline__ float gelu_erf(float x) {
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float e = 1.0f - poly * __expf(-z * z);                     // erf(|x| / sqrt 2)
     return 0.5f * x + 0.5f * fabsf(x) * e;                            // 0.5 x (1 + sign(x) e)
+}
+
+// erf-GELU through a logistic fit of erf (nat_gemm.hip): x / (1 + 2^(-x (p0 + p1 x^2 + p2 x^4))), |error| < 3.0e-5
+__device__ __forceinline__ float gelu_logistic(float x) {
+    const float x2 = fminf(x * x, 64.0f);
+    const float t = x * (2.3009787f + x2 * (0.10690469f - 1.0350827e-3f * x2));
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-t));
 }
 
 // What one output tile needs from this lane: source pointers of its 16-byte pieces of the four quarter-tiles.
@@ -242,23 +271,66 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
             prev[mt] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint4*>(p.C + (size_t)m * p.ldc + n) : make_uint4(0u, 0u, 0u, 0u);
         }
     };
-    auto finish_quadrant = [&](int ap, int bp, int m0, int n0, const uint4 (&prev)[4]) {
-        int n = n0 + wc * 64 + bp * 32 + qcol;
-        const bool n_in = n < p.N;                                         // N % 8 == 0: a group of 8 is in or out
-        if (n > p.N - 8) n = p.N - 8;
-        float bq[8];
+    float rs1[2][4], rs2[2][4];                                            // EPI_ACCUM_STATS: this lane's share of its rows' (sum, sum of squares)
+    constexpr bool EPI_LN = (EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_GELU);
+    float rrs[2][4], rnm[2][4];                                            // EPI_LN_*: (rstd, -rstd * mean) of this lane's 8 rows of the tile
+    auto row_norms = [&](int m0) {
+        // Lane quarter fq of a row's four lanes fetches partial fq (an unconditional load of a clamped index, weighted 0 beyond
+        // stats_parts: a load inside a branch or a run-time loop is waited for one at a time — 8 x P dependent round trips, 4 us per
+        // tile when it was written that way); the four are added across the quarters in a fixed tree (bit-reproducible).
+        const int pi = fq < p.stats_parts ? fq : p.stats_parts - 1;
+        const float wgt = fq < p.stats_parts ? 1.0f : 0.0f;
+        float2 v[2][4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bq[e] = 0.f;
+        for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                int m = m0 + wr * 128 + ap * 64 + mt * 16 + frow;
+                if (m >= p.M) m = p.M - 1;
+                v[ap][mt] = *reinterpret_cast<const float2*>(p.stats + ((size_t)pi * p.M + m) * 2);
+            }
+#pragma unroll
+        for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                float sx = v[ap][mt].x * wgt, sq = v[ap][mt].y * wgt;
+                sx += __shfl_xor(sx, 16, 64); sq += __shfl_xor(sq, 16, 64);
+                sx += __shfl_xor(sx, 32, 64); sq += __shfl_xor(sq, 32, 64);
+                const float mean = sx * p.inv_k;
+                const float rstd = __builtin_amdgcn_rsqf(fmaxf(sq * p.inv_k - mean * mean, 0.f) + p.eps);
+                rrs[ap][mt] = rstd; rnm[ap][mt] = -rstd * mean;
+            }
+    };
+    // the per-column vectors of a quadrant's 8 columns of this lane (bias, and colsum for the LayerNorm-folded forms)
+    auto load_cols = [&](int bp, int n0, float (&bq)[8], float (&cq)[8]) {
+        int n = n0 + wc * 64 + bp * 32 + qcol;
+        if (n > p.N - 8) n = p.N - 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bq[e] = 0.f; cq[e] = 0.f; }
         if (EPI != EPI_ACCUM) {
             const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
             bq[0] = b0.x; bq[1] = b0.y; bq[2] = b0.z; bq[3] = b0.w; bq[4] = b1.x; bq[5] = b1.y; bq[6] = b1.z; bq[7] = b1.w;
         }
+        if (EPI_LN) {
+            const float4 c0 = *reinterpret_cast<const float4*>(p.colsum + n), c1 = *reinterpret_cast<const float4*>(p.colsum + n + 4);
+            cq[0] = c0.x; cq[1] = c0.y; cq[2] = c0.z; cq[3] = c0.w; cq[4] = c1.x; cq[5] = c1.y; cq[6] = c1.z; cq[7] = c1.w;
+        }
+    };
+    auto finish_quadrant = [&](int ap, int bp, int m0, int n0, const uint4 (&prev)[4], const float (&bq)[8], const float (&cq)[8]) {
+        int n = n0 + wc * 64 + bp * 32 + qcol;
+        const bool n_in = n < p.N;                                         // N % 8 == 0: a group of 8 is in or out
+        if (n > p.N - 8) n = p.N - 8;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             f32x4 x = acc[ap][mt][bp][0], y = acc[ap][mt][bp][1];
             swap_rows(x, y);
-            float o[8] = {x[0] + bq[0], x[1] + bq[1], x[2] + bq[2], x[3] + bq[3], y[0] + bq[4], y[1] + bq[5], y[2] + bq[6], y[3] + bq[7]};
-            if (EPI == EPI_ACCUM) {
+            float o[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (EPI_LN) o[e] = fmaf(rrs[ap][mt], o[e], fmaf(rnm[ap][mt], cq[e], bq[e]));
+                else o[e] += bq[e];
+            }
+            if (EPI == EPI_ACCUM || EPI == EPI_ACCUM_STATS) {
                 const bf16x8 s8 = __builtin_bit_cast(bf16x8, prev[mt]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] += (float)s8[e];
@@ -266,11 +338,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (EPI == EPI_BIAS_GELU) o[e] = gelu_erf(o[e]);
+                if (EPI == EPI_LN_BIAS_GELU) o[e] = gelu_logistic(o[e]);
                 if (EPI == EPI_BIAS_RELU) o[e] = fmaxf(o[e], 0.f);
             }
             const bf16x8 w = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3], (__bf16)o[4], (__bf16)o[5], (__bf16)o[6], (__bf16)o[7]};
             const int m = m0 + wr * 128 + ap * 64 + mt * 16 + frow;
             if (m < p.M && n_in) *reinterpret_cast<bf16x8*>(p.C + (size_t)m * p.ldc + n) = w;
+            if (EPI == EPI_ACCUM_STATS) {                                     // of the ROUNDED values: what the next projection reads
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)w[e]; a1 += f; a2 += f * f; }
+                if (bp == 0) { rs1[ap][mt] = a1; rs2[ap][mt] = a2; } else { rs1[ap][mt] += a1; rs2[ap][mt] += a2; }
+            }
             acc[ap][mt][bp][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ap][mt][bp][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -284,7 +363,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
     // (with the stagger, the other group's reads of it finish one barrier later), and it is waited for one phase before its
     // first read: vmcnt(8) in phases 4, 1 and 2 leaves the four youngest quarter-tiles (8 DMA instructions per lane) in flight;
     // the barrier of that phase publishes the rest.  After an epilogue the same three waits allow EPI_STORES more.
-    constexpr int EPI_STORES = 16;                                      // vector-memory instructions an epilogue leaves in the queue
+    constexpr int EPI_STORES = 16;                                      // vector-memory instructions an epilogue leaves in the queue (EPI_ACCUM_STATS: +1 / +2 in
+                                                                        // wave group 0, whose first waits then reach one or two stores further back: conservative)
     const int G = gridDim.x;
     const int my_tiles = (nblk - (int)blockIdx.x + G - 1) / G;
     const int total = my_tiles * nk;                                    // k-tiles in this block's stream
@@ -298,10 +378,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();           // the stagger: this group's barriers pair with the other's next ones
 
+    // (EPI_ACCUM_STATS: wave group 0 also stores the row partials — one or two more instructions in ITS queue; a wait that allowed
+    // only 8 + 16 would reach back to the tile's first stores, which drain slowly: +3 us per tile boundary when it did)
+    const int extra_stores = (EPI == EPI_ACCUM_STATS && wr == 0) ? (p.stats_p128 ? 2 : 1) : 0;
 #define PPN_GEMM_WAIT(full, wide) do {                                                          \
         if (!(full)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
-        else if (wide) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + EPI_STORES) : "memory");  \
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                   \
+        else if (wide) {                                                                        \
+            if (extra_stores == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + EPI_STORES) : "memory");          \
+            else if (extra_stores == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(9 + EPI_STORES) : "memory");     \
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(10 + EPI_STORES) : "memory");        \
+        } else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                 \
     } while (0)
 #define PPN_GEMM_MMA(ap, bp, fb) do {                          \
         __builtin_amdgcn_s_barrier();                          \
@@ -316,7 +402,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
     // One tile per workgroup (the default launch): the tile's LAST k-tile is peeled and each quadrant is finished — converted,
     // exchanged, stored — in the phase after its final MFMAs, in the segment where this wave group only reads and the other group
     // owns the matrix pipe; three quarters of the store tail then overlap the remaining quadrants' MFMAs.
-    const bool overlap = (my_tiles == 1) && (EPI != EPI_RELU_DOT2);
+    const bool overlap = (my_tiles == 1) && (EPI != EPI_RELU_DOT2) && (EPI != EPI_ACCUM_STATS) && !EPI_LN;
     int g = 0, cur_m0 = 0, cur_n0 = 0;
     for (int it = 0; it < my_tiles; ++it) {
         const int nk_loop = overlap ? nk - 1 : nk;
@@ -360,17 +446,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
             if (EPI == EPI_ACCUM) load_prev(0, 0, m0, n0, pa);
             PPN_GEMM_MMA(0, 0, fb0);
             load_b(buf, 1, fb1);
-            finish_quadrant(0, 0, m0, n0, pa);
+            { float bq[8], cq[8]; load_cols(0, n0, bq, cq); finish_quadrant(0, 0, m0, n0, pa, bq, cq); }
             if (EPI == EPI_ACCUM) load_prev(0, 1, m0, n0, pb);
             PPN_GEMM_MMA(0, 1, fb1);
             load_a(buf, 1);
-            finish_quadrant(0, 1, m0, n0, pb);
+            { float bq[8], cq[8]; load_cols(1, n0, bq, cq); finish_quadrant(0, 1, m0, n0, pb, bq, cq); }
             if (EPI == EPI_ACCUM) load_prev(1, 1, m0, n0, pa);
             PPN_GEMM_MMA(1, 1, fb1);
-            finish_quadrant(1, 1, m0, n0, pa);
+            { float bq[8], cq[8]; load_cols(1, n0, bq, cq); finish_quadrant(1, 1, m0, n0, pa, bq, cq); }
             if (EPI == EPI_ACCUM) load_prev(1, 0, m0, n0, pb);
             PPN_GEMM_MMA(1, 0, fb0);
-            finish_quadrant(1, 0, m0, n0, pb);
+            { float bq[8], cq[8]; load_cols(0, n0, bq, cq); finish_quadrant(1, 0, m0, n0, pb, bq, cq); }
             ++g;
         } else if (EPI == EPI_RELU_DOT2) {
             // max(acc + bias, 0) . w2[c] over this wave's 64 columns: reduce over the 4 lane quarters, then ONE plain 8-byte store per
@@ -413,19 +499,59 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
                     if (fq == 0) reinterpret_cast<float2*>(lds + (g & 1) * BUF_BYTES)[wc * BM + wr * 128 + ap * 64 + mt * 16 + frow] = make_float2(s0, s1);
                 }
         } else {
-            // persistent form: the whole tile is finished here; exactly EPI_STORES vector-memory instructions stay in the queue
-            if (EPI == EPI_ACCUM) {
+            // persistent form: the whole tile is finished here; exactly EPI_STORES vector-memory instructions stay in the queue.
+            // The two wave groups run one barrier apart, so left alone their epilogues SERIALISE: group 0's next barrier (phase 1 of
+            // the next tile) pairs with group 1's last one of this tile, group 1 waits there through group 0's whole epilogue and
+            // group 0 then waits through group 1's (measured round 5: 2 x ~2 us per tile).  One extra barrier of group 0 in front
+            // aligns the groups, both finish their halves of the tile at the same time, and one extra barrier of group 1 behind the
+            // epilogue restores the stagger for the next tile's k-loop.
+            if (wr == 0) __builtin_amdgcn_s_barrier();
+            if (EPI == EPI_ACCUM || EPI == EPI_ACCUM_STATS) {
                 uint4 pq[4][4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) load_prev(q >> 1, q & 1, m0, n0, pq[q]);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the 16 reads drain the queue once
+                float bq[2][8], cq[2][8];
+                load_cols(0, n0, bq[0], cq[0]); load_cols(1, n0, bq[1], cq[1]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the 16 + 4 reads drain the queue once
 #pragma unroll
-                for (int q = 0; q < 4; ++q) finish_quadrant(q >> 1, q & 1, m0, n0, pq[q]);
+                for (int q = 0; q < 4; ++q) finish_quadrant(q >> 1, q & 1, m0, n0, pq[q], bq[q & 1], cq[q & 1]);
+                if (EPI == EPI_ACCUM_STATS) {
+                    // row sums: over the row's 4 lanes (xor 16, 32), then red[wave column][row of the tile] in LDS; thread r of wave
+                    // group 0 adds the wave columns IN ORDER (bit-reproducible, no atomics) and is the only writer of (partial, row).
+                    float2* red = reinterpret_cast<float2*>(lds + LDS_BYTES);
+#pragma unroll
+                    for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            float a1 = rs1[ap][mt], a2 = rs2[ap][mt];
+                            a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
+                            a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+                            if (fq == 0) lds_st_f2(red + wc * BM + wr * 128 + ap * 64 + mt * 16 + frow, make_float2(a1, a2));
+                        }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                          // (the groups are aligned here: one barrier publishes all eight waves' sums)
+                    if (wr == 0) {
+                        const float2 r0 = lds_f2(red + tid), r1 = lds_f2(red + BM + tid), r2 = lds_f2(red + 2 * BM + tid), r3 = lds_f2(red + 3 * BM + tid);
+                        float2* so = reinterpret_cast<float2*>(p.stats);
+                        if (p.stats_p128) {
+                            so[(size_t)(n0 / 128) * p.M + m0 + tid] = make_float2(r0.x + r1.x, r0.y + r1.y);
+                            so[(size_t)(n0 / 128 + 1) * p.M + m0 + tid] = make_float2(r2.x + r3.x, r2.y + r3.y);
+                        } else {
+                            so[(size_t)(n0 / BN) * p.M + m0 + tid] = make_float2(((r0.x + r1.x) + r2.x) + r3.x, ((r0.y + r1.y) + r2.y) + r3.y);
+                        }
+                    }
+                }
             } else {
+                // every load of the epilogue in front of its first store: a load's first use drains the WHOLE queue (hipcc waits
+                // vmcnt(0) for an ordinary load beside LDS-DMA), and behind a quadrant's stores that drain would wait for them too
                 const uint4 none[4] = {};
+                float bq[2][8], cq[2][8];
+                load_cols(0, n0, bq[0], cq[0]); load_cols(1, n0, bq[1], cq[1]);
+                if (EPI_LN) row_norms(m0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) finish_quadrant(q >> 1, q & 1, m0, n0, none);
+                for (int q = 0; q < 4; ++q) finish_quadrant(q >> 1, q & 1, m0, n0, none, bq[q & 1], cq[q & 1]);
             }
+            if (wr == 1) __builtin_amdgcn_s_barrier();       // the stagger again: pairs with group 0's first barrier of the next tile (or its closing one)
         }
         // next tile
         cur = nxt;

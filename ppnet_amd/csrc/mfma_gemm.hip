@@ -31,11 +31,11 @@ namespace {
 template <int AMODE, int EPI>
 int launch(const gemm::Params& p, int persistent, hipStream_t stream) {
     static DeviceOnce attr;
-    if (const int e = dynamic_lds_once(attr, (const void*)gemm::gemm_bf16_kernel<AMODE, EPI>, gemm::LDS_BYTES)) return e;
+    if (const int e = dynamic_lds_once(attr, (const void*)gemm::gemm_bf16_kernel<AMODE, EPI>, gemm::lds_bytes(EPI))) return e;
     const int tiles = ((p.M + gemm::BM - 1) / gemm::BM) * ((p.N + gemm::BN - 1) / gemm::BN);
     int grid = tiles;
     if (persistent > 0 && tiles > persistent && p.M % gemm::BM == 0 && p.N % gemm::BN == 0) grid = persistent;   // one block per CU
-    hipLaunchKernelGGL((gemm::gemm_bf16_kernel<AMODE, EPI>), dim3(grid), dim3(gemm::NTHREADS), gemm::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((gemm::gemm_bf16_kernel<AMODE, EPI>), dim3(grid), dim3(gemm::NTHREADS), gemm::lds_bytes(EPI), stream, p);
     return (int)hipGetLastError();
 }
 
@@ -90,6 +90,47 @@ int gemm_mfma_launch(const void* a, const void* w, const float* bias, void* c, l
         case 3: return launch<gemm::DENSE, gemm::EPI_BIAS_RELU>(p, persistent, stream);
         default: return -1;
     }
+}
+
+// ppn_nat_gemm_bf16 mode 2 (round 5): c += a w^T + bias in place + row partials of the new c, on the 256 x 256 core with the old c
+// read in the epilogue.  M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128; p128: one partial per 128 columns (else per 256).
+int gemm_acc_stats_launch(const void* a, const void* w, const float* bias, float* stats, void* c, long long M, int N, int K, int p128,
+                          int n_cu, hipStream_t stream) {
+    gemm::Params p{};
+    p.A = (const __bf16*)a; p.B = (const __bf16*)w; p.C = (__bf16*)c; p.bias = bias;
+    p.M = (int)M; p.N = N; p.K = K; p.lda = K; p.ldc = N;
+    p.stats = stats; p.stats_p128 = p128;
+    static DeviceOnce attr;
+    if (const int e = dynamic_lds_once(attr, (const void*)gemm::gemm_bf16_kernel<gemm::DENSE, gemm::EPI_ACCUM_STATS>, gemm::lds_bytes(gemm::EPI_ACCUM_STATS))) return e;
+    const int tiles = (p.M / gemm::BM) * (p.N / gemm::BN);
+    int grid = tiles < n_cu ? tiles : n_cu;
+    if (grid > 8) grid &= ~7;                                        // the XCD-aware tile order wants a multiple of 8
+    hipLaunchKernelGGL((gemm::gemm_bf16_kernel<gemm::DENSE, gemm::EPI_ACCUM_STATS>), dim3(grid), dim3(gemm::NTHREADS),
+                       gemm::lds_bytes(gemm::EPI_ACCUM_STATS), stream, p);
+    return (int)hipGetLastError();
+}
+
+// ppn_nat_gemm_bf16 modes 0 / 1 (round 5): c = [gelu](LN(a) w^T + b) with the LayerNorm folded into the epilogue of the 256 x 256 core
+// (persistent launch, the two wave groups' epilogues side by side); stats [parts][M][2] = row partials of a.
+int gemm_ln_launch(const void* a, const void* w, const float* bias, const float* colsum, const float* stats, int parts, void* c, long long M,
+                   int N, int K, int gelu, float eps, int n_cu, hipStream_t stream) {
+    gemm::Params p{};
+    p.A = (const __bf16*)a; p.B = (const __bf16*)w; p.C = (__bf16*)c; p.bias = bias; p.colsum = colsum;
+    p.M = (int)M; p.N = N; p.K = K; p.lda = K; p.ldc = N;
+    p.stats = const_cast<float*>(stats); p.stats_parts = parts; p.inv_k = 1.0f / (float)K; p.eps = eps;
+    const int tiles = (p.M / gemm::BM) * (p.N / gemm::BN);
+    int grid = tiles < n_cu ? tiles : n_cu;
+    if (grid > 8) grid &= ~7;
+    if (gelu) {
+        static DeviceOnce attr;
+        if (const int e = dynamic_lds_once(attr, (const void*)gemm::gemm_bf16_kernel<gemm::DENSE, gemm::EPI_LN_BIAS_GELU>, gemm::LDS_BYTES)) return e;
+        hipLaunchKernelGGL((gemm::gemm_bf16_kernel<gemm::DENSE, gemm::EPI_LN_BIAS_GELU>), dim3(grid), dim3(gemm::NTHREADS), gemm::LDS_BYTES, stream, p);
+    } else {
+        static DeviceOnce attr;
+        if (const int e = dynamic_lds_once(attr, (const void*)gemm::gemm_bf16_kernel<gemm::DENSE, gemm::EPI_LN_BIAS>, gemm::LDS_BYTES)) return e;
+        hipLaunchKernelGGL((gemm::gemm_bf16_kernel<gemm::DENSE, gemm::EPI_LN_BIAS>), dim3(grid), dim3(gemm::NTHREADS), gemm::LDS_BYTES, stream, p);
+    }
+    return (int)hipGetLastError();
 }
 
 }  // namespace ppn

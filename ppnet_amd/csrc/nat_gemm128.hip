@@ -243,7 +243,9 @@ static int knob() {
     static const int k = [] { const char* e = getenv("PPNET_NAT_GEMM128"); return !e ? 1 : (e[0] == '0' ? 0 : (e[0] == 'a' ? 2 : 1)); }();
     return k;
 }
-bool nat_gemm128_partials(int C) { return knob() != 0 && C <= 512 && (C % 128) == 0; }
+// (round 5: widths above 256 keep one partial per 256 columns — their producers are the 256 x 256 core's accumulating epilogue now, and the
+// LayerNorm-folded consumers read half as many partials per row; width 256 stays at two because the fused MLP kernel emits two)
+bool nat_gemm128_partials(int C) { return knob() != 0 && C <= 256 && (C % 128) == 0; }
 bool nat_gemm128_wanted(int N, int K, int mode) {
     const int C = mode == 2 ? N : K;
     if (!nat_gemm128_partials(C) || (N % 128) != 0 || (K % 32) != 0 || K < 64) return false;

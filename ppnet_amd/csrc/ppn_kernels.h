@@ -168,6 +168,10 @@ int row_stats_launch(const void* x, long long rows, int C, float* stats, hipStre
 bool nat_mlp_supported(long long M, int C, int HID);
 int nat_mlp_pack_launch(const void* w1, const void* w2, void* wpk, int C, int HID, hipStream_t stream);
 int nat_mlp_launch(void* s, const void* wpk, const float* hb, const float* b2, float* stats_out, long long M, int C, int HID, float eps, hipStream_t stream);
+int gemm_acc_stats_launch(const void* a, const void* w, const float* bias, float* stats, void* c, long long M, int N, int K, int p128,
+                          int n_cu, hipStream_t stream);
+int gemm_ln_launch(const void* a, const void* w, const float* bias, const float* colsum, const float* stats, int parts, void* c, long long M,
+                   int N, int K, int gelu, float eps, int n_cu, hipStream_t stream);
 int gemm_mfma_launch(const void* a, const void* w, const float* bias, void* c, long long M, int N, int K, int epi, int persistent,
                      hipStream_t stream);
 

@@ -45,7 +45,11 @@ def _use_mfma_conv(x, conv, narrow=False):
 # Per-shape gate between the build's GEMMs and the vendor library behind LayerNorm kernels: stream widths C with
 # C >= LIBRARY_GEMM_FROM_C or C < LIBRARY_GEMM_BELOW_C take the library.  Defaults from the alternating A/B of tools/ppnet_ab.py
 # (DESIGN.md section 4); PPNET_LIBRARY_GEMM_FROM_C / PPNET_LIBRARY_GEMM_BELOW_C override, PPNET_LIBRARY_GEMM=1 = the library everywhere.
-LIBRARY_GEMM_FROM_C = 512
+# Round 5: NO width takes the library by default.  With the LayerNorm-folded and accumulating epilogues on the 256 x 256 core
+# (csrc/mfma_gemm.h EPI_LN_BIAS[_GELU] / EPI_ACCUM_STATS: the old stream read in the epilogue, both wave groups' epilogues side by side)
+# the build's kernels on every level take 22.02 ms per SegNet batch against 22.55 with the round-4 gate at 512 and 22.93 with the
+# vendor's GEMMs everywhere (alternating on one box, profiles/r05_ppnet_ab.txt): no `Cijk_*` kernel is left in a bf16 batch.
+LIBRARY_GEMM_FROM_C = 1 << 30
 LIBRARY_GEMM_BELOW_C = 0
 
 

@@ -56,11 +56,14 @@ def test_ln_folded_projection_vs_float64(M, N, K, gelu):
     assert torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 256, 256), (512, 256, 512), (512, 512, 128), (1024, 1024, 2048), (16384, 512, 512), (70400 // 256 * 256, 256, 256)])
+@pytest.mark.parametrize("M,N,K", [(512, 256, 256), (512, 256, 512), (512, 512, 128), (1024, 1024, 2048), (16384, 512, 512), (70400 // 256 * 256, 256, 256),
+                                   # round 5 (the old s read in the epilogue of the 256 x 256 core): DiNAT-B's own level-2 / level-3 shapes at a
+                                   # quarter batch, and more tiles than compute units with an odd tile count per workgroup
+                                   (16384, 512, 1024), (4096, 1024, 1024), (4096, 1024, 2048), (256 * 259, 512, 256), (768, 768, 192)])
 def test_accumulating_projection_and_row_partials(M, N, K):
-    """mode 2: s += a W^T + b in place; stats_out[t] = (sum, sum of squares) of the new bfloat16 rows over tile column t.  The old s
-    enters through the matrix pipe (times an identity): exact, so the only roundings are the float32 accumulation and the final
-    bfloat16 one."""
+    """mode 2: s += a W^T + b in place; stats_out[t] = (sum, sum of squares) of the new bfloat16 rows over tile column t (128 columns
+    for streams of width <= 512, else 256).  The old s is read in the epilogue and added in float32 (round 3-4: through the matrix
+    pipe, times an identity — equally exact), so the only roundings are the float32 accumulation and the final bfloat16 one."""
     from ppnet_amd import fused
     a, w, b = _ops(M, N, K, 3)
     g = torch.Generator(device="cuda").manual_seed(4)
