@@ -307,6 +307,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
         if (n > p.N - 8) n = p.N - 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { bq[e] = 0.f; cq[e] = 0.f; }
+        // (what these loads and the queue drain in front of their first use cost was measured by building the epilogue without
+        // them — wrong results, timing only: 1 us per tile, 0.23 ms per PPNet batch at most, profiles/r05_gemm_epilogue_loads.txt;
+        // staging them through LDS by DMA as nat_gemm.hip does would win back part of that and was not built)
         if (EPI != EPI_ACCUM) {
             const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
             bq[0] = b0.x; bq[1] = b0.y; bq[2] = b0.z; bq[3] = b0.w; bq[4] = b1.x; bq[5] = b1.y; bq[6] = b1.z; bq[7] = b1.w;
