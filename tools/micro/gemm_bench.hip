@@ -28,7 +28,9 @@ static void launch(const Params& p, hipStream_t s) {
     if (!attr) { CK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); attr = true; }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const bool aligned = p.M % BM == 0 && p.N % BN == 0;
-    const int grid = (aligned && tiles > g_cus && !getenv("GEMM_ONE_TILE_PER_BLOCK")) ? g_cus : tiles;      // persistent: one block per CU
+    // persistent: one block per CU — except the classifier epilogue, which reduces its tile's sums once at the end of the workgroup
+    // (one tile per workgroup: what conv3x3_mfma_launch launches)
+    const int grid = (aligned && tiles > g_cus && !getenv("GEMM_ONE_TILE_PER_BLOCK") && EPI != EPI_RELU_DOT2) ? g_cus : tiles;
     hipLaunchKernelGGL((gemm_bf16_kernel<AMODE, EPI>), dim3(grid), dim3(NTHREADS), LDS_BYTES, s, p);
 }
 
