@@ -345,17 +345,20 @@ __global__ __launch_bounds__(NT, PPN_PATHS_WAVES_PER_EU) void edage_paths_kernel
 
     PPN_PSTAMP(3);
     // ------------------------------------------------------------------ A5: exact integer hull (gift wrapping)
-    // One wave walks the hull (gift wrapping, exact integer tests): each lane keeps 16 lattice points in
-    // registers and proposes its own best successor; the wave then refines a candidate with ballots —
-    // "is anyone's proposal to the right of cur->cand (or collinear and farther)?" — and a readlane, a few
-    // rounds per vertex, with no barrier and no LDS traffic inside the walk.
+    // ALL FOUR waves walk the hull together (round 5; rounds 1-4: one wave with 16 points per lane while three idled — 62 k of the
+    // kernel's 265 k cycles): a lane keeps 4 lattice points in registers and proposes its best successor; each wave reduces its 64
+    // proposals with a butterfly of exchanges under "to the right of cur->cand, or collinear and farther"; the four
+    // wave candidates meet in LDS (one slot set per vertex parity: ONE barrier per vertex) and every thread picks the same winner with
+    // the same exact integer predicate.  The predicate is a strict total preorder on directions from cur (ties: the farther point;
+    // equal points are the same vertex), so the successor — and the hull — is the one the serial walk finds.
     __shared__ int hull_meta[2];                                 // hn, flags
-    if (wv == 0) {
-        constexpr int PPL = (PPN_PATH_POINTS + 63) / 64;         // points per lane
+    __shared__ int hull_cand[2][NW][4];                          // [vertex parity][wave]: have, x, y
+    {
+        constexpr int PPL = (PPN_PATH_POINTS + NT - 1) / NT;     // points per lane
         int px[PPL], py[PPL];
 #pragma unroll
         for (int k = 0; k < PPL; ++k) {
-            const int q = min(lane + 64 * k, PPN_PATH_POINTS - 1);   // tail lanes repeat the last point (harmless duplicate)
+            const int q = min(tid + NT * k, PPN_PATH_POINTS - 1);    // tail lanes repeat the last point (harmless duplicate)
             px[k] = lat[q][0]; py[k] = lat[q][1];
         }
         // start = lexicographically smallest lattice point
@@ -367,51 +370,64 @@ __global__ __launch_bounds__(NT, PPN_PATHS_WAVES_PER_EU) void edage_paths_kernel
             const int ox = __shfl_xor(sx0, o, 64), oy = __shfl_xor(sy0, o, 64);
             if (ox < sx0 || (ox == sx0 && oy < sy0)) { sx0 = ox; sy0 = oy; }
         }
+        if (lane == 0) { hull_cand[0][wv][1] = sx0; hull_cand[0][wv][2] = sy0; }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int ox = hull_cand[0][w][1], oy = hull_cand[0][w][2];
+            if (ox < sx0 || (ox == sx0 && oy < sy0)) { sx0 = ox; sy0 = oy; }
+        }
+        __syncthreads();                                         // slot set 0 is written again by vertex 0
+        // `a` beats `b` as the successor of cur: a is to the right of cur -> b, or collinear with it and farther
+        // (branch-free on purpose: with early returns hipcc emitted ~40 instructions and two exec-mask branches per call, 850
+        // instructions per hull vertex; 14 calls per vertex)
+        auto beats = [&](int ax, int ay, int bx_, int by_, int cx, int cy) -> bool {
+            const int ux = ax - cx, uy = ay - cy, vx = bx_ - cx, vy = by_ - cy;
+            const int cr = __mul24(vx, uy) - __mul24(vy, ux);
+            const int da = __mul24(ux, ux) + __mul24(uy, uy), db = __mul24(vx, vx) + __mul24(vy, vy);
+            return (cr < 0) | ((cr == 0) & (da > db));
+        };
         int cx = sx0, cy = sy0, n = 0;
         uint32_t hflags = 0;
-        while (true) {
-            if (lane == 0) { hull_i[n][0] = cx; hull_i[n][1] = cy; }
+        while (true) {                                           // block-uniform control flow: every thread sees the same cur / winner
+            if (tid == 0) { hull_i[n][0] = cx; hull_i[n][1] = cy; }
+            const int par = n & 1;
             ++n;
-            // this lane's proposal: the point with all its other points on or to the left of cur -> proposal
+            // this lane's proposal among its own points
             int bx = 0, by = 0, have = 0;
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
                 const int rx = px[k], ry = py[k];
-                if (rx == cx && ry == cy) continue;
-                if (!have) { bx = rx; by = ry; have = 1; continue; }
-                const int cr = __mul24(bx - cx, ry - cy) - __mul24(by - cy, rx - cx);
-                if (cr < 0) { bx = rx; by = ry; }
-                else if (cr == 0) {
-                    const int db = __mul24(bx - cx, bx - cx) + __mul24(by - cy, by - cy);
-                    const int dr = __mul24(rx - cx, rx - cx) + __mul24(ry - cy, ry - cy);
-                    if (dr > db) { bx = rx; by = ry; }
-                }
+                const bool take = ((rx != cx) | (ry != cy)) & ((have == 0) | beats(rx, ry, bx, by, cx, cy));
+                bx = take ? rx : bx; by = take ? ry : by; have = take ? 1 : have;
             }
-            const unsigned long long hv = __ballot(have);
-            if (!hv) break;                                      // every point coincides with cur
-            int l0 = __ffsll((long long)hv) - 1;
-            int kx = __builtin_amdgcn_readlane(bx, l0), ky = __builtin_amdgcn_readlane(by, l0);
-            while (true) {
-                bool better = false;
-                if (have) {
-                    const int cr = __mul24(kx - cx, by - cy) - __mul24(ky - cy, bx - cx);
-                    if (cr < 0) better = true;
-                    else if (cr == 0) {
-                        const int dk = __mul24(kx - cx, kx - cx) + __mul24(ky - cy, ky - cy);
-                        const int dm = __mul24(bx - cx, bx - cx) + __mul24(by - cy, by - cy);
-                        better = dm > dk;
-                    }
-                }
-                const unsigned long long m = __ballot(better);
-                if (!m) break;
-                l0 = __ffsll((long long)m) - 1;
-                kx = __builtin_amdgcn_readlane(bx, l0); ky = __builtin_amdgcn_readlane(by, l0);
+            // this wave's candidate: a butterfly over the 64 proposals (6 exchanges).  (Rounds 1-4 refined a candidate with ballots,
+            // "first lane whose proposal beats it": consecutive lanes hold consecutive path points, whose directions from cur are
+            // monotone along the path, so that loop advanced ONE lane per round — up to 64 rounds per vertex, 2 900 cycles of them.)
+            int kx = bx, ky = by, kh = have;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int ox = __shfl_xor(kx, o, 64), oy = __shfl_xor(ky, o, 64), oh = __shfl_xor(kh, o, 64);
+                const bool take = (oh != 0) & ((kh == 0) | beats(ox, oy, kx, ky, cx, cy));
+                kx = take ? ox : kx; ky = take ? oy : ky; kh = take ? 1 : kh;
             }
-            if (kx == sx0 && ky == sy0) break;
+            const int hv = kh;
+            if (lane == 0) { hull_cand[par][wv][0] = hv ? 1 : 0; hull_cand[par][wv][1] = kx; hull_cand[par][wv][2] = ky; }
+            __syncthreads();
+            // the four wave candidates -> the successor (the same computation in every thread)
+            int wx = 0, wy = 0, whave = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int ch = hull_cand[par][w][0], ox = hull_cand[par][w][1], oy = hull_cand[par][w][2];
+                const bool take = (ch != 0) & ((whave == 0) | beats(ox, oy, wx, wy, cx, cy));
+                wx = take ? ox : wx; wy = take ? oy : wy; whave = take ? 1 : whave;
+            }
+            if (!whave) break;                                   // every point coincides with cur
+            if (wx == sx0 && wy == sy0) break;
             if (n >= PPN_MAX_HULL) { hflags |= PPN_FLAG_HULL_CAP; break; }
-            cx = kx; cy = ky;
+            cx = wx; cy = wy;
         }
-        if (lane == 0) { hull_meta[0] = n; hull_meta[1] = (int)hflags; }
+        if (tid == 0) { hull_meta[0] = n; hull_meta[1] = (int)hflags; }
     }
     __syncthreads();
     const int hn = hull_meta[0];
