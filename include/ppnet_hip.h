@@ -466,8 +466,8 @@ int ppn_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int6
                   int32_t persistent_blocks, void* stream);
 
 /* Row-statistics partials per row that the accumulating mode of ppn_nat_gemm_bf16 writes for a residual stream of width C (and
- * that the LayerNorm modes expect to read for K = C): one per 128 columns on the small-tile kernel (C <= 512), one per 256 on the
- * persistent one.  C % 256 == 0; < 0: invalid. */
+ * that the LayerNorm modes expect to read for K = C): one per 128 columns at C = 256 (what ppn_nat_mlp_bf16 emits there too), one per
+ * 256 columns for wider streams (round 4: per 128 up to C = 512).  C % 256 == 0; < 0: invalid. */
 int32_t ppn_nat_gemm_partials(int32_t C);
 
 /* The dense half of a NAT layer at C = 256 / 512 / 1024 with everything between two projections in the GEMMs' epilogues
@@ -481,9 +481,12 @@ int32_t ppn_nat_gemm_partials(int32_t C);
  *   mode 2: c += a w^T + bias IN PLACE, and stats_out [P][M][2], P = ppn_nat_gemm_partials(N), receives per column tile (sum, sum of
  *           squares) of every row of the NEW c over the tile's columns — of the bfloat16 values stored: what mode 0 / 1 of the
  *           next projection reads as stats_in with partials_in = P.  colsum / stats_in unused.
- * Two kernels behind it: stream widths <= 512 (HBM-bound: levels 1-2) on 128 x 128 tiles, three workgroups per CU
- * (csrc/nat_gemm128.hip); wider ones on the persistent 256 x 256 kernel, one workgroup per CU (csrc/nat_gemm.hip).  Bit-reproducible
- * (no atomics). */
+ *   The partials of a row are summed in a fixed tree (lane quarter q takes partial q), not in index order: bit-reproducible, and
+ *   equal to any other order to float32 rounding.
+ * Behind it since round 5 (K >= 128): ONE kernel, the persistent 256 x 256 core of csrc/mfma_gemm.h with these three epilogues (mode 2
+ * reads the old c in its epilogue).  Rounds 3-4's kernels (csrc/nat_gemm.hip: the old c through the matrix pipe against an identity;
+ * csrc/nat_gemm128.hip: 128 x 128 tiles) serve K = 64 and the A/B knobs PPNET_NAT_LN=old / PPNET_NAT_ACC=old.  Bit-reproducible (no
+ * atomics). */
 int ppn_nat_gemm_bf16(const void* a, const void* w, const float* bias, const float* colsum, const float* stats_in, int32_t partials_in,
                       float* stats_out, void* c, int64_t M, int32_t N, int32_t K, int32_t mode, float eps, void* stream);
 
