@@ -580,14 +580,17 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None)
     model = bench_ppnet(torch, dev, R, calibrate=mb.grid[:CALIBRATION_PROBLEMS])
     if hold is not None:
         hold["model"] = model                  # the float32 leg compares its outputs with this object's (ppnet.parity)
-    g = mb.grid[:batch]
-    init, end = mb.segpoint[:batch, 0].contiguous(), mb.segpoint[:batch, 10].contiguous()
-    obs, n_obs = mb.obstacles[:batch], mb.n_obstacles[:batch, 0].contiguous()
+    # the batch: every (n_maps / batch)-th map of the step — 256 problems spread over all 100 target paths (rounds 1-4 took the first
+    # 256 maps = 2.56 paths: three paths decide a success rate)
+    sel = torch.arange(batch, device=dev) * (mb.grid.shape[0] // batch)
+    g = mb.grid[sel].contiguous()
+    init, end = mb.segpoint[sel, 0].contiguous(), mb.segpoint[sel, 10].contiguous()
+    obs, n_obs = mb.obstacles[sel].contiguous(), mb.n_obstacles[sel, 0].contiguous()
     from ppnet_amd import edage
-    ridge = evaluate.label_heatmaps(pb, mb, PLACEMENTS)[:batch].contiguous()
+    ridge = evaluate.label_heatmaps(pb, mb, PLACEMENTS)[sel].contiguous()
     _, space = edage.label_masks(pb, mb, PLACEMENTS, want_path=False, want_space=True)
-    tail_heat = model.heatmap(space[:batch].contiguous()) if model.gennet_trained else ridge     # the trained network's own prediction
-    target_px = (pb.length.repeat_interleave(PLACEMENTS) * R / MAP_SIZE)[:batch]
+    tail_heat = model.heatmap(space[sel].contiguous()) if model.gennet_trained else ridge     # the trained network's own prediction
+    target_px = (pb.length.repeat_interleave(PLACEMENTS) * R / MAP_SIZE)[sel]
     s_comm = torch.cuda.Stream(dev) if world > 1 else None
     gathered = torch.empty(world * batch, shard.PLAN_RECORD_WIDTH, dtype=torch.float64, device=dev) if world > 1 else None
 
