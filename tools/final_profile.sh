@@ -6,7 +6,7 @@
 # PART=a (bench lines, generator kernel stats / traffic / SQ counters, PPNet breakdown + matrix-pipe counters), PART=b (attention,
 # GEMM and MLP tables, A/B, training, graph latency, sweep) or unset (everything) — one gpurun call holds 20 minutes.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$PWD; OUT=$ROOT/gpurun_out/final; mkdir -p $OUT
 export TMPDIR=/tmp
 if [ "$PART" != "b" ]; then

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """PPNet batch time under the GEMM knobs, alternating in ONE process on one box (the knobs are read at call time):
-default = segnet.LIBRARY_GEMM_FROM_C = 512: the build's LN-folded GEMMs (ppn_nat_gemm_bf16) + the fused MLP kernel (ppn_nat_mlp_bf16)
-on the levels below C = 512, LayerNorm kernels + the vendor GEMM from there on; PPNET_LIBRARY_GEMM_FROM_C=1073741824 = the build's
-GEMMs on every level; =1024 = the vendor path on level 3 only; PPNET_LIBRARY_GEMM = the vendor library on every level (round 2's
+default (round 5) = the build's LN-folded / accumulating GEMMs (ppn_nat_gemm_bf16) + the fused MLP kernel (ppn_nat_mlp_bf16) on every
+level; PPNET_LIBRARY_GEMM_FROM_C=512 = round 4's gate (LayerNorm kernels + the vendor GEMM from C = 512 on); =1024 = the vendor path on level 3 only; PPNET_LIBRARY_GEMM = the vendor library on every level (round 2's
 default); PPNET_NO_FUSED_MLP = level 1's MLP as two GEMM launches again; PPNET_NO_LN_FOLD = LayerNorm kernels + the build's
 one-tile-per-workgroup GEMM (ppn_gemm_bf16) where the vendor's is not selected."""
 import os, sys, time
@@ -23,7 +22,7 @@ def run(n):
         m = model.segment_u8(g)
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / n * 1e3
-KN = ("PPNET_LIBRARY_GEMM_FROM_C=1073741824", "PPNET_LIBRARY_GEMM_FROM_C=1024", "PPNET_LIBRARY_GEMM=1", "PPNET_NO_FUSED_MLP=1", "PPNET_NO_LN_FOLD=1")
+KN = ("PPNET_LIBRARY_GEMM_FROM_C=512", "PPNET_LIBRARY_GEMM_FROM_C=1024", "PPNET_LIBRARY_GEMM=1", "PPNET_NO_FUSED_MLP=1", "PPNET_NO_LN_FOLD=1")
 def setk(k):
     for x in KN: os.environ.pop(x.split("=")[0], None)
     if k: os.environ[k.split("=")[0]] = k.split("=")[1]
@@ -32,4 +31,4 @@ for k in (None,) + KN:
 for rnd in range(3):
     for k in (None,) + KN:
         setk(k)
-        print(f"round {rnd} {k or 'default (own kernels below C=512, vendor GEMM from there)':58s} SegNet {run(8):7.3f} ms per batch of {B}", flush=True)
+        print(f"round {rnd} {k or 'default (own kernels on every level)':58s} SegNet {run(8):7.3f} ms per batch of {B}", flush=True)
