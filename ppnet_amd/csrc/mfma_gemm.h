@@ -109,6 +109,26 @@ __device__ __forceinline__ float gelu_logistic(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-t));
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_logistic2(f32x2 x) {               // two at a time: the multiplies / adds packed
+    f32x2 x2 = x * x;
+    x2 = f32x2{fminf(x2.x, 64.0f), fminf(x2.y, 64.0f)};
+    const f32x2 k0 = {2.3009787f, 2.3009787f}, k1 = {0.10690469f, 0.10690469f}, k2 = {-1.0350827e-3f, -1.0350827e-3f}, one = {1.0f, 1.0f};
+    const f32x2 t = x * __builtin_elementwise_fma(x2, __builtin_elementwise_fma(x2, k2, k1), k0);
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(-t.x), __builtin_amdgcn_exp2f(-t.y)} + one;
+    return x * f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+
+// sum over the four lanes that share a row of the MFMA layout (lanes l, l ^ 16, l ^ 32, l ^ 48) on the vector ALU: v_permlane16/32_swap of a
+// value with itself leaves (even rows, odd rows) / (lower half, upper half) copies whose sum is the xor-16 / xor-32 partner sum — no
+// trip through the LDS crossbar (ds_bpermute) and no wait (nat_gemm.hip)
+__device__ __forceinline__ float quad_sum(float v) {
+    auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+
 // What one output tile needs from this lane: source pointers of its 16-byte pieces of the four quarter-tiles.
 struct TileSrc {
     uint32_t a[2][2];           // [unit][pass]: BYTE offset from p.A at k-tile 0 (CONV3: the centre tap of the pixel); < 2^32
@@ -293,9 +313,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
         for (int ap = 0; ap < 2; ++ap)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                float sx = v[ap][mt].x * wgt, sq = v[ap][mt].y * wgt;
-                sx += __shfl_xor(sx, 16, 64); sq += __shfl_xor(sq, 16, 64);
-                sx += __shfl_xor(sx, 32, 64); sq += __shfl_xor(sq, 32, 64);
+                const float sx = quad_sum(v[ap][mt].x * wgt), sq = quad_sum(v[ap][mt].y * wgt);
                 const float mean = sx * p.inv_k;
                 const float rstd = __builtin_amdgcn_rsqf(fmaxf(sq * p.inv_k - mean * mean, 0.f) + p.eps);
                 rrs[ap][mt] = rstd; rnm[ap][mt] = -rstd * mean;
@@ -328,10 +346,21 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
             f32x4 x = acc[ap][mt][bp][0], y = acc[ap][mt][bp][1];
             swap_rows(x, y);
             float o[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+            if constexpr (EPI_LN) {
+                // two values per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): no MFMA runs beside an epilogue, so the
+                // packed forms are what they are elsewhere, half the issue slots (beside MFMAs they cost more than they save:
+                // nat_c128.hip) — the LayerNorm algebra 16 -> 8 instructions per 8 values, the GELU's non-transcendental part 7 -> 4 per value
+                const f32x2 rr2 = {rrs[ap][mt], rrs[ap][mt]}, nm2 = {rnm[ap][mt], rnm[ap][mt]};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (EPI_LN) o[e] = fmaf(rrs[ap][mt], o[e], fmaf(rnm[ap][mt], cq[e], bq[e]));
-                else o[e] += bq[e];
+                for (int e = 0; e < 8; e += 2) {
+                    f32x2 v = {o[e], o[e + 1]};
+                    v = __builtin_elementwise_fma(rr2, v, __builtin_elementwise_fma(nm2, f32x2{cq[e], cq[e + 1]}, f32x2{bq[e], bq[e + 1]}));
+                    if (EPI == EPI_LN_BIAS_GELU) v = gelu_logistic2(v);
+                    o[e] = v.x; o[e + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += bq[e];
             }
             if (EPI == EPI_ACCUM || EPI == EPI_ACCUM_STATS) {
                 const bf16x8 s8 = __builtin_bit_cast(bf16x8, prev[mt]);
@@ -341,16 +370,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (EPI == EPI_BIAS_GELU) o[e] = gelu_erf(o[e]);
-                if (EPI == EPI_LN_BIAS_GELU) o[e] = gelu_logistic(o[e]);
                 if (EPI == EPI_BIAS_RELU) o[e] = fmaxf(o[e], 0.f);
             }
             const bf16x8 w = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3], (__bf16)o[4], (__bf16)o[5], (__bf16)o[6], (__bf16)o[7]};
             const int m = m0 + wr * 128 + ap * 64 + mt * 16 + frow;
             if (m < p.M && n_in) *reinterpret_cast<bf16x8*>(p.C + (size_t)m * p.ldc + n) = w;
             if (EPI == EPI_ACCUM_STATS) {                                     // of the ROUNDED values: what the next projection reads
-                float a1 = 0.f, a2 = 0.f;
+                f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float f = (float)w[e]; a1 += f; a2 += f * f; }
+                for (int e = 0; e < 8; e += 2) { const f32x2 f = {(float)w[e], (float)w[e + 1]}; s1 += f; s2 = __builtin_elementwise_fma(f, f, s2); }
+                const float a1 = s1.x + s1.y, a2 = s2.x + s2.y;
                 if (bp == 0) { rs1[ap][mt] = a1; rs2[ap][mt] = a2; } else { rs1[ap][mt] += a1; rs2[ap][mt] += a2; }
             }
             acc[ap][mt][bp][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ap][mt][bp][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -526,9 +555,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_bf16_kernel(const Params p) 
                     for (int ap = 0; ap < 2; ++ap)
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt) {
-                            float a1 = rs1[ap][mt], a2 = rs2[ap][mt];
-                            a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
-                            a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+                            const float a1 = quad_sum(rs1[ap][mt]), a2 = quad_sum(rs2[ap][mt]);
                             if (fq == 0) lds_st_f2(red + wc * BM + wr * 128 + ap * 64 + mt * 16 + frow, make_float2(a1, a2));
                         }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
