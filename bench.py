@@ -594,17 +594,21 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None)
     s_comm = torch.cuda.Stream(dev) if world > 1 else None
     gathered = torch.empty(world * batch, shard.PLAN_RECORD_WIDTH, dtype=torch.float64, device=dev) if world > 1 else None
 
-    def one(timers=None):
+    def one(timers=None, tail_stream=None):
+        """One batch on the current stream.  tail_stream: the planner tail on that stream (PPNet.plan_tail(side_stream=...)): with a
+        trained GenNet the walk kernel is as long as its longest walk (2.5 ms at 1 / 16 of the chip), and behind it on the SAME stream
+        the next batch's SegNet would wait for it."""
         if timers: timers[0].record()
         mask = model.segment_u8(g)
         if timers: timers[1].record()
         heat = model.heatmap(mask)
         if timers: timers[2].record()
-        res = model.plan_tail(tail_heat, init, end, obs, n_obs)
+        res = model.plan_tail(tail_heat, init, end, obs, n_obs, side_stream=tail_stream)
         if timers: timers[3].record()
         if world > 1:                                                         # end-of-batch gather of the plan records
-            rec = shard.pack_plan_records(res, evaluate.plan_lengths(res["waypoints"], res["counts"]))
-            ev = torch.cuda.Event(); ev.record()
+            with torch.cuda.stream(tail_stream if tail_stream is not None else torch.cuda.current_stream(dev)):
+                rec = shard.pack_plan_records(res, evaluate.plan_lengths(res["waypoints"], res["counts"]))
+                ev = torch.cuda.Event(); ev.record()
             with torch.cuda.stream(s_comm):
                 s_comm.wait_event(ev)
                 shard.gather_records(rec, world, out=gathered)
@@ -644,17 +648,19 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None)
     # 26.40 (3).  Every batch is still the full chain on its own buffers; the timed region is `steps` whole batches.
     n_streams = max(1, int(os.environ.get("PPNET_STREAMS", "2")))
     pp_streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream(dev)]
-    for st in pp_streams:                                   # each stream's allocator pool and library workspaces: outside the clock
+    # ... and each batch stream has a tail stream of its own (PPNET_TAIL_STREAM=0: the tail stays on the batch's stream, as in rounds 2-4)
+    tail_streams = [torch.cuda.Stream(dev) for _ in pp_streams] if os.environ.get("PPNET_TAIL_STREAM", "1") != "0" else [None] * len(pp_streams)
+    for st, ts in zip(pp_streams, tail_streams):            # each stream's allocator pool and library workspaces: outside the clock
         st.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(st):
-            one()
+            one(tail_stream=ts)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for i in range(steps):
         with torch.cuda.stream(pp_streams[i % n_streams]):
-            res, heat = one()
+            res, heat = one(tail_stream=tail_streams[i % n_streams])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -687,6 +693,7 @@ def ppnet_leg(torch, dev, pb, mb, batch, steps, world, rank, cpu_leg, hold=None)
                        + (" -> all-gather of plan records" if world > 1 else ""),
            "ms_segnet": round(t_seg, 2), "ms_gennet": round(t_gen, 2), "ms_tail": round(t_tail, 2),
            "ms_per_batch_hip_graph": round(ms_graph, 2) if ms_graph is not None else None, "streams": n_streams,
+           "tail_streams": sum(t is not None for t in tail_streams),
            "ms_per_batch_chained_network_output": round(ms_chained, 2),
            "weights": {"gennet": ("trained by this build (tools/train_gennet.py; ppnet_amd/weights/gennet_r%d.pth, reference checkpoint layout)" % R)
                                  if model.gennet_trained else "seeded random init",

@@ -173,9 +173,23 @@ class PPNet(torch.nn.Module):
         return cp
 
     @torch.no_grad()
-    def plan_tail(self, heat, init, end, obstacles, n_obstacles, clearance=None, down_sample_rate=2, max_wp=L.MAX_WAYPOINTS):
+    def plan_tail(self, heat, init, end, obstacles, n_obstacles, clearance=None, down_sample_rate=2, max_wp=L.MAX_WAYPOINTS, side_stream=None):
         """extract_path + collision_check_circle_edge over the consecutive waypoints (process_map.py:486-503) for B
-        8-bit heat maps [B,R,R].  max_wp: the walk's step cap (stands in for the reference's 1 s timeout)."""
+        8-bit heat maps [B,R,R].  max_wp: the walk's step cap (stands in for the reference's 1 s timeout).
+        side_stream: run the tail's kernels on that HIP stream behind everything the current stream has enqueued so far (an event),
+        and return at once — the greedy walk is one wave per problem and as long as its longest walk (2 048 steps for a problem whose
+        walk never arrives: 2.5 ms per batch with trained weights), a latency chain that fills 1 / 16 of the chip; on its own stream the
+        NEXT batch's networks run beside it instead of behind it.  The result tensors then belong to `side_stream`: synchronise with it
+        (or wait on an event recorded there) before reading them from another stream."""
+        if side_stream is not None:
+            cur = torch.cuda.current_stream(heat.device)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            with torch.cuda.stream(side_stream):
+                side_stream.wait_event(ev)
+                for t in (heat, init, end, obstacles, n_obstacles):
+                    t.record_stream(side_stream)
+                return self.plan_tail(heat, init, end, obstacles, n_obstacles, clearance, down_sample_rate, max_wp)
         if clearance is None:
             clearance = 1 / 50 * self.resolution
         ok, wp, cnt = plan.extract_paths(heat, init, end, down_sample_rate, max_wp)

@@ -179,6 +179,28 @@ def _oracle_tail(heat, init, end, obs, n_obs, clearance, max_wp):
 
 
 @pytest.mark.gpu
+def test_plan_tail_on_a_side_stream_equals_the_serial_tail(dev, stage_b, segnet_models):
+    """PPNet.plan_tail(side_stream=...) (round 5: the walk kernel is as long as its longest walk, so bench.py runs it beside the next
+    batch's networks): the same kernels behind an event on another stream — identical results once that stream is synchronised, also
+    when the heat map is produced on the current stream right in front of the call."""
+    from ppnet_amd import evaluate
+    pb, mb = stage_b
+    _, _, p16 = segnet_models
+    init, end = mb.segpoint[:, 0].contiguous(), mb.segpoint[:, 10].contiguous()
+    obs, n_obs = mb.obstacles, mb.n_obstacles[:, 0].contiguous()
+    want = p16.plan_tail(evaluate.label_heatmaps(pb, mb, 4), init, end, obs, n_obs)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(dev)
+    for _ in range(3):
+        heat = evaluate.label_heatmaps(pb, mb, 4)              # enqueued on the current stream; the tail must wait for it
+        got = p16.plan_tail(heat, init, end, obs, n_obs, side_stream=side)
+        del heat                                               # (record_stream keeps its memory until the side stream is done)
+        side.synchronize()
+        for k in ("ok", "counts", "collision", "success", "waypoints"):
+            assert torch.equal(got[k], want[k]), k
+
+
+@pytest.mark.gpu
 def test_plan_tail_vs_oracle_on_network_and_ridge_heatmaps(dev, stage_b, segnet_models):
     """plan() = segment_u8 -> heatmap -> plan_tail.  The tail is checked against oracle/plan_np.py fed the SAME heat maps:
     (i) the maps the (random-weight) networks produce — noise, the walk fails or wanders: both sides must agree on that —
