@@ -35,27 +35,38 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int MK = 7, MN = 3, MHD = 32;
-constexpr int TQ = 4;                  // 4 x 4 queries per MFMA block
-constexpr int HR = 10;                 // key tiles (halo rows) per block
 constexpr int KB = 64;                 // bytes per staged key row (32 bf16)
-constexpr int BT_ROWS = 16, BT_PITCH = 24;   // bias tables: 22 columns used; at a pitch of 24 floats the 4 query rows of a block read disjoint banks
 constexpr int RT = 16, HROWS = RT + 6, PC = 24;
 constexpr int SLOTS = HROWS * PC;      // 528 = 33 x 16
 constexpr int IMG = SLOTS * KB;
 constexpr int TAIL = 4 * KB;
-constexpr int TBL = 2 * BT_ROWS * BT_PITCH * 4;
 constexpr int BUF = 2 * IMG + TAIL;                  // a tile: K image | V image | 4 zero slots
-constexpr int LDS_TOTAL = 2 * BUF + TBL;             // two tiles | the head's two bias tables
+constexpr int BT_ROWS = 16;
+// The 16 queries of an MFMA block are TQY x TQX of the tile: 4 x 4 (the union of their windows is 10 halo rows x 10 columns: 10 key
+// tiles of 16 column slots, 100 of 160 slots hold a key of some query) or 2 x 8 (8 rows x 14 columns: 8 key tiles, 112 of 128 — a fifth
+// less of everything that is per key slot: logit MFMAs, exponentials, maxima, conversions, K / V / bias reads).
+template <int TQY_, int TQX_>
+struct Blk {
+    static constexpr int TQY = TQY_, TQX = TQX_;
+    static constexpr int HR = TQY + MK - 1;              // key tiles (halo rows) per block
+    static constexpr int NBY = RT / TQY, NBX = RT / TQX; // blocks of a tile
+    // bias tables: a lane reads columns (c0 - tj0 + 6) + 4g + r - jx, i.e. -(TQX - 1) .. 21: the tables start COL0 floats into a row;
+    // the pitch keeps the query rows of a block in disjoint banks (4 x 4: 16 addresses per row, 4 rows at 24; 2 x 8: 20, 2 rows at 32)
+    static constexpr int BT_PITCH = TQX == 4 ? 24 : 32, BT_COL0 = TQX == 4 ? 0 : 8;
+    static constexpr int TBL = 2 * BT_ROWS * BT_PITCH * 4;
+    static constexpr int LDS_TOTAL = 2 * BUF + TBL;      // two tiles | the head's two bias tables
+    static_assert(TQY * TQX == 16 && HR % 2 == 0 && NBY * NBX == 16 && RT - TQX + 16 <= PC + 4 && TBL % 16 == 0, "block shape");
+};
 constexpr int NPAIR = SLOTS / 16;      // wave instructions per image
 constexpr int NW = 16, NTHR = NW * 64;
 constexpr int PPW = (NPAIR + NW - 1) / NW;
 constexpr int DESC = 32;               // ints per tile descriptor
-static_assert(SLOTS % 16 == 0 && TBL % 16 == 0 && (PC & 7) == 0, "staging layout");
+static_assert(SLOTS % 16 == 0 && (PC & 7) == 0, "staging layout");
 static_assert(PPW * 10 <= 32 && HROWS + 2 <= 32 && PC <= 32, "packed staging coordinates");
 
 // descriptor of a tile (what of it does not depend on the head): byte offsets of the halo origin's k row (head 0), of the tile
 // origin's q row and of its output row; the halo extent and its real part (virtual padding), packed; the tile's geometry
-enum { D_KV = 0, D_Q = 2, D_O = 4, D_EXT = 6, D_TY0, D_TX0, D_HS, D_WS, D_HQ, D_WQ, D_R0, D_C0, D_VALID, D_ROW = 16, D_COL = 20 };
+enum { D_KV = 0, D_Q = 2, D_O = 4, D_EXT = 6, D_TY0, D_TX0, D_HS, D_WS, D_HQ, D_WQ, D_R0, D_C0, D_VALID, D_ROW = 16, D_COL = 24 };
 // D_ROW + by / D_COL + bx: the geometry of block row by / block column bx of the tile, so that a wave derives its block's from two
 // words instead of a dozen clamps and compares: window origin r0 (16 bits) | its place in the halo ro << 16 (4) | bias-table row
 // r0 - ti0 + 6 << 20 (4) | the block row holds queries << 24 | the image ends inside it << 25 | no query's window is clamped << 26
@@ -75,11 +86,26 @@ __device__ __forceinline__ float max3(float a, float b, float c) {        // (fm
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// maximum of N registers as a tree of v_max3 (40 -> 14 -> 5 -> 2 -> 1, 32 -> 11 -> 4 -> 2 -> 1: four deep)
+template <int N>
+__device__ __forceinline__ float max_tree(const float (&v)[N]) {
+    if constexpr (N == 1) return v[0];
+    else if constexpr (N == 2) return max3(v[0], v[1], v[1]);
+    else {
+        constexpr int M = (N + 2) / 3;
+        float r[M];
+#pragma unroll
+        for (int i = 0; i < N / 3; ++i) r[i] = max3(v[3 * i], v[3 * i + 1], v[3 * i + 2]);
+        if constexpr (N % 3 == 1) r[M - 1] = v[N - 1];
+        if constexpr (N % 3 == 2) r[M - 1] = max3(v[N - 2], v[N - 1], v[N - 1]);
+        return max_tree<M>(r);
+    }
+}
 }  // namespace
 
 // One descriptor per tile: it depends on the launch's geometry only (not on the data), so a launcher-side cache keeps it per shape.
 __global__ __launch_bounds__(256) void na2d_halo16_prep_kernel(int* __restrict__ desc, int heads, int H, int W, int Hr, int Wr, int dil, int tiles_y, int tiles_x,
-                                                               int total_tiles, int padded) {
+                                                               int total_tiles, int padded, int tqy, int tqx) {
     const int gtile = (int)blockIdx.x * 256 + threadIdx.x;
     if (gtile >= total_tiles) return;
     const int ntiles = tiles_y * tiles_x;
@@ -109,16 +135,21 @@ __global__ __launch_bounds__(256) void na2d_halo16_prep_kernel(int* __restrict__
     d[D_O] = (int)(unsigned)oo; d[D_O + 1] = (int)(unsigned)(oo >> 32);
     d[D_EXT] = NR | (NC << 8) | (NRr << 16) | (NCr << 24);
     d[D_TY0] = ty0; d[D_TX0] = tx0; d[D_HS] = hs; d[D_WS] = ws; d[D_HQ] = hq; d[D_WQ] = wq; d[D_R0] = R0; d[D_C0] = C0; d[D_VALID] = 1;
-    for (int k = 0; k < RT / TQ; ++k) {
-        const int ti0 = ty0 + k * TQ, tj0 = tx0 + k * TQ;
-        const int r0 = clampm(ti0 - MN, 0, hs - MK), c0 = clampm(tj0 - MN, 0, ws - MK);          // the block's window origin
-        const int rl = ti0 < hq, cl = tj0 < wq;
-        d[D_ROW + k] = rl ? (r0 | ((r0 - R0) << 16) | ((r0 - ti0 + MK - 1) << 20) | B_LIVE | (ti0 + TQ > hq ? B_CUT : 0) |
-                             (ti0 >= MN && ti0 + TQ - 1 + MN <= hs - 1 ? B_INT : 0)) : 0;
-        d[D_COL + k] = cl ? (c0 | ((c0 - C0) << 16) | ((c0 - tj0 + MK - 1) << 20) | B_LIVE | (tj0 + TQ > wq ? B_CUT : 0) |
-                             (tj0 >= MN && tj0 + TQ - 1 + MN <= ws - 1 ? B_INT : 0)) : 0;
+    for (int k = D_ROW; k < DESC; ++k) d[k] = 0;
+    for (int k = 0; k < RT / tqy; ++k) {
+        const int ti0 = ty0 + k * tqy;
+        const int r0 = clampm(ti0 - MN, 0, hs - MK);                                             // the block row's window origin
+        if (ti0 < hq)
+            d[D_ROW + k] = r0 | ((r0 - R0) << 16) | ((r0 - ti0 + MK - 1) << 20) | B_LIVE | (ti0 + tqy > hq ? B_CUT : 0) |
+                           (ti0 >= MN && ti0 + tqy - 1 + MN <= hs - 1 ? B_INT : 0);
     }
-    for (int k = D_COL + RT / TQ; k < DESC; ++k) d[k] = 0;
+    for (int k = 0; k < RT / tqx; ++k) {
+        const int tj0 = tx0 + k * tqx;
+        const int c0 = clampm(tj0 - MN, 0, ws - MK);
+        if (tj0 < wq)
+            d[D_COL + k] = c0 | ((c0 - C0) << 16) | ((c0 - tj0 + MK - 1) << 20) | B_LIVE | (tj0 + tqx > wq ? B_CUT : 0) |
+                           (tj0 >= MN && tj0 + tqx - 1 + MN <= ws - 1 ? B_INT : 0);
+    }
 }
 
 struct Tile {
@@ -139,9 +170,12 @@ __device__ __forceinline__ Tile load_tile(const int* __restrict__ desc, int gtil
     return t;
 }
 
+template <int TQY, int TQX>
 __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pad_kv, __bf16* __restrict__ out,
                                                            const float* __restrict__ rpb, const int* __restrict__ desc, int Wr, int Ws, int heads,
                                                            int dil, float scale, int n_items, const __bf16* __restrict__ zero) {
+    typedef Blk<TQY, TQX> S;
+    constexpr int HR = S::HR, BT_PITCH = S::BT_PITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char nl[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;                                // MFMA column (query) and lane quarter
@@ -158,7 +192,7 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
     int gtile = item / heads, h = item - gtile * heads;
     const int step_t = nx / heads, step_h = nx - step_t * heads;           // item + nx without a division per tile
 
-    // the 4 zero slots behind each V image
+    // the 4 zero slots behind each V image (the bias reads of masked logits may reach back into the second one's)
     if (threadIdx.x < 2 * TAIL / 4) reinterpret_cast<uint32_t*>(nl + (threadIdx.x >= TAIL / 4 ? BUF : 0) + 2 * IMG)[threadIdx.x & (TAIL / 4 - 1)] = 0u;
 
     // ---- the tile-independent part of this lane's staging pieces.  Pair k = wave + 16 i covers slots 16 k .. 16 k + 15 of both
@@ -214,13 +248,13 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
         }
     };
 
-    // ---- this wave's block of the tile: rows 4 by .., columns 4 bx ..; lane (j, g): query (jy, jx) of it, quarter g
-    const int by = wave >> 2, bx = wave & 3;
-    const int jy = j >> 2, jx = j & 3;
-    const int ry = by * TQ + jy, rx = bx * TQ + jx;                        // the query's place in the tile
+    // ---- this wave's block of the tile: rows TQY by .., columns TQX bx ..; lane (j, g): query (jy, jx) of it, quarter g
+    const int by = wave / S::NBX, bx = wave % S::NBX;
+    const int jy = j / TQX, jx = j % TQX;
+    const int ry = by * TQY + jy, rx = bx * TQX + jx;                      // the query's place in the tile
     const unsigned qoff_full = (unsigned)(ry * Ws + rx) * (unsigned)dil * tokb + 16u * g;             // B operand: channels 8g .. 8g+7 of query j
     const unsigned ooff_full = (unsigned)(ry * Wr + rx) * (unsigned)dil * (unsigned)(heads * MHD * 2) + 8u * g;
-    const int btl_full = (-jy * BT_PITCH - jx + 4 * g) * 4;
+    const int btl_full = (S::BT_COL0 - jy * BT_PITCH - jx + 4 * g) * 4;
     // dead queries (a tile the image cuts) shadow a live one and are never stored
     auto q_request = [&](const Tile& T) __attribute__((always_inline)) -> bf16x8 {
         const int rmax = T.hq - 1 - T.ty0, cmax = T.wq - 1 - T.tx0;
@@ -237,8 +271,8 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
     auto build_tables = [&](int hh) __attribute__((always_inline)) {
         if (threadIdx.x < 2 * BT_ROWS * BT_PITCH) {
             const int which = threadIdx.x >= BT_ROWS * BT_PITCH, t = threadIdx.x - which * BT_ROWS * BT_PITCH;
-            const int a = t / BT_PITCH, b = t - a * BT_PITCH;
-            const float v = (a < 13 && b < 13) ? rpb[(size_t)hh * 169 + a * 13 + b] / scale : 0.f;
+            const int a = t / BT_PITCH, b = t - a * BT_PITCH - S::BT_COL0;
+            const float v = (a < 13 && b >= 0 && b < 13) ? rpb[(size_t)hh * 169 + a * 13 + b] / scale : 0.f;
             BTL[threadIdx.x] = (which == 0 || (a >= MN && a <= 3 * MN && b >= MN && b <= 3 * MN)) ? v : -1.0e30f;
         }
     };
@@ -248,14 +282,18 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
     stage(cur, lds0);
     bf16x8 q_next = q_request(cur);
     int bsel = 0;
+    bool stored = false;                                                   // wave-uniform: the tile before left two stores in flight
     const int q4 = j >> 2, p4 = j & 3;                                     // transposed read: this lane addresses row q4, columns 4 p4 ..
     const float NEG = -1.0e30f;
     const float sl2 = scale * 1.4426950408889634f;
 
     while (true) {
-        // everything this wave has in flight — its pieces of this tile's stage, the q fragment, the last tile's stores — has landed;
-        // behind the barrier so has every other wave's, and every wave has left the tile before (whose buffer the next stage fills)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this wave's pieces of this tile's stage and its q fragment have landed — NOT the last tile's two stores, which are younger
+        // than both (vmcnt retires in order; a live block issues exactly two store instructions behind everything it requested, a dead
+        // one none): waiting for them too was a store's round trip per tile with all 16 waves idle.  Behind the barrier every other
+        // wave's pieces have landed as well, and every wave has left the tile before (whose buffer the next stage fills)
+        if (stored) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bf16x8 qf = q_next;
         asm volatile("" : "+v"(qf));
         __syncthreads();
@@ -278,11 +316,12 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
         }
 
         const Tile& T = cur;
-        if (T.row & T.col & B_LIVE) {                                      // wave-uniform: the block holds queries (an invalid tile's words are 0)
+        stored = (T.row & T.col & B_LIVE) != 0;
+        if (stored) {                                      // wave-uniform: the block holds queries (an invalid tile's words are 0)
             const unsigned char* Kimg = buf;
             const unsigned char* Vimg = buf + IMG;
             const unsigned char* BT = nl + 2 * BUF;
-            const int ti0 = T.ty0 + by * TQ, tj0 = T.tx0 + bx * TQ;
+            const int ti0 = T.ty0 + by * TQY, tj0 = T.tx0 + bx * TQX;
             const int hs = T.hs, ws = T.ws, hq = T.hq, wq = T.wq;
             const bool cut = ((T.row | T.col) & B_CUT) != 0;               // wave-uniform: the image ends inside this block
             const int jyc = cut ? min(jy, hq - 1 - ti0) : jy, jxc = cut ? min(jx, wq - 1 - tj0) : jx;
@@ -302,44 +341,64 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
             // one function of the key's offset from the query (na2d_mfma.hip)
             const bool interior = (T.row & T.col & B_INT) != 0 && !cut;
             const int bts = ((interior ? BT_ROWS * BT_PITCH : 0) + ((T.row >> 20) & 15) * BT_PITCH + ((T.col >> 20) & 15)) * 4;   // uniform
-            const int btl = cut ? (-jyc * BT_PITCH - jxc + 4 * g) * 4 : btl_full;
+            const int btl = cut ? (S::BT_COL0 - jyc * BT_PITCH - jxc + 4 * g) * 4 : btl_full;
             const float* bt = reinterpret_cast<const float*>(BT + bts + btl);
 #pragma unroll
             for (int t = 0; t < HR; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(kb + t * PC * KB);
 #pragma unroll
             for (int t = 0; t < HR; ++t) sacc[t] = f32x4{bt[t * BT_PITCH], bt[t * BT_PITCH + 1], bt[t * BT_PITCH + 2], bt[t * BT_PITCH + 3]};
+#ifndef PPN_HALO_MASK_AFTER
+            if (!interior) {
+                // Window mask, applied to the INITIAL accumulator like the interior table's (-1e30 + q.k is -1e30 in float32): one
+                // select per logit in front of the MFMA instead of two operations behind it.  Lane (j, g) holds, per tile t, keys
+                // (row r0 + t, column c0 + 4g + r), r = 0 .. 3, of query j.  A query's window starts 0 .. TQY - 1 rows below r0 (the
+                // clamp is monotone with slope <= 1), so halo rows TQY - 1 .. 6 of the block are in EVERY query's window: only
+                // the TQY - 1 rows at either end need the row test.
+                const int wi = clampm(ti0 + jyc - MN, 0, hs - MK), wj = clampm(tj0 + jxc - MN, 0, ws - MK);
+                bool cv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int cx = c0 + 4 * g + r; cv[r] = cx >= wj && cx <= wj + MK - 1; }
+#pragma unroll
+                for (int t = 0; t < HR; ++t) {
+                    const bool edge = t < TQY - 1 || t > MK - 1;          // compile-time
+                    const bool rv = !edge || (r0 + t >= wi && r0 + t <= wi + MK - 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[t][r] = (rv && cv[r]) ? sacc[t][r] : NEG;
+                }
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < HR; ++t) sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, sacc[t], 0, 0, 0);
+#ifdef PPN_HALO_MASK_AFTER                                                  // (A/B build: the mask behind the MFMAs, two operations per logit)
             if (!interior) {
-                // window mask.  Lane (j, g) holds, per tile t, keys (row r0 + t, column c0 + 4g + r), r = 0 .. 3, of query j
                 const int wi = clampm(ti0 + jyc - MN, 0, hs - MK), wj = clampm(tj0 + jxc - MN, 0, ws - MK);
-                uint32_t rowmask = 0;
 #pragma unroll
-                for (int t = 0; t < HR; ++t) rowmask |= (uint32_t)((r0 + t >= wi) && (r0 + t <= wi + MK - 1)) << t;
-                uint32_t csel[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const int cx = c0 + 4 * g + r; csel[r] = (cx >= wj && cx <= wj + MK - 1) ? 0xffffffffu : 0u; }
-#pragma unroll
-                for (int t = 0; t < HR; ++t) {
-                    const uint32_t rsel = 0u - ((rowmask >> t) & 1u);      // all ones when halo row t is in this query's window
+                for (int t = 0; t < HR; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const uint32_t m = rsel & csel[r];
-                        sacc[t][r] = __uint_as_float((__float_as_uint(sacc[t][r]) & m) | (__float_as_uint(NEG) & ~m));
+                        const int cx = c0 + 4 * g + r;
+                        const bool ok = r0 + t >= wi && r0 + t <= wi + MK - 1 && cx >= wj && cx <= wj + MK - 1;
+                        sacc[t][r] = ok ? sacc[t][r] : NEG;
                     }
-                }
             }
-            float red[14];                                                 // 40 -> 14 -> 5 -> 2 -> 1: 20 instructions, 4 deep
+#endif
+            // The maxima are inline assembly, and the compiler's hazard recogniser does not look inside it: a vector instruction that
+            // reads an MFMA's result fewer than 11 wait states after the MFMA's issue gets the register's OLD content (no hardware
+            // interlock) — hipcc had scheduled the v_max3 of tile t right behind the MFMA of tile t + 1, and the "maximum" was one of
+            // K-fragment bit patterns (harmless to the softmax while the logits are small, wrong all the same).  Every logit passes
+            // through this statement, which is the wait.
+            if constexpr (HR == 10)
+                asm volatile("s_nop 7\n\ts_nop 4" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(sacc[2]), "+v"(sacc[3]), "+v"(sacc[4]), "+v"(sacc[5]), "+v"(sacc[6]),
+                             "+v"(sacc[7]), "+v"(sacc[8]), "+v"(sacc[9]));
+            else
+                asm volatile("s_nop 7\n\ts_nop 4" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(sacc[2]), "+v"(sacc[3]), "+v"(sacc[4]), "+v"(sacc[5]), "+v"(sacc[6]),
+                             "+v"(sacc[7]));
+            static_assert(HR == 10 || HR == 8, "the wait above names every logit tile");
+            float lg[4 * HR];
 #pragma unroll
-            for (int i = 0; i < 13; ++i) {
-                const int a0 = 3 * i, a1 = 3 * i + 1, a2 = 3 * i + 2;
-                red[i] = max3(sacc[a0 >> 2][a0 & 3], sacc[a1 >> 2][a1 & 3], sacc[a2 >> 2][a2 & 3]);
-            }
-            red[13] = sacc[HR - 1][3];
-            const float m0 = max3(red[0], red[1], red[2]), m1 = max3(red[3], red[4], red[5]), m2 = max3(red[6], red[7], red[8]);
-            const float m3 = max3(red[9], red[10], red[11]), m4 = fmaxf(red[12], red[13]);
-            float mx = fmaxf(max3(m0, m1, m2), fmaxf(m3, m4));
+            for (int i = 0; i < 4 * HR; ++i) lg[i] = sacc[i >> 2][i & 3];
+            float mx = max_tree<4 * HR>(lg);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float nm = -mx * sl2;                                    // p = 2^((S' - max) * scale * log2 e): one multiply-add per logit
@@ -401,10 +460,10 @@ namespace {
 // per-tile kernel runs), the warm-up pass in front of a capture has normally met it already.  Nothing is allocated or freed per
 // launch, so a captured graph holds no allocation nodes of this kernel.
 struct DescKey {
-    int dev, B, H, W, Hr, Wr, heads, dil, padded;
+    int dev, B, H, W, Hr, Wr, heads, dil, padded, tqy;
     bool operator<(const DescKey& o) const {
-        const int a[9] = {dev, B, H, W, Hr, Wr, heads, dil, padded}, b[9] = {o.dev, o.B, o.H, o.W, o.Hr, o.Wr, o.heads, o.dil, o.padded};
-        for (int i = 0; i < 9; ++i)
+        const int a[10] = {dev, B, H, W, Hr, Wr, heads, dil, padded, tqy}, b[10] = {o.dev, o.B, o.H, o.W, o.Hr, o.Wr, o.heads, o.dil, o.padded, o.tqy};
+        for (int i = 0; i < 10; ++i)
             if (a[i] != b[i]) return a[i] < b[i];
         return false;
     }
@@ -422,7 +481,7 @@ const int* descriptors(const DescKey& k, int tiles_y, int tiles_x, long long tot
     int* d = nullptr;
     if (hipMalloc((void**)&d, (size_t)total * DESC * 4) != hipSuccess) return nullptr;
     hipLaunchKernelGGL(na2d_halo16_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d, k.heads, k.H, k.W, k.Hr, k.Wr, k.dil, tiles_y,
-                       tiles_x, (int)total, k.padded);
+                       tiles_x, (int)total, k.padded, k.tqy, 16 / k.tqy);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(d); return nullptr; }
     g_desc[k] = d;
     return d;
@@ -439,19 +498,27 @@ int na2d_halo16_launch(const void* qkv, const void* pad_kv, const float* rpb, vo
     const int Ws = pad_kv ? Wr : W;                                          // stored token grid
     // a piece's offset from its tile's halo origin, and a query's from its tile's, are 32-bit (bytes)
     if (items >= (1LL << 30) || heads > 255 || (long long)(HROWS + 2) * dil * Ws * 3 * heads * MHD * 2 >= (1LL << 31)) return -1;
-    static DeviceOnce attr;                                                  // per device, like the descriptor tables (DescKey.dev)
+    // the query block of a wave: 2 x 8 (8 key tiles) unless PPNET_NA_HALO_BLOCK=4x4 (10 key tiles; the round-3/4 form, kept for A/B)
+    static const bool blk44 = [] { const char* e = std::getenv("PPNET_NA_HALO_BLOCK"); return e && e[0] == '4'; }();
+    static DeviceOnce attr44, attr28;                                        // per device, like the descriptor tables (DescKey.dev)
     const int dev = current_device();
     if (dev < 0) return (int)hipErrorInvalidDevice;
     const int n_cu = device_cu_count() & ~7;
-    if (n_cu < 8 || dynamic_lds_once(attr, (const void*)na2d_halo16_kernel, LDS_TOTAL) != 0) return -1;
-    const int* desc = descriptors(DescKey{dev, B, H, W, Hr, Wr, heads, dil, pad_kv ? 1 : 0}, tiles_y, tiles_x, total, stream);
+    const void* fn = blk44 ? (const void*)na2d_halo16_kernel<4, 4> : (const void*)na2d_halo16_kernel<2, 8>;
+    const int lds = blk44 ? Blk<4, 4>::LDS_TOTAL : Blk<2, 8>::LDS_TOTAL;
+    if (n_cu < 8 || dynamic_lds_once(blk44 ? attr44 : attr28, fn, lds) != 0) return -1;
+    const int* desc = descriptors(DescKey{dev, B, H, W, Hr, Wr, heads, dil, pad_kv ? 1 : 0, blk44 ? 4 : 2}, tiles_y, tiles_x, total, stream);
     if (!desc) return -1;
     // whole XCD rows of workgroups, no more than the items of an XCD's run
     const long long per = (items + 7) / 8;
     int grid = n_cu;
     if (per * 8 < grid) grid = (int)per * 8;
-    hipLaunchKernelGGL(na2d_halo16_kernel, dim3(grid), dim3(NTHR), LDS_TOTAL, stream, (const __bf16*)qkv, (const __bf16*)pad_kv, (__bf16*)out, rpb, desc, Wr,
-                       Ws, heads, dil, scale, (int)items, (const __bf16*)zero);
+    if (blk44)
+        hipLaunchKernelGGL((na2d_halo16_kernel<4, 4>), dim3(grid), dim3(NTHR), lds, stream, (const __bf16*)qkv, (const __bf16*)pad_kv, (__bf16*)out, rpb, desc,
+                           Wr, Ws, heads, dil, scale, (int)items, (const __bf16*)zero);
+    else
+        hipLaunchKernelGGL((na2d_halo16_kernel<2, 8>), dim3(grid), dim3(NTHR), lds, stream, (const __bf16*)qkv, (const __bf16*)pad_kv, (__bf16*)out, rpb, desc,
+                           Wr, Ws, heads, dil, scale, (int)items, (const __bf16*)zero);
     return (int)hipGetLastError();
 }
 

@@ -505,8 +505,8 @@ def nat_mlp_(s2d, wpk, hb, b2, hidden, stats_out=None, eps=1e-5):
 
 
 def nat_partials(C):
-    """Row-statistics partials per row of a residual stream of width C (ppn_nat_gemm_partials: one per 128 columns on the small-tile
-    kernel that serves C <= 512, one per 256 on the persistent one)."""
+    """Row-statistics partials per row of a residual stream of width C (ppn_nat_gemm_partials: one per 128 columns up to
+    C = 256, one per 256 columns above — what the accumulating GEMM's epilogue emits and the LayerNorm-folding GEMM reads)."""
     n = L.lib.ppn_nat_gemm_partials(C)
     if n < 0:
         raise ValueError(f"ppn_nat_gemm_partials({C})")

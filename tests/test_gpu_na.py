@@ -90,10 +90,13 @@ def test_padded_grid_queries_only_real_tokens(dev, H, W, Hr, Wr, d, heads):
 
 @pytest.mark.parametrize("B,side,C,heads,d,pad", [(256, 64, 128, 4, 1, 0), (64, 56, 128, 4, 1, 0), (8, 32, 256, 8, 1, 0), (4, 40, 64, 2, 2, 0),
                                                   (3, 33, 64, 2, 1, 0), (2, 30, 64, 2, 2, 34)])
-def test_persistent_halo_kernel_is_bit_identical_to_the_per_tile_kernel(dev, B, side, C, heads, d, pad, monkeypatch):
-    """na2d_halo16_kernel (persistent, LDS-DMA staging, tile descriptors) computes block for block what na2d_mfma_kernel<16> does:
-    the outputs are EQUAL, at the bench's full size (256 x 64 x 64 x 4 heads), on partial tiles, dilation groups of unequal size
-    and virtual padding — a size-independent property the oracle is too slow to give."""
+def test_persistent_halo_kernel_against_the_per_tile_kernel(dev, B, side, C, heads, d, pad, monkeypatch):
+    """na2d_halo16_kernel (persistent, LDS-DMA staging, tile descriptors) against na2d_mfma_kernel<16> at the bench's full size
+    (256 x 64 x 64 x 4 heads), on partial tiles, dilation groups of unequal size and virtual padding — a size-independent property
+    the oracle is too slow to give.  With 4 x 4 query blocks (PPNET_NA_HALO_BLOCK=4x4) it computes block for block what the per-tile
+    kernel does and the outputs are EQUAL; with 2 x 8 blocks (the default) logits, maxima and probabilities are the same numbers
+    and only the float32 order of the 8 instead of 10 key tiles' sums differs: at most one bfloat16 step, on a few elements."""
+    import os
     import torch
     from ppnet_amd.na import na2d_forward
     torch.manual_seed(side + d)
@@ -105,7 +108,13 @@ def test_persistent_halo_kernel_is_bit_identical_to_the_per_tile_kernel(dev, B, 
     a = na2d_forward(qkv, rpb, heads, d, 32 ** -0.5, **kw)
     monkeypatch.setenv("PPNET_NA_HALO16", "0")
     b = na2d_forward(qkv, rpb, heads, d, 32 ** -0.5, **kw)
-    assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    assert torch.isfinite(a.float()).all()
+    if os.environ.get("PPNET_NA_HALO_BLOCK", "").startswith("4"):
+        assert torch.equal(a, b)
+    else:
+        af, bf = a.float(), b.float()
+        assert bool(((af - bf).abs() <= 2.0 ** -7 * bf.abs().clamp_min(2.0 ** -6)).all())          # one step of an 8-bit significand
+        assert float((a != b).float().mean()) < 1e-4
 
 
 def test_no_cpu_fallback():

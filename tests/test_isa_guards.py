@@ -108,3 +108,47 @@ def test_nat_mlp_no_lds_write_reaches_a_barrier_unwaited(tmp_path):
         assert not unwaited_write_reaches(b, set()), f"a ds_write reaches the s_barrier at instruction {b} without s_waitcnt lgkmcnt(0)"
     heads = [i for i in barriers if i > 0 and waits_lgkm0(body[i - 1])]
     assert len(heads) >= 8, (len(heads), len(barriers))
+
+
+def test_halo_attention_inline_asm_never_reads_a_fresh_mfma_result(tmp_path):
+    """na2d_halo16_kernel's row maxima are inline assembly (`v_max3_f32`, which unlike fmaxf does not canonicalise its operands
+    first).  The compiler's hazard recogniser does not look inside inline assembly, and gfx950 has no hardware interlock between an
+    XDL write and a VALU read: a v_max3 issued fewer than 11 wait states behind the v_mfma_f32_16x16x32_bf16 that writes one of its
+    sources reads the register's OLD content (round 5: hipcc had interleaved them, the maxima were K-fragment bit patterns — harmless
+    to the softmax only while the logits are small).  The kernel waits explicitly; this checks the emitted code, both block shapes."""
+    asm = _device_asm(tmp_path, "na2d_halo16.hip")
+    kernels = re.findall(r"^(_ZN3ppn18na2d_halo16_kernel\w*):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M)
+    assert len(kernels) == 2, [k for k, _ in kernels]
+
+    def regs(tok):
+        tok = tok.strip().rstrip(",")
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.fullmatch(r"v(\d+)", tok)
+        return {int(m.group(1))} if m else set()
+
+    for name, text in kernels:
+        since = {}                                                  # register -> wait states since the MFMA that last wrote it
+        checked = 0
+        for line in text.splitlines():
+            l = line.split(";")[0].strip()
+            if not l or l.endswith(":") or l.startswith("."):
+                continue
+            op, _, rest = l.partition(" ")
+            ops = [t for t in rest.split(",")] if rest else []
+            if op.startswith("v_max3_f32"):
+                for t in ops[1:]:
+                    for r in regs(t):
+                        assert since.get(r, 99) >= 11, (name, l, r, since.get(r))
+                checked += 1
+            step = int(rest) + 1 if op == "s_nop" else 1
+            for r in since:
+                since[r] += step
+            if op.startswith("v_mfma"):
+                for r in regs(ops[0]):
+                    since[r] = 0
+            elif op.startswith("v_") and ops:
+                for r in regs(ops[0]):
+                    since.pop(r, None)                              # rewritten by an ordinary instruction (the compiler's own hazards)
+        assert checked >= 10, (name, checked)
