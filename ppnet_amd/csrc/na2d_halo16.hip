@@ -16,7 +16,7 @@
 // launch neither allocates nor prepares anything (a captured HIP graph holds the kernel alone).
 //
 // LDS (138,752 B): 2 x { K image 22 x 24 slots x 64 B | V image (both with the 32-byte halves of a row swapped on every other
-// group of 4 slots: conflict-free fragment reads) | 4 zero slots } | BT, BTM 2 x 16 x 24 f32 of the workgroup's head.  The column pitch is 24 slots for 22 loaded: a block reads 16 slots from
+// group of 4 slots: conflict-free fragment reads) | 4 slots } | BT, BTM 2 x 16 x 24 f32 of the workgroup's head.  The column pitch is 24 slots for 22 loaded: a block reads 16 slots from
 // column co <= 12, so its last 4 run into the next halo row (the V image / the zero slots behind the last row) — finite values
 // whose logits carry the window mask, i.e. probability exactly 0.
 #include <hip/hip_runtime.h>
@@ -173,7 +173,7 @@ __device__ __forceinline__ Tile load_tile(const int* __restrict__ desc, int gtil
 template <int TQY, int TQX>
 __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pad_kv, __bf16* __restrict__ out,
                                                            const float* __restrict__ rpb, const int* __restrict__ desc, int Wr, int Ws, int heads,
-                                                           int dil, float scale, int n_items, const __bf16* __restrict__ zero) {
+                                                           int dil, float scale, int n_items) {
     typedef Blk<TQY, TQX> S;
     constexpr int HR = S::HR, BT_PITCH = S::BT_PITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char nl[];
@@ -192,8 +192,12 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
     int gtile = item / heads, h = item - gtile * heads;
     const int step_t = nx / heads, step_h = nx - step_t * heads;           // item + nx without a division per tile
 
-    // the 4 zero slots behind each V image (the bias reads of masked logits may reach back into the second one's)
-    if (threadIdx.x < 2 * TAIL / 4) reinterpret_cast<uint32_t*>(nl + (threadIdx.x >= TAIL / 4 ? BUF : 0) + 2 * IMG)[threadIdx.x & (TAIL / 4 - 1)] = 0u;
+    // Both tile buffers start as zeros, once: a slot that no piece of a tile covers — the 2 padding columns of the 24-slot pitch, the
+    // rows and columns beyond a border tile's halo extent, the 4 slots behind each V image — keeps what an EARLIER tile left there
+    // (or these zeros): finite K and V values whose logits carry the window mask, i.e. probability exactly 0.  Re-zeroing them per
+    // tile was a second pair of DMA instructions per piece (each ~60+ issue cycles) for lanes that are idle in the first.
+    for (int i = threadIdx.x; i < 2 * BUF / 16; i += NTHR) reinterpret_cast<uint4*>(nl)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();                                                       // ... before the first piece lands
 
     // ---- the tile-independent part of this lane's staging pieces.  Pair k = wave + 16 i covers slots 16 k .. 16 k + 15 of both
     // images, this lane the 16 bytes at position lane % 4 of slot 16 k + lane / 4 = halo row t, column sc.  Both images are stored with
@@ -216,9 +220,9 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
     const char* qkvb = reinterpret_cast<const char*>(qkv);
     const unsigned vofs = (unsigned)heads * MHD * 2;
 
-    // Every slot has a source — its token's row, the padded token (virtual padding: k / v = the qkv bias) or a line of zeros (beyond
-    // the halo extent; V must stay finite and K a number) — so each of the three classes is one DMA under its lanes' mask from a
-    // uniform base with a 32-bit lane offset: two compares per pair are all the vector work the staging of a tile costs
+    // A slot inside the tile's halo extent has a source — its token's row or the padded token (virtual padding: k / v = the qkv
+    // bias) — and each of the two classes is one DMA under its lanes' mask from a uniform base with a 32-bit lane offset: two compares
+    // per pair are all the vector work the staging of a tile costs.  Slots outside the extent are not written (see above).
     auto stage = [&](const Tile& T, unsigned buf) __attribute__((always_inline)) {
         if (!T.valid) return;
         const char* kbase = qkvb + T.kv + (unsigned)T.h * (MHD * 2);
@@ -240,9 +244,6 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
                     const char* pk = reinterpret_cast<const char*>(pad_kv) + (size_t)(heads + T.h) * (MHD * 2);
                     dma16(pk, c16, kl);
                     dma16(pk + vofs, c16, vl);
-                } else {
-                    dma16(zero, c16, kl);
-                    dma16(zero, c16, vl);
                 }
             }
         }
@@ -515,10 +516,10 @@ int na2d_halo16_launch(const void* qkv, const void* pad_kv, const float* rpb, vo
     if (per * 8 < grid) grid = (int)per * 8;
     if (blk44)
         hipLaunchKernelGGL((na2d_halo16_kernel<4, 4>), dim3(grid), dim3(NTHR), lds, stream, (const __bf16*)qkv, (const __bf16*)pad_kv, (__bf16*)out, rpb, desc,
-                           Wr, Ws, heads, dil, scale, (int)items, (const __bf16*)zero);
+                           Wr, Ws, heads, dil, scale, (int)items);
     else
         hipLaunchKernelGGL((na2d_halo16_kernel<2, 8>), dim3(grid), dim3(NTHR), lds, stream, (const __bf16*)qkv, (const __bf16*)pad_kv, (__bf16*)out, rpb, desc,
-                           Wr, Ws, heads, dil, scale, (int)items, (const __bf16*)zero);
+                           Wr, Ws, heads, dil, scale, (int)items);
     return (int)hipGetLastError();
 }
 
