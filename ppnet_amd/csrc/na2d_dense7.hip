@@ -31,12 +31,21 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int HD7 = 32, D7_WAVES = 8;
 }  // namespace
 
+namespace {
+__device__ __forceinline__ float d7_max3(float a, float b, float c) {     // (fmaxf would canonicalise every MFMA result first)
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+}  // namespace
+
 template <int G7>
-__global__ __launch_bounds__(64 * D7_WAVES, 6) void na2d_dense7_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pad_kv,
+__global__ __launch_bounds__(64 * D7_WAVES, 4) void na2d_dense7_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ pad_kv,
                                                                     const float* __restrict__ rpb, __bf16* __restrict__ out, int B, int Hr, int Wr,
-                                                                    int heads, int dil, float scale, long long n_items, const __bf16* __restrict__ zero) {
+                                                                    int heads, int dil, float scale, int n_items, const __bf16* __restrict__ zero) {
     constexpr int NK = G7 * G7;                                            // 49 or 64 key slots in use
     constexpr int TP = 68;                                                 // table row pitch in floats: 16 consecutive rows start on 16 different bank groups
+    constexpr bool FULL = G7 == 8;                                         // 8 x 8 groups: every slot is a stored token of every group
     __shared__ __attribute__((aligned(16))) unsigned char vimg_all[D7_WAVES][64 * 64];      // per wave: 64 key slots x 32 bf16 of V
     __shared__ __attribute__((aligned(16))) float tl[NK * TP];             // this workgroup's head of the bias / window table
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -47,12 +56,11 @@ __global__ __launch_bounds__(64 * D7_WAVES, 6) void na2d_dense7_kernel(const __b
     const unsigned char* qkvb = reinterpret_cast<const unsigned char*>(qkv);
     const unsigned char* padb = reinterpret_cast<const unsigned char*>(pad_kv);
     const unsigned char* zerob = reinterpret_cast<const unsigned char*>(zero);
-    // this lane's key slots (the same for every item): slot 16 t + j as the MFMA A row, slot p >> 2 for the V pieces
     // A workgroup keeps ONE head (its table rows live in LDS, read 4 x 16 bytes per query tile instead of 4 KB per item from
-    // L2) and walks groups four at a time, one per wave.  Workgroups w and w + 8 sit on the same XCD (round-robin dispatch) and
+    // L2) and walks groups eight at a time, one per wave.  Workgroups w and w + 8 sit on the same XCD (round-robin dispatch) and
     // take the same groups with neighbouring heads, so the two heads of a 128-byte line still meet in one L2.
     const int h = (int)((blockIdx.x >> 3) % heads);
-    const long long slot0 = (long long)(blockIdx.x / (8 * heads)) * 8 + (blockIdx.x & 7), nslots = (long long)(gridDim.x / (8 * heads)) * 8;
+    const int slot0 = (int)(blockIdx.x / (8 * heads)) * 8 + (blockIdx.x & 7), nslots = (int)(gridDim.x / (8 * heads)) * 8;
     // T[u * G + v][slot] = rpb[h][kr - u + 6][kc - v + 6] / scale (the units of the raw product: the table is the logits' initial
     // accumulator) for key slot = kr * G + kc inside the query's window (start clamp(u - 3, 0, G - 7) per axis: the whole group for
     // G = 7), -1e30 outside it and on slots >= G * G.  Built by the workgroup from its head's 169 values: nothing is prepared or
@@ -71,48 +79,93 @@ __global__ __launch_bounds__(64 * D7_WAVES, 6) void na2d_dense7_kernel(const __b
         }
     }
     __syncthreads();
-    for (long long gq = slot0; gq * D7_WAVES < n_items; gq += nslots) {
-        const long long grp = gq * D7_WAVES + wave;                          // n_items = number of (image, group) pairs
-        if (grp >= n_items) break;
-        const int gj = (int)(grp % dil);
-        const int gi = (int)((grp / dil) % dil);
-        const int b = (int)(grp / ((long long)dil * dil));
-        const int hq = gi < Hr ? (Hr - gi + dil - 1) / dil : 0, wq = gj < Wr ? (Wr - gj + dil - 1) / dil : 0;   // real rows / columns of the group
-        const int nq = hq * wq;
-        if (nq == 0) continue;                                               // a group of padding only: no queries (wave-uniform)
-        const uint32_t g0 = ((uint32_t)(b * Hr + gi) * Wr + gj) * tokb;      // the group's first token (wave-uniform)
-        const uint32_t rowb = (uint32_t)dil * Wr * tokb, colb = (uint32_t)dil * tokb;
-        const uint32_t kh = (uint32_t)(heads + h) * (HD7 * 2), vh = (uint32_t)(2 * heads + h) * (HD7 * 2);
 
-        // this lane's key slots, recomputed per item from an opaque copy of the lane id: as loop invariants they would pin eight
-        // registers, and this kernel's throughput is its occupancy (80 VGPRs = 6 waves per SIMD; a spill would put scratch traffic
-        // into the same in-order vmcnt queue as the loads below)
-        int lane_o = lane;
-        asm volatile("" : "+v"(lane_o));
-        const int j_o = lane_o & 15;
-        // K fragments: real token, padded token (the qkv bias: virtual padding) or a zero line (slots 49..63)
+    // ---- what of an item does not depend on the item (round 5: the counters said 308 vector and 171 scalar instructions per item,
+    // two thirds of them this bookkeeping recomputed per item — three 64-bit divisions for the item's (image, group row, group
+    // column), two 32-bit ones for its extent, eight slot decompositions with 64-bit pointer selects — and the kernel's time
+    // followed its instruction count, not its occupancy: 1, 2 or 3 resident workgroups per CU ran within 20 %).
+    // This lane's key slots: slot 16 t + j is its MFMA A row of key tile t, slot (64 it + lane) / 4 the V piece it copies in round it.
+    const uint32_t rowb = (uint32_t)dil * Wr * tokb, colb = (uint32_t)dil * tokb;
+    const uint32_t kh = (uint32_t)(heads + h) * (HD7 * 2), vh = (uint32_t)(2 * heads + h) * (HD7 * 2);
+    uint32_t offK[4], offV[4], geoK = 0, geoV = 0;                         // byte offset from the group's first token; (row | column << 4) per slot
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int kk = 16 * t + j, kr = kk < NK ? kk / G7 : 15, kc = kk < NK ? kk % G7 : 0;
+        offK[t] = (uint32_t)kr * rowb + (uint32_t)kc * colb + 16u * g;
+        geoK |= (uint32_t)(kr | (kc << 4)) << (8 * t);
+        const int vk = (t * 64 + lane) >> 2, vr = vk < NK ? vk / G7 : 15, vc = vk < NK ? vk % G7 : 0;
+        offV[t] = (uint32_t)vr * rowb + (uint32_t)vc * colb + 16u * (lane & 3);
+        geoV |= (uint32_t)(vr | (vc << 4)) << (8 * t);
+    }
+    // the padded token's K fragment (virtual padding: the qkv bias) — one per head, not one load per padded slot and item
+    bf16x8 kpad = {};
+    if (!FULL && padb) kpad = *reinterpret_cast<const bf16x8*>(padb + kh + 16 * g);
+    // items of this wave: grp = (slot0 + n * nslots) * 8 + wave; (image, group row, group column) advance by a constant step with
+    // carries instead of being divided out of grp per item
+    const int dd = dil * dil, stride = nslots * D7_WAVES;
+    int grp = slot0 * D7_WAVES + wave;
+    int b = grp / dd, gi = (grp - b * dd) / dil, gj = grp - b * dd - gi * dil;
+    const int sb = stride / dd, si = (stride - sb * dd) / dil, sj = stride - sb * dd - si * dil;
+    const int hq_base = Hr / dil, hq_rem = Hr - hq_base * dil, wq_base = Wr / dil, wq_rem = Wr - wq_base * dil;
+    int geo_hq = -1, geo_wq = -1;                                          // the extent the masks below and the V image's padding were made for
+    uint32_t realm = 0, qmagic = 0;                                        // bit t: K slot t is a stored token; bit 4 + it: V piece it
+
+    for (; grp < n_items; grp += stride) {
+        const int hq = FULL ? G7 : hq_base + (gi < hq_rem), wq = FULL ? G7 : wq_base + (gj < wq_rem);   // stored rows / columns of the group
+        const int nq = hq * wq;
+        const uint32_t g0 = ((uint32_t)(b * Hr + gi) * Wr + gj) * tokb;      // the group's first token (wave-uniform)
+        gj += sj;
+        { const int c = gj >= dil; gj -= c ? dil : 0; gi += si + c; }
+        { const int c = gi >= dil; gi -= c ? dil : 0; b += sb + c; }
+        if (nq == 0) continue;                                               // a group of padding only: no queries (wave-uniform)
+        const bool regeo = !FULL && (hq != geo_hq || wq != geo_wq);          // wave-uniform; false from the second item on unless the image
+        if (regeo) {                                                         // cuts groups unequally (Hr, Wr not multiples of the dilation)
+            geo_hq = hq; geo_wq = wq;
+            realm = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                realm |= (uint32_t)((int)((geoK >> (8 * t)) & 15) < hq && (int)((geoK >> (8 * t + 4)) & 15) < wq) << t;
+                realm |= (uint32_t)((int)((geoV >> (8 * t)) & 15) < hq && (int)((geoV >> (8 * t + 4)) & 15) < wq) << (4 + t);
+            }
+            qmagic = 65536u / (uint32_t)wq + 1u;                             // q / wq == (q * qmagic) >> 16 for q < 64
+        }
+        if (FULL) { realm = 0xffu; qmagic = 65536u / G7 + 1u; }
+        // K fragments: stored token, padded token (the qkv bias: virtual padding) or zeros (slots 49..63)
+        const unsigned char* gbase = qkvb + g0;                              // uniform base + 32-bit lane offset
         bf16x8 kf[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int kk = 16 * t + j_o, kr = kk < NK ? kk / G7 : 99, kc = kk % G7;       // row 99: beyond the group (slots 49..63)
-            const bool slot = kr < G7, real = kr < hq && kc < wq;
-            const unsigned char* src = real ? qkvb + (g0 + kr * rowb + kc * colb + kh) : ((slot && padb) ? padb + kh : zerob);
-            kf[t] = *reinterpret_cast<const bf16x8*>(src + 16 * g);
+            if (FULL) {
+                kf[t] = *reinterpret_cast<const bf16x8*>(gbase + kh + offK[t]);
+            } else {
+                const bool real = (realm >> t) & 1u;
+                const bf16x8 raw = *reinterpret_cast<const bf16x8*>(gbase + kh + (real ? offK[t] : 16u * g));     // (a lane without a token re-reads the first)
+                const bool slot = 16 * t + j < NK;
+                const bf16x8 other = slot ? kpad : bf16x8{};
+                kf[t] = real ? raw : other;
+            }
         }
-        // V rows -> LDS (piece p = slot * 4 + chunk lives at byte 16 p): four 1 KiB DMAs per wave
+        // V rows -> LDS (piece p = slot * 4 + chunk lives at byte 16 p): the stored tokens' pieces by LDS-DMA under their lanes' mask.
+        // The pieces of padded tokens and of slots 49..63 do not depend on the item while its extent is the previous item's: they are
+        // written when the extent changes (always for the first item) and left alone otherwise.
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int vk = (it * 64 + lane_o) >> 2, kr = vk < NK ? vk / G7 : 99, kc = vk % G7;
-            const bool slot = kr < G7, real = kr < hq && kc < wq;
-            const unsigned char* src = real ? qkvb + (g0 + kr * rowb + kc * colb + vh) : ((slot && padb) ? padb + vh : zerob);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * (lane & 3)),
-                                             (__attribute__((address_space(3))) void*)(vimg + it * 1024), 16, 0, 0);
+            const bool real = (realm >> (4 + it)) & 1u;
+            if (FULL || real)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + vh + offV[it]),
+                                                 (__attribute__((address_space(3))) void*)(vimg + it * 1024), 16, 0, 0);
+            else if (regeo) {
+                const bool slot = ((it * 64 + lane) >> 2) < NK;
+                const unsigned char* src = (slot && padb) ? padb + vh : zerob;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * (lane & 3)),
+                                                 (__attribute__((address_space(3))) void*)(vimg + it * 1024), 16, 0, 0);
+            }
         }
         for (int qt = 0; qt * 16 < nq; ++qt) {                               // 16 real queries at a time (one tile unless dilation 3)
             const int qq = qt * 16 + j;
             const bool qvalid = qq < nq;
             const int qc = qvalid ? qq : nq - 1;                             // dead columns shadow the last real query, never stored
-            const int u = qc / wq, v = qc - u * wq;
+            const int u = (int)(((uint32_t)qc * qmagic) >> 16), v = qc - u * wq;
             const uint32_t trow = g0 + u * rowb + v * colb;                  // byte offset of the query's token row
             const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qkvb + (trow + (uint32_t)h * (HD7 * 2) + 16 * g));
             // bias / window rows of this query's position in the group, from LDS
@@ -123,9 +176,13 @@ __global__ __launch_bounds__(64 * D7_WAVES, 6) void na2d_dense7_kernel(const __b
             for (int t = 0; t < 4; ++t) s[t] = *reinterpret_cast<const f32x4*>(tb + 16 * t);
 #pragma unroll
             for (int t = 0; t < 4; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, s[t], 0, 0, 0);
-            float mx = -3.0e38f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+            // the maxima are inline assembly (no canonicalisation of 16 MFMA results), which the compiler's hazard recogniser does not
+            // look into: an MFMA result read by a vector instruction fewer than 11 wait states behind the MFMA's issue is the
+            // register's OLD content.  Every logit passes through this statement, which is the wait (na2d_halo16.hip).
+            asm volatile("s_nop 7\n\ts_nop 4" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));
+            const float m0 = d7_max3(s[0][0], s[0][1], s[0][2]), m1 = d7_max3(s[0][3], s[1][0], s[1][1]), m2 = d7_max3(s[1][2], s[1][3], s[2][0]);
+            const float m3 = d7_max3(s[2][1], s[2][2], s[2][3]), m4 = d7_max3(s[3][0], s[3][1], s[3][2]);
+            float mx = d7_max3(d7_max3(m0, m1, m2), d7_max3(m3, m4, s[3][3]), m4);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float nm = -mx * sl2;                                      // p = 2^((S' - max) * scale * log2 e)
@@ -177,9 +234,18 @@ static int launch_dense_groups(const void* qkv, const void* pad_kv, const float*
     }
     // workgroups come in sets of 8 * heads (one head each, see the kernel): as many sets as fill the 3 workgroups (24 waves) a CU holds, at least one
     const long long per_set = 8LL * heads, want_sets = ((groups + D7_WAVES - 1) / D7_WAVES + 7) / 8;
-    long long sets = std::max<long long>(1, std::min<long long>(want_sets, ((long long)cus * 3) / per_set));
+    // as many sets as fill the workgroups a CU really holds (registers: 2 of the 7 x 7 form, 3 of the 8 x 8 one): a grid sized for
+    // more leaves a last, half-empty round of workgroups
+    static const int resident = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)na2d_dense7_kernel<G>, 64 * D7_WAVES, 0) != hipSuccess || n < 1) n = 2;
+        return n > 3 ? 3 : n;
+    }();
+    const char* occ_env = std::getenv("PPNET_D7_WG_PER_CU");                 // experiment: fewer resident workgroups per CU
+    const int wg_per_cu = occ_env && occ_env[0] >= '1' && occ_env[0] <= '3' ? std::min(resident, occ_env[0] - '0') : resident;
+    long long sets = std::max<long long>(1, std::min<long long>(want_sets, ((long long)cus * wg_per_cu) / per_set));
     hipLaunchKernelGGL(na2d_dense7_kernel<G>, dim3((unsigned)(sets * per_set)), dim3(64 * D7_WAVES), 0, stream, (const __bf16*)qkv, (const __bf16*)pad_kv,
-                       rpb, (__bf16*)out, B, Hr, Wr, heads, dil, scale, groups, zero);
+                       rpb, (__bf16*)out, B, Hr, Wr, heads, dil, scale, (int)groups, zero);
     return (int)hipGetLastError();
 }
 
@@ -193,7 +259,8 @@ int na2d_dense7_launch(const void* qkv, const void* pad_kv, const float* rpb, vo
     if (!g7 && !g8) return -2;
     const __bf16* zero = (const __bf16*)zero_line();
     if (!zero) return (int)hipErrorOutOfMemory;
-    if ((long long)B * dil * dil <= 0 || (long long)B * Hr * Wr * 3 * heads * HD7 * 2 >= (1LL << 32)) return -2;     // 32-bit byte offsets inside
+    if ((long long)B * dil * dil <= 0 || (long long)B * dil * dil >= (1LL << 30) || dil > 4096 ||
+        (long long)B * Hr * Wr * 3 * heads * HD7 * 2 >= (1LL << 32)) return -2;                   // 32-bit byte offsets and item numbers inside
     return g7 ? launch_dense_groups<7>(qkv, pad_kv, rpb, out, B, Hr, Wr, heads, dil, scale, zero, stream)
               : launch_dense_groups<8>(qkv, pad_kv, rpb, out, B, Hr, Wr, heads, dil, scale, zero, stream);
 }

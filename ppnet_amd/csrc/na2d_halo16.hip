@@ -500,7 +500,8 @@ int na2d_halo16_launch(const void* qkv, const void* pad_kv, const float* rpb, vo
     // a piece's offset from its tile's halo origin, and a query's from its tile's, are 32-bit (bytes)
     if (items >= (1LL << 30) || heads > 255 || (long long)(HROWS + 2) * dil * Ws * 3 * heads * MHD * 2 >= (1LL << 31)) return -1;
     // the query block of a wave: 2 x 8 (8 key tiles) unless PPNET_NA_HALO_BLOCK=4x4 (10 key tiles; the round-3/4 form, kept for A/B)
-    static const bool blk44 = [] { const char* e = std::getenv("PPNET_NA_HALO_BLOCK"); return e && e[0] == '4'; }();
+    const char* const blk_env = std::getenv("PPNET_NA_HALO_BLOCK");         // read per launch: tools alternate it inside one process
+    const bool blk44 = blk_env && blk_env[0] == '4';
     static DeviceOnce attr44, attr28;                                        // per device, like the descriptor tables (DescKey.dev)
     const int dev = current_device();
     if (dev < 0) return (int)hipErrorInvalidDevice;
