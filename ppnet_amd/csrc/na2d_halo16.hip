@@ -50,10 +50,20 @@ struct Blk {
     static constexpr int TQY = TQY_, TQX = TQX_;
     static constexpr int HR = TQY + MK - 1;              // key tiles (halo rows) per block
     static constexpr int NBY = RT / TQY, NBX = RT / TQX; // blocks of a tile
-    // bias tables: a lane reads columns (c0 - tj0 + 6) + 4g + r - jx, i.e. -(TQX - 1) .. 21: the tables start COL0 floats into a row;
-    // the pitch keeps the query rows of a block in disjoint banks (4 x 4: 16 addresses per row, 4 rows at 24; 2 x 8: 20, 2 rows at 32)
-    static constexpr int BT_PITCH = TQX == 4 ? 24 : 32, BT_COL0 = TQX == 4 ? 0 : 8;
-    static constexpr int TBL = 2 * BT_ROWS * BT_PITCH * 4;
+    // Bias tables, [row][column].  A lane reads row (r0 - ti0 + 6) + t - jy, columns (c0 - tj0 + 6) + 4g + r - jx, r = 0 .. 3: the
+    // (t, r) part is an immediate (consecutive r = consecutive words: ds_read2_b32 fills an accumulator's register pair in place),
+    // the (jy, jx, g) part the lane's own.  A 32-bit LDS read is banked (address / 4) mod 32 over the lane groups {0-31}, {32-63}
+    // (g = 0, 1 / 2, 3), so inside a group the lanes' parts must fall into different banks unless they are equal:
+    //   4 x 4: pitch 24 — 4 g - jx takes 8 values, the 4 query rows sit 24 = -8 banks apart;
+    //   2 x 8: pitch 48 — 4 g - jx takes 12 values, the 2 query rows sit 48 = 16 banks apart.  (Pitch 32 put both query rows of a
+    //          block into the same banks: 16.8 M conflict cycles per launch at 64 x 64, a third of the kernel's LDS time; a
+    //          transposed table at pitch 17 is conflict-free too, but hipcc pairs neighbouring words into ds_read2_b32 and then
+    //          moves 29 registers per block into place.)  Columns start BT_COL0 = 8 in: a lane's column index runs from -7.
+    static constexpr int BT_PITCH = TQX == 4 ? 24 : 48, BT_COL0 = TQX == 4 ? 0 : 8;
+    static constexpr int BT_SIZE = BT_ROWS * BT_PITCH;                   // floats per table
+    static constexpr int TBL = 2 * BT_SIZE * 4;
+    static __device__ __forceinline__ constexpr int bt_at(int a, int b) { return a * BT_PITCH + b + BT_COL0; }   // element (row a, column b)
+    static constexpr int BT_DROW = BT_PITCH, BT_DCOL = 1;
     static constexpr int LDS_TOTAL = 2 * BUF + TBL;      // two tiles | the head's two bias tables
     static_assert(TQY * TQX == 16 && HR % 2 == 0 && NBY * NBX == 16 && RT - TQX + 16 <= PC + 4 && TBL % 16 == 0, "block shape");
 };
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
                                                            const float* __restrict__ rpb, const int* __restrict__ desc, int Wr, int Ws, int heads,
                                                            int dil, float scale, int n_items) {
     typedef Blk<TQY, TQX> S;
-    constexpr int HR = S::HR, BT_PITCH = S::BT_PITCH;
+    constexpr int HR = S::HR;
     extern __shared__ __attribute__((aligned(16))) unsigned char nl[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;                                // MFMA column (query) and lane quarter
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
     const int ry = by * TQY + jy, rx = bx * TQX + jx;                      // the query's place in the tile
     const unsigned qoff_full = (unsigned)(ry * Ws + rx) * (unsigned)dil * tokb + 16u * g;             // B operand: channels 8g .. 8g+7 of query j
     const unsigned ooff_full = (unsigned)(ry * Wr + rx) * (unsigned)dil * (unsigned)(heads * MHD * 2) + 8u * g;
-    const int btl_full = (S::BT_COL0 - jy * BT_PITCH - jx + 4 * g) * 4;
+    const int btl_full = S::bt_at(-jy, -jx + 4 * g) * 4;
     // dead queries (a tile the image cuts) shadow a live one and are never stored
     auto q_request = [&](const Tile& T) __attribute__((always_inline)) -> bf16x8 {
         const int rmax = T.hq - 1 - T.ty0, cmax = T.wq - 1 - T.tx0;
@@ -270,11 +280,11 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
     // workgroup itself: its items are 32 apart (a multiple of every power-of-two head count), so the head changes rarely or never
     float* const BTL = reinterpret_cast<float*>(nl + 2 * BUF);
     auto build_tables = [&](int hh) __attribute__((always_inline)) {
-        if (threadIdx.x < 2 * BT_ROWS * BT_PITCH) {
-            const int which = threadIdx.x >= BT_ROWS * BT_PITCH, t = threadIdx.x - which * BT_ROWS * BT_PITCH;
-            const int a = t / BT_PITCH, b = t - a * BT_PITCH - S::BT_COL0;
+        for (int i = threadIdx.x; i < 2 * S::BT_SIZE; i += NTHR) {
+            const int which = i >= S::BT_SIZE, t = i - which * S::BT_SIZE;
+            const int a = t / S::BT_PITCH, b = t % S::BT_PITCH - S::BT_COL0;
             const float v = (a < 13 && b >= 0 && b < 13) ? rpb[(size_t)hh * 169 + a * 13 + b] / scale : 0.f;
-            BTL[threadIdx.x] = (which == 0 || (a >= MN && a <= 3 * MN && b >= MN && b <= 3 * MN)) ? v : -1.0e30f;
+            BTL[i] = (which == 0 || (a >= MN && a <= 3 * MN && b >= MN && b <= 3 * MN)) ? v : -1.0e30f;
         }
     };
     int h_tab = h;
@@ -341,13 +351,14 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
             // (wave-uniform) takes the table whose entries outside the centred 7 x 7 window are -1e30: bias and window mask are then
             // one function of the key's offset from the query (na2d_mfma.hip)
             const bool interior = (T.row & T.col & B_INT) != 0 && !cut;
-            const int bts = ((interior ? BT_ROWS * BT_PITCH : 0) + ((T.row >> 20) & 15) * BT_PITCH + ((T.col >> 20) & 15)) * 4;   // uniform
-            const int btl = cut ? (S::BT_COL0 - jyc * BT_PITCH - jxc + 4 * g) * 4 : btl_full;
+            const int bts = ((interior ? S::BT_SIZE : 0) + S::bt_at((T.row >> 20) & 15, (int)((T.col >> 20) & 15) - S::BT_COL0)) * 4;   // uniform
+            const int btl = cut ? S::bt_at(-jyc, -jxc + 4 * g) * 4 : btl_full;
             const float* bt = reinterpret_cast<const float*>(BT + bts + btl);
 #pragma unroll
             for (int t = 0; t < HR; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(kb + t * PC * KB);
 #pragma unroll
-            for (int t = 0; t < HR; ++t) sacc[t] = f32x4{bt[t * BT_PITCH], bt[t * BT_PITCH + 1], bt[t * BT_PITCH + 2], bt[t * BT_PITCH + 3]};
+            for (int t = 0; t < HR; ++t)
+                sacc[t] = f32x4{bt[t * S::BT_DROW], bt[t * S::BT_DROW + S::BT_DCOL], bt[t * S::BT_DROW + 2 * S::BT_DCOL], bt[t * S::BT_DROW + 3 * S::BT_DCOL]};
 #ifndef PPN_HALO_MASK_AFTER
             if (!interior) {
                 // Window mask, applied to the INITIAL accumulator like the interior table's (-1e30 + q.k is -1e30 in float32): one
