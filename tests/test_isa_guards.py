@@ -110,15 +110,16 @@ def test_nat_mlp_no_lds_write_reaches_a_barrier_unwaited(tmp_path):
     assert len(heads) >= 8, (len(heads), len(barriers))
 
 
-def test_halo_attention_inline_asm_never_reads_a_fresh_mfma_result(tmp_path):
-    """na2d_halo16_kernel's row maxima are inline assembly (`v_max3_f32`, which unlike fmaxf does not canonicalise its operands
+@pytest.mark.parametrize("src,kernel,instances", [("na2d_halo16.hip", r"_ZN3ppn18na2d_halo16_kernel", 2), ("na2d_dense7.hip", r"_ZN3ppn18na2d_dense7_kernel", 2)])
+def test_attention_inline_asm_never_reads_a_fresh_mfma_result(tmp_path, src, kernel, instances):
+    """na2d_halo16_kernel's and na2d_dense7_kernel's row maxima are inline assembly (`v_max3_f32`, which unlike fmaxf does not canonicalise its operands
     first).  The compiler's hazard recogniser does not look inside inline assembly, and gfx950 has no hardware interlock between an
     XDL write and a VALU read: a v_max3 issued fewer than 11 wait states behind the v_mfma_f32_16x16x32_bf16 that writes one of its
     sources reads the register's OLD content (round 5: hipcc had interleaved them, the maxima were K-fragment bit patterns — harmless
     to the softmax only while the logits are small).  The kernel waits explicitly; this checks the emitted code, both block shapes."""
-    asm = _device_asm(tmp_path, "na2d_halo16.hip")
-    kernels = re.findall(r"^(_ZN3ppn18na2d_halo16_kernel\w*):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M)
-    assert len(kernels) == 2, [k for k, _ in kernels]
+    asm = _device_asm(tmp_path, src)
+    kernels = re.findall(r"^(" + kernel + r"\w*):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M)
+    assert len(kernels) == instances, [k for k, _ in kernels]
 
     def regs(tok):
         tok = tok.strip().rstrip(",")
@@ -151,4 +152,4 @@ def test_halo_attention_inline_asm_never_reads_a_fresh_mfma_result(tmp_path):
             elif op.startswith("v_") and ops:
                 for r in regs(ops[0]):
                     since.pop(r, None)                              # rewritten by an ordinary instruction (the compiler's own hazards)
-        assert checked >= 10, (name, checked)
+        assert checked >= 6, (name, checked)
