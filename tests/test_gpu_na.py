@@ -117,6 +117,34 @@ def test_persistent_halo_kernel_against_the_per_tile_kernel(dev, B, side, C, hea
         assert float((a != b).float().mean()) < 1e-4
 
 
+@pytest.mark.parametrize("B,side,heads,d,pad", [(64, 56, 2, 8, 0), (48, 16, 2, 3, 21), (96, 32, 2, 4, 0), (40, 16, 4, 4, 28)])
+def test_dense_group_kernel_over_many_items_per_wave(dev, B, side, heads, d, pad, monkeypatch):
+    """na2d_dense7_kernel walks its (image, group) items with a constant stride and advances (image, group row, group column) by
+    carries instead of dividing them out per item (round 5), and rewrites a wave's padding pieces only when a group's extent changes:
+    sizes at which a wave takes several items (more groups than resident waves) with equal and with unequal extents (16 / 3: groups of
+    6 and 5 rows), against the halo / per-tile kernels on the same input (PPNET_NA_NO_DENSE7 is read per process: a child runs them)."""
+    import subprocess, sys, os, tempfile
+    import torch
+    from ppnet_amd.na import na2d_forward
+    C = heads * 32
+    torch.manual_seed(B + side + d)
+    qkv = torch.randn(B, side, side, 3 * C, device=dev, dtype=torch.bfloat16)
+    rpb = torch.randn(heads, 13, 13, device=dev)
+    pkv = torch.randn(3 * C, device=dev, dtype=torch.bfloat16)
+    kw = dict(pad_kv=pkv, padded_hw=(pad, pad)) if pad else {}
+    a = na2d_forward(qkv, rpb, heads, d, 32 ** -0.5, **kw).float().cpu()
+    with tempfile.TemporaryDirectory() as td:
+        torch.save({"qkv": qkv.cpu(), "rpb": rpb.cpu(), "pkv": pkv.cpu()}, os.path.join(td, "in.pt"))
+        code = ("import torch, sys; from ppnet_amd.na import na2d_forward; d = torch.load(sys.argv[1] + '/in.pt'); dev = torch.device('cuda', 0);"
+                f"kw = dict(pad_kv=d['pkv'].to(dev), padded_hw=({pad}, {pad})) if {pad} else dict();"
+                f"o = na2d_forward(d['qkv'].to(dev), d['rpb'].to(dev), {heads}, {d}, 32 ** -0.5, **kw); torch.save(o.float().cpu(), sys.argv[1] + '/out.pt')")
+        env = dict(os.environ, PPNET_NA_NO_DENSE7="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        subprocess.run([sys.executable, "-c", code, td], check=True, env=env, timeout=300)
+        b = torch.load(os.path.join(td, "out.pt"))
+    assert torch.isfinite(a).all() and a.shape == b.shape
+    assert float((a - b).abs().max()) < 3e-2 and float((a - b).pow(2).mean().sqrt()) < 2e-3
+
+
 def test_no_cpu_fallback():
     import torch
     from ppnet_amd import na
