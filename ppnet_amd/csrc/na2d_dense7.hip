@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64 * D7_WAVES, 4) void na2d_dense7_kernel(const __b
                 }
             }
             if (qvalid) {
-                const float inv = 1.0f / lsum[0];
+                const float inv = __builtin_amdgcn_rcpf(lsum[0]);   // (1 ulp; the result is rounded to bfloat16 next)
                 // the output row of a token is a third of its qkv row: byte offset trow / 3
                 unsigned char* dst = reinterpret_cast<unsigned char*>(out) + (trow / 3u + (uint32_t)h * (HD7 * 2) + 8 * g);
 #pragma unroll

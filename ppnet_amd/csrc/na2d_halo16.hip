@@ -449,7 +449,7 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
                 lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, lacc, 0, 0, 0);
             }
             if (qvalid) {
-                const float inv = 1.0f / lacc[0];
+                const float inv = __builtin_amdgcn_rcpf(lacc[0]);     // (1 ulp; the full division is 10 instructions for a value rounded to bfloat16 next)
                 char* dst = reinterpret_cast<char*>(out) + T.o + (unsigned)T.h * (MHD * 2) + ooff_full;
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(RT == 16 ? 512 : 256, RT == 16 ? 4 : 2) void na2d_m
             lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, lacc, 0, 0, 0);
         }
         if (qvalid) {
-            const float inv = 1.0f / lacc[0];
+            const float inv = __builtin_amdgcn_rcpf(lacc[0]);         // (1 ulp; as na2d_halo16.hip: the two kernels stay bit-equal)
             const int y = gi + u * dil, x = gj + v * dil;
             __bf16* dst = out + ((size_t)(b * Hr + y) * Wr + x) * ((size_t)heads * MHD) + (size_t)h * MHD;
 #pragma unroll
