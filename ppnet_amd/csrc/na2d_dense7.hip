@@ -183,8 +183,14 @@ __global__ __launch_bounds__(64 * D7_WAVES, 4) void na2d_dense7_kernel(const __b
             const float m0 = d7_max3(s[0][0], s[0][1], s[0][2]), m1 = d7_max3(s[0][3], s[1][0], s[1][1]), m2 = d7_max3(s[1][2], s[1][3], s[2][0]);
             const float m3 = d7_max3(s[2][1], s[2][2], s[2][3]), m4 = d7_max3(s[3][0], s[3][1], s[3][2]);
             float mx = d7_max3(d7_max3(m0, m1, m2), d7_max3(m3, m4, s[3][3]), m4);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            {   // the query's other three lane quarters (lane ^ 16, lane ^ 32) by register swaps: v_permlane16_swap / v_permlane32_swap
+                // of the value with itself leave it and its partner's — no trip through the LDS crossbar (ds_bpermute) in the
+                // chain every exponential waits for
+                auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+                t = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+            }
             const float nm = -mx * sl2;                                      // p = 2^((S' - max) * scale * log2 e)
 #pragma unroll
             for (int t = 0; t < 4; ++t)

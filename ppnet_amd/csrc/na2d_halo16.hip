@@ -411,8 +411,14 @@ __global__ __launch_bounds__(NTHR) void na2d_halo16_kernel(const __bf16* __restr
 #pragma unroll
             for (int i = 0; i < 4 * HR; ++i) lg[i] = sacc[i >> 2][i & 3];
             float mx = max_tree<4 * HR>(lg);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            {   // the query's other three lane quarters (lane ^ 16, lane ^ 32) by register swaps: v_permlane16_swap / v_permlane32_swap
+                // of the value with itself leave it and its partner's — no trip through the LDS crossbar (ds_bpermute) in the
+                // chain every exponential waits for
+                auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+                t = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+            }
             const float nm = -mx * sl2;                                    // p = 2^((S' - max) * scale * log2 e): one multiply-add per logit
 #pragma unroll
             for (int t = 0; t < HR; ++t)
